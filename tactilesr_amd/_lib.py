@@ -1,0 +1,80 @@
+"""ctypes binding of libtactilesr_hip.so (the C ABI declared in include/tactilesr_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, the
+product raises.  Nothing here imports from ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_int, c_void_p, c_float, c_longlong
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtactilesr_hip.so")
+ABI_VERSION = 1
+
+_P, _I, _F, _L = c_void_p, c_int, c_float, c_longlong
+
+# name -> argtypes; must list every symbol include/tactilesr_hip.h declares
+SIGNATURES = {
+    "tsr_abi_version": [],
+    "tsr_pack_conv_weight": [_P, _P, _I, _I, _I, _P],
+    "tsr_conv2d_fwd": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "tsr_stem_fwd": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "tsr_head_fwd": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _P],
+    "tsr_nchw_to_cb16": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "tsr_cb16_to_nchw": [_P, _P, _I, _I, _I, _I, _I, _P],
+}
+
+_lib = None
+
+
+class TactileSRHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TactileSRHipError(
+            f"{LIB_PATH} not found: build it with `python -m tactilesr_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    v = lib.tsr_abi_version()
+    if v != ABI_VERSION:
+        raise TactileSRHipError(f"libtactilesr_hip.so ABI {v} != expected {ABI_VERSION}: rebuild")
+    _lib = lib
+    return lib
+
+
+def ptr(t) -> c_void_p:
+    """Device pointer of a tensor (None -> NULL).  Tensors must be CUDA fp32/int contiguous."""
+    if t is None:
+        return c_void_p(0)
+    if not t.is_cuda:
+        raise TactileSRHipError("tactilesr_amd kernels need CUDA (ROCm) tensors; got a CPU tensor "
+                                "(there is no CPU fallback)")
+    if not t.is_contiguous():
+        raise TactileSRHipError("non-contiguous tensor passed to a HIP kernel")
+    return c_void_p(t.data_ptr())
+
+
+def stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_ERR = {1: "bad argument", 2: "kernel launch failure"}
+
+
+def call(name: str, *args) -> None:
+    st = getattr(load(), name)(*args)
+    if st != 0:
+        raise TactileSRHipError(f"{name} failed: status {st} ({_ERR.get(st, 'unknown')})")

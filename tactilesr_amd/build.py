@@ -1,0 +1,66 @@
+"""Build libtactilesr_hip.so in-tree with hipcc for gfx950 (no torch linkage).
+
+    python -m tactilesr_amd.build          # incremental
+    python -m tactilesr_amd.build --force
+
+The .so is git-ignored but travels with the gpurun snapshot; nothing is JIT-built at
+import time on the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "libtactilesr_hip.so")
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+         "-I", CSRC, "-I", os.path.join(os.path.dirname(HERE), "include")]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _newer(path, deps):
+    if not os.path.exists(path):
+        return True
+    t = os.path.getmtime(path)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    jobs = []
+    objs = []
+    for src in _sources():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJDIR, src[:-4] + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + headers):
+            jobs.append([HIPCC, *FLAGS, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print("[build]", " ".join(cmd[-4:]), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        return r
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if jobs or force or _newer(LIB, objs):
+        run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,235 @@
+// Boundary kernels of TactileSR.forward: the taxel stem and the image head.
+//
+//  * tsr_stem_fwd: nn.Upsample(scale_factor, bilinear, align_corners=False) + Conv2d(
+//    axisCnt -> 64, 3x3, pad 1, no bias) + [BatchNorm eval as scale/shift] + ReLU
+//    (model/tactileSR_model.py:34-39 pattern stem, :59-63 force stem).  The upsampled
+//    image is never written to HBM: a row band is rebuilt in LDS from the 4x4 taxels.
+//    Reads NCHW taxels (48 floats / sample), writes CB16.  HBM-write bound.
+//  * tsr_head_fwd: Conv2d(C -> 1, 3x3, pad 1, no bias) + ReLU (model/tactileSR_model.py:
+//    55-56); the trailing F.interpolate to the same size (:83) is an exact identity and
+//    is elided.  Reads CB16, writes the NCHW (B,1,H,W) result.  HBM-read bound.
+//  * layout converters NCHW <-> CB16 (test / probe plumbing).
+#include "tsr_common.h"
+
+// ATen upsample_bilinear2d (align_corners=False) source index.
+__device__ __forceinline__ void bilin_src(int dst, float scale, int n_in, int& i0, int& i1, float& lam) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  i0 = i0 < n_in - 1 ? i0 : n_in - 1;
+  i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
+  lam = src - (float)i0;
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ lr, int lr_ctot, int lr_coff,
+                                                   int hin, int win, int sf,
+                                                   const float* __restrict__ w,      // OIHW (64,CIN,3,3)
+                                                   const float* __restrict__ scale,
+                                                   const float* __restrict__ shift,
+                                                   float* __restrict__ out, int out_ctot, int out_coff,
+                                                   int relu, int B, int RB) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = hin * sf, W = win * sf;
+  const int WP = W + 2;
+  float* wl = smem;                       // [9*CIN][64]
+  float* tax = wl + 9 * CIN * 64;         // [CIN][hin*win]
+  float* up = tax + ((CIN * hin * win + 3) & ~3);  // [CIN][RB+2][WP]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int y0 = blockIdx.x * RB;
+  const int rows = (H - y0) < RB ? (H - y0) : RB;
+
+  for (int i = tid; i < 9 * CIN * 64; i += 256) {
+    const int n = i & 63, kc = i >> 6;         // kc = tap*CIN + c
+    const int tap = kc / CIN, c = kc - tap * CIN;
+    wl[i] = w[(n * CIN + c) * 9 + tap];
+  }
+  for (int i = tid; i < CIN * hin * win; i += 256)
+    tax[i] = lr[((size_t)b * lr_ctot + lr_coff) * hin * win + i];
+  __syncthreads();
+
+  const float sc = 1.0f / (float)sf;
+  const int nup = CIN * (RB + 2) * WP;
+  for (int i = tid; i < nup; i += 256) {
+    const int c = i / ((RB + 2) * WP);
+    const int rem = i - c * ((RB + 2) * WP);
+    const int yy = rem / WP, xx = rem - yy * WP;
+    const int gy = y0 - 1 + yy, gx = xx - 1;
+    float v = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      int ya, yb, xa, xb;
+      float ly, lx;
+      bilin_src(gy, sc, hin, ya, yb, ly);
+      bilin_src(gx, sc, win, xa, xb, lx);
+      const float* t = tax + c * hin * win;
+      const float top = (1.f - lx) * t[ya * win + xa] + lx * t[ya * win + xb];
+      const float bot = (1.f - lx) * t[yb * win + xa] + lx * t[yb * win + xb];
+      v = (1.f - ly) * top + ly * bot;
+    }
+    up[i] = v;
+  }
+  __syncthreads();
+
+  const int HW = H * W;
+  const int npix = rows * W;
+  const int out_blocks = out_ctot >> 4;
+  for (int it = tid; it < npix * 4; it += 256) {
+    const int blk = it / npix, p = it - blk * npix;
+    const int y = p / W, x = p - y * W;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+          const float u = up[(c * (RB + 2) + y + kh) * WP + x + kw];
+          const f32x4* wr = (const f32x4*)(wl + ((kh * 3 + kw) * CIN + c) * 64 + blk * 16);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 wv = wr[q];
+            acc[4 * q + 0] = fmaf(u, wv[0], acc[4 * q + 0]);
+            acc[4 * q + 1] = fmaf(u, wv[1], acc[4 * q + 1]);
+            acc[4 * q + 2] = fmaf(u, wv[2], acc[4 * q + 2]);
+            acc[4 * q + 3] = fmaf(u, wv[3], acc[4 * q + 3]);
+          }
+        }
+    const int oc = out_coff + blk * 16;
+    float* o = out + (((size_t)b * out_blocks + (oc >> 4)) * HW + (size_t)(y0 + y) * W + x) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = blk * 16 + 4 * q + j;
+        float t = acc[4 * q + j] * (scale ? scale[n] : 1.f) + (shift ? shift[n] : 0.f);
+        v[j] = relu ? fmaxf(t, 0.f) : t;
+      }
+      ((f32x4*)o)[q] = v;
+    }
+  }
+}
+
+extern "C" int tsr_stem_fwd(const float* lr, int lr_ctot, int lr_coff, int axis_cnt, int hin, int win, int sf,
+                            const float* w_oihw, const float* scale, const float* shift,
+                            float* out, int out_ctot, int out_coff, int relu, int B, void* stream) {
+  if (!lr || !w_oihw || !out || B <= 0 || axis_cnt != 3 || hin <= 0 || win <= 0 || sf <= 0) return TSR_ERR_ARG;
+  if ((out_ctot & 15) || (out_coff & 15) || out_coff + 64 > out_ctot || lr_coff + axis_cnt > lr_ctot)
+    return TSR_ERR_ARG;
+  const int H = hin * sf, W = win * sf;
+  const int RB = 8;
+  const size_t smem = (size_t)(9 * 3 * 64 + ((3 * hin * win + 3) & ~3) + 3 * (RB + 2) * (W + 2)) * 4;
+  if (smem > 64 * 1024) return TSR_ERR_ARG;
+  dim3 grid((H + RB - 1) / RB, B);
+  hipLaunchKernelGGL((stem_kernel<3>), grid, dim3(256), smem, (hipStream_t)stream, lr, lr_ctot, lr_coff, hin,
+                     win, sf, w_oihw, scale, shift, out, out_ctot, out_coff, relu, B, RB);
+  return tsr_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ in, int in_ctot, int cin,
+                                                   const float* __restrict__ w,   // OIHW (1,cin,3,3)
+                                                   float* __restrict__ out, int relu, int B, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // [cin/16][9][16]
+  const int tid = threadIdx.x;
+  const int nblk = cin >> 4;
+  for (int i = tid; i < nblk * 9 * 16; i += 256) {
+    const int j = i & 15, r = i >> 4;
+    const int tap = r % 9, blk = r / 9;
+    wl[i] = w[(blk * 16 + j) * 9 + tap];
+  }
+  __syncthreads();
+  const int HW = H * W;
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + tid;
+  if (p >= HW) return;
+  const int y = p / W, x = p - y * W;
+  const int in_blocks = in_ctot >> 4;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int blk = 0; blk < nblk; ++blk) {
+    const float* plane = in + ((size_t)b * in_blocks + blk) * HW * 16;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int gy = y + kh - 1;
+      if (gy < 0 || gy >= H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int gx = x + kw - 1;
+        if (gx < 0 || gx >= W) continue;
+        const f32x4* src = (const f32x4*)(plane + (size_t)(gy * W + gx) * 16);
+        const f32x4* wr = (const f32x4*)(wl + (blk * 9 + kh * 3 + kw) * 16);
+        const f32x4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+        const f32x4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a0 = fmaf(v0[j], w0[j], a0);
+          a1 = fmaf(v1[j], w1[j], a1);
+          a2 = fmaf(v2[j], w2[j], a2);
+          a3 = fmaf(v3[j], w3[j], a3);
+        }
+      }
+    }
+  }
+  float v = (a0 + a1) + (a2 + a3);
+  if (relu) v = fmaxf(v, 0.f);
+  out[(size_t)b * HW + p] = v;
+}
+
+extern "C" int tsr_head_fwd(const float* in, int in_ctot, int cin, const float* w_oihw, float* out_nchw,
+                            int relu, int B, int H, int W, void* stream) {
+  if (!in || !w_oihw || !out_nchw || B <= 0 || (cin & 15) || (in_ctot & 15) || cin > in_ctot || cin <= 0)
+    return TSR_ERR_ARG;
+  dim3 grid((H * W + 255) / 256, B);
+  const size_t smem = (size_t)cin * 9 * 4;
+  hipLaunchKernelGGL(head_kernel, grid, dim3(256), smem, (hipStream_t)stream, in, in_ctot, cin, w_oihw,
+                     out_nchw, relu, B, H, W);
+  return tsr_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ void nchw_to_cb16_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW,
+                                    int dst_ctot, int dst_coff, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int pix = i % HW;
+    size_t r = i / HW;
+    const int c = r % C;
+    const int b = r / C;
+    dst[cb16_index(b, dst_coff + c, pix, dst_ctot, HW)] = src[i];
+  }
+}
+
+__global__ void cb16_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW,
+                                    int src_ctot, int src_coff, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int pix = i % HW;
+    size_t r = i / HW;
+    const int c = r % C;
+    const int b = r / C;
+    dst[i] = src[cb16_index(b, src_coff + c, pix, src_ctot, HW)];
+  }
+}
+
+extern "C" int tsr_nchw_to_cb16(const float* src, float* dst, int B, int C, int HW, int dst_ctot,
+                                int dst_coff, void* stream) {
+  if (!src || !dst || (dst_ctot & 15) || dst_coff + C > dst_ctot) return TSR_ERR_ARG;
+  const size_t total = (size_t)B * C * HW;
+  const size_t g = (total + 255) / 256;
+  hipLaunchKernelGGL(nchw_to_cb16_kernel, dim3(g > 65535 ? 65535 : (int)g), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, C, HW, dst_ctot, dst_coff, total);
+  return tsr_check_launch();
+}
+
+extern "C" int tsr_cb16_to_nchw(const float* src, float* dst, int B, int C, int HW, int src_ctot,
+                                int src_coff, void* stream) {
+  if (!src || !dst || (src_ctot & 15) || src_coff + C > src_ctot) return TSR_ERR_ARG;
+  const size_t total = (size_t)B * C * HW;
+  const size_t g = (total + 255) / 256;
+  hipLaunchKernelGGL(cb16_to_nchw_kernel, dim3(g > 65535 ? 65535 : (int)g), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, C, HW, src_ctot, src_coff, total);
+  return tsr_check_launch();
+}

@@ -1,0 +1,30 @@
+// Shared device/host helpers for the tactileSR HIP kernels (gfx950 / MI355X only).
+//
+// Internal activation layout "CB16": float act[B][C/16][H*W][16]
+//   - channel-blocked NHWC: the 16 channels of one block are contiguous (64 B), the
+//     pixels of one (image, block) plane are contiguous, so a conv workgroup stages a
+//     [halo rows][halo cols][16] slab with fully coalesced 16-B loads and an MFMA A
+//     fragment (4 consecutive channels of one pixel) is a single ds_read_b128.
+//   - boundary tensors (LR taxels in, SR image out) stay NCHW as the reference's
+//     callers hand them over (train/tactileSR_train.py:43-47).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TSR_CB 16   // channel block
+
+#define TSR_OK 0
+#define TSR_ERR_ARG 1
+#define TSR_ERR_LAUNCH 2
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int tsr_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? TSR_OK : TSR_ERR_LAUNCH;
+}
+
+__device__ __forceinline__ size_t cb16_index(int b, int c, int pix, int C, int HW) {
+  return (((size_t)b * (C >> 4) + (c >> 4)) * HW + pix) * 16 + (c & 15);
+}

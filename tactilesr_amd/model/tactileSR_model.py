@@ -1,0 +1,313 @@
+"""MI355X-native drop-in for the reference's ``model/tactileSR_model.py``.
+
+Same public surface as the reference classes -- ``TactileSR(scale_factor, seqsCnt,
+axisCnt, patternFeatureExtraLayerCnt, forceFeatureExtraLayerCnt)``, ``MSRB``,
+``ResBlock``; same attribute names, submodule names, ``state_dict`` keys (205 for
+T=1) and construction-time RNG consumption (so ``torch.manual_seed(s); TactileSR()``
+yields bit-identical initial weights; /root/reference/model/tactileSR_model.py:22-65,
+92-98,161-194,217-220) -- but ``forward`` never touches ATen convolution: it drives
+the hand-written HIP kernels of ``libtactilesr_hip.so`` through the C ABI of
+``include/tactilesr_hip.h``.  The nn.Conv2d / nn.BatchNorm2d children are parameter
+containers only.  There is no CPU fallback: CPU tensors or a missing library raise.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .._lib import call, ptr, stream
+
+_I = _lib.c_int
+
+
+def _conv_bn_relu(cin: int, cout: int, k: int, bias: bool) -> nn.Sequential:
+    return nn.Sequential(nn.Conv2d(cin, cout, k, padding=k // 2, bias=bias), nn.BatchNorm2d(cout), nn.ReLU(True))
+
+
+def _reference_init(root: nn.Module) -> None:
+    """Kaiming-normal(fan_out, relu) on every conv weight (biases keep their default
+    init), BN gamma = beta = 0.1; reference model/tactileSR_model.py:92-98,208-214."""
+    for m in root.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.constant_(m.weight, 0.1)
+            nn.init.constant_(m.bias, 0.1)
+
+
+class MSRB(nn.Module):
+    """Multi-scale residual block container (reference model/tactileSR_model.py:157-214):
+    {3x3,5x5}@64 -> cat128 -> {3x3,5x5}@128 -> cat256 -> 1x1 -> +x -> ReLU."""
+
+    def __init__(self, n_feats: int = 64):
+        super().__init__()
+        self.conv_3_1 = _conv_bn_relu(n_feats, n_feats, 3, True)
+        self.conv_5_1 = _conv_bn_relu(n_feats, n_feats, 5, True)
+        self.conv_3_2 = _conv_bn_relu(2 * n_feats, 2 * n_feats, 3, True)
+        self.conv_5_2 = _conv_bn_relu(2 * n_feats, 2 * n_feats, 5, True)
+        self.confusion = nn.Conv2d(4 * n_feats, n_feats, 1, padding=0, stride=1)
+        self.relu = nn.ReLU(inplace=True)
+        _reference_init(self)
+
+    def forward(self, x):  # pragma: no cover - the fused engine runs whole networks
+        raise _lib.TactileSRHipError("MSRB is executed by TactileSR's fused HIP engine, not standalone")
+
+
+class ResBlock(nn.Module):
+    """relu(x + conv2(relu(conv1(x)))) container (reference model/tactileSR_model.py:216-225)."""
+
+    def __init__(self, n_feats: int = 64):
+        super().__init__()
+        self.conv1 = nn.Conv2d(n_feats, n_feats, kernel_size=3, padding=1)
+        self.conv2 = nn.Conv2d(n_feats, n_feats, kernel_size=3, padding=1)
+
+    def forward(self, x):  # pragma: no cover
+        raise _lib.TactileSRHipError("ResBlock is executed by TactileSR's fused HIP engine, not standalone")
+
+
+class _PackedConv:
+    """Device-side constants of one conv launch: packed weight, folded scale/shift."""
+    __slots__ = ("w", "scale", "shift", "cin", "cout", "ks")
+
+    def __init__(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d]):
+        w = conv.weight.detach().float().contiguous()
+        self.cout, self.cin, self.ks = w.shape[0], w.shape[1], w.shape[2]
+        self.w = torch.empty_like(w)
+        call("tsr_pack_conv_weight", ptr(w), ptr(self.w), _I(self.cout), _I(self.cin), _I(self.ks), stream())
+        self.scale, self.shift = _fold(conv.bias, bn, self.cout, w.device)
+
+
+def _fold(bias, bn: Optional[nn.BatchNorm2d], cout: int, device):
+    """Eval-mode BatchNorm2d folded onto the conv output: y = conv*scale + shift with
+    scale = gamma/sqrt(var+eps), shift = (bias-mean)*scale + beta."""
+    if bn is None:
+        if bias is None:
+            return None, None
+        return None, bias.detach().float().contiguous()
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    b = bias.detach().float() if bias is not None else torch.zeros(cout, device=device)
+    shift = (b - bn.running_mean.detach().float()) * scale + bn.bias.detach().float()
+    return scale.contiguous(), shift.contiguous()
+
+
+class TactileSR(nn.Module):
+    """STSR / MTSR taxel super-resolution network on MI355X.
+
+    ``model(LR)`` with LR ``(B, seqsCnt*axisCnt, 4, 4)`` fp32 on a ROCm device returns
+    ``(B, 1, 4*scale_factor, 4*scale_factor)``, numerically equal (<=1e-5 relative) to
+    the reference forward (model/tactileSR_model.py:67-84).
+    """
+
+    def __init__(self, scale_factor=10, seqsCnt=1, axisCnt=3, patternFeatureExtraLayerCnt=6,
+                 forceFeatureExtraLayerCnt=1):
+        super().__init__()
+        self.taxel_cnt = 4
+        self.scale_factor = scale_factor
+        self.seqsCnt = seqsCnt
+        self.axisCnt = axisCnt
+
+        # construction order == RNG order of the reference (blocks first, then stems)
+        self.patternFeatureExtra_layer = self.make_layer(MSRB, patternFeatureExtraLayerCnt)
+        self.forceFeatureExtra_layer = self.make_layer(ResBlock, forceFeatureExtraLayerCnt)
+        self.inputLayer_pattern_list = nn.ModuleList()
+        for _ in range(seqsCnt):
+            self.inputLayer_pattern_list.append(nn.Sequential(
+                nn.Upsample(scale_factor=scale_factor, mode="bilinear", align_corners=False),
+                nn.Conv2d(axisCnt, 64, 3, padding=1, bias=False), nn.BatchNorm2d(64), nn.ReLU(True),
+                nn.Conv2d(64, 64, 3, padding=1, bias=False), nn.BatchNorm2d(64), nn.ReLU(True)))
+        self.inputContact_layer = nn.Sequential(
+            nn.Conv2d(seqsCnt * 64, 64, 3, padding=1, bias=False), nn.BatchNorm2d(64), nn.ReLU(True))
+        self.output_layer = nn.Sequential(
+            nn.Conv2d(128, 128, 3, padding=1, bias=False), nn.ReLU(True),
+            nn.Conv2d(128, 1, 3, padding=1, bias=False), nn.ReLU(True))
+        self.input_layer_force = nn.Sequential(
+            nn.Upsample(scale_factor=scale_factor, mode="bilinear", align_corners=False),
+            nn.Conv2d(axisCnt, 64, 3, padding=1, bias=False), nn.ReLU(True))
+        self._init_network()
+        self._plan = None
+        self._plan_key = None
+        self.max_images_per_pass = 4096   # workspace bound: ~6.6 MB of CB16 activations per image
+
+    def make_layer(self, block, num_of_layer):
+        return nn.Sequential(*[block() for _ in range(num_of_layer)])
+
+    def _init_network(self):
+        _reference_init(self)
+
+    # ------------------------------------------------------------------ engine
+    def _param_key(self):
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    def _build_plan(self):
+        """Pack weights / fold eval-mode BN once per parameter version."""
+        plan: Dict[str, object] = {}
+        stems = []
+        for seq in self.inputLayer_pattern_list:
+            s1, sh1 = _fold(None, seq[2], 64, seq[1].weight.device)
+            stems.append((seq[1].weight.detach().float().contiguous(), s1, sh1, _PackedConv(seq[4], seq[5])))
+        plan["stems"] = stems
+        plan["fuse"] = _PackedConv(self.inputContact_layer[0], self.inputContact_layer[1])
+        msrbs = []
+        for blk in self.patternFeatureExtra_layer:
+            msrbs.append((_PackedConv(blk.conv_3_1[0], blk.conv_3_1[1]), _PackedConv(blk.conv_5_1[0], blk.conv_5_1[1]),
+                          _PackedConv(blk.conv_3_2[0], blk.conv_3_2[1]), _PackedConv(blk.conv_5_2[0], blk.conv_5_2[1]),
+                          _PackedConv(blk.confusion, None)))
+        plan["msrb"] = msrbs
+        plan["force_w"] = self.input_layer_force[1].weight.detach().float().contiguous()
+        plan["res"] = [(_PackedConv(b.conv1, None), _PackedConv(b.conv2, None)) for b in self.forceFeatureExtra_layer]
+        plan["head0"] = _PackedConv(self.output_layer[0], None)
+        plan["head_w"] = self.output_layer[2].weight.detach().float().contiguous()
+        return plan
+
+    def _get_plan(self):
+        key = self._param_key()
+        if self._plan is None or key != self._plan_key:
+            self._plan = self._build_plan()
+            self._plan_key = key
+        return self._plan
+
+    @staticmethod
+    def _conv(pc: _PackedConv, src, s_ctot, s_coff, dst, d_ctot, d_coff, relu, B, H, W, res=None, r_ctot=0, r_coff=0):
+        call("tsr_conv2d_fwd", ptr(src), _I(s_ctot), _I(s_coff), _I(pc.cin), ptr(pc.w), _I(pc.cout), _I(pc.ks),
+             ptr(pc.scale), ptr(pc.shift), ptr(res), _I(r_ctot), _I(r_coff),
+             ptr(dst), _I(d_ctot), _I(d_coff), _I(1 if relu else 0), _I(B), _I(H), _I(W), stream())
+
+    def _infer_pass(self, x: torch.Tensor, out: torch.Tensor, stages=None) -> None:
+        """Eval-mode forward of one batch slice; mirrors reference forward :67-84."""
+        plan = self._get_plan()
+        B, hin, win = x.shape[0], x.shape[2], x.shape[3]
+        sf, T, A = self.scale_factor, self.seqsCnt, self.axisCnt
+        H, W = hin * sf, win * sf
+        HW = H * W
+        dev = x.device
+
+        def buf(c):
+            return torch.empty(B * c * HW, dtype=torch.float32, device=dev)
+
+        ctot = x.shape[1]
+        stemA, catT = buf(64), buf(64 * T)
+        for t, (w1, s1, sh1, pc2) in enumerate(plan["stems"]):
+            call("tsr_stem_fwd", ptr(x), _I(ctot), _I(A * t), _I(A), _I(hin), _I(win), _I(sf), ptr(w1), ptr(s1),
+                 ptr(sh1), ptr(stemA), _I(64), _I(0), _I(1), _I(B), stream())
+            self._conv(pc2, stemA, 64, 0, catT, 64 * T, 64 * t, True, B, H, W)
+        xa, xb = buf(64), buf(64)
+        self._conv(plan["fuse"], catT, 64 * T, 0, xa, 64, 0, True, B, H, W)
+        if stages is not None:
+            stages["stems"] = (catT, 64 * T)
+            stages["fuse"] = (xa.clone(), 64)
+        del stemA
+        hcat = buf(128)
+        cat1, cat2 = buf(128), buf(256)
+        n_msrb = len(plan["msrb"])
+        cur = xa
+        if n_msrb == 0:
+            call("tsr_cb16_to_nchw", ptr(xa), ptr(xb), _I(B), _I(64), _I(HW), _I(64), _I(0), stream())
+            call("tsr_nchw_to_cb16", ptr(xb), ptr(hcat), _I(B), _I(64), _I(HW), _I(128), _I(64), stream())
+        for i, (c31, c51, c32, c52, conf) in enumerate(plan["msrb"]):
+            last = i == n_msrb - 1
+            self._conv(c31, cur, 64, 0, cat1, 128, 0, True, B, H, W)
+            self._conv(c51, cur, 64, 0, cat1, 128, 64, True, B, H, W)
+            self._conv(c32, cat1, 128, 0, cat2, 256, 0, True, B, H, W)
+            self._conv(c52, cat1, 128, 0, cat2, 256, 128, True, B, H, W)
+            nxt = xb if cur is xa else xa
+            if last:   # pattern feature lands in channels [64,128) of the head input (cat: force first)
+                self._conv(conf, cat2, 256, 0, hcat, 128, 64, True, B, H, W, res=cur, r_ctot=64, r_coff=0)
+            else:
+                self._conv(conf, cat2, 256, 0, nxt, 64, 0, True, B, H, W, res=cur, r_ctot=64, r_coff=0)
+                cur = nxt
+            if stages is not None:
+                stages[f"msrb{i}"] = (hcat.clone(), 128, 64) if last else (cur.clone(), 64, 0)
+        del cat1, cat2
+        # force branch
+        f0, f1 = buf(64), buf(64)
+        call("tsr_stem_fwd", ptr(x), _I(ctot), _I(0), _I(A), _I(hin), _I(win), _I(sf), ptr(plan["force_w"]),
+             ptr(None), ptr(None), ptr(f0), _I(64), _I(0), _I(1), _I(B), stream())
+        if stages is not None:
+            stages["force_in"] = (f0.clone(), 64, 0)
+        n_res = len(plan["res"])
+        if n_res == 0:
+            call("tsr_cb16_to_nchw", ptr(f0), ptr(f1), _I(B), _I(64), _I(HW), _I(64), _I(0), stream())
+            call("tsr_nchw_to_cb16", ptr(f1), ptr(hcat), _I(B), _I(64), _I(HW), _I(128), _I(0), stream())
+        f2 = buf(64) if n_res > 1 else None
+        curf = f0
+        for i, (c1, c2) in enumerate(plan["res"]):
+            last = i == n_res - 1
+            self._conv(c1, curf, 64, 0, f1, 64, 0, True, B, H, W)
+            if last:
+                self._conv(c2, f1, 64, 0, hcat, 128, 0, True, B, H, W, res=curf, r_ctot=64, r_coff=0)
+            else:
+                nxt = f2 if curf is f0 else f0
+                self._conv(c2, f1, 64, 0, nxt, 64, 0, True, B, H, W, res=curf, r_ctot=64, r_coff=0)
+                curf = nxt
+        h0 = buf(128)
+        self._conv(plan["head0"], hcat, 128, 0, h0, 128, 0, True, B, H, W)
+        if stages is not None:
+            stages["force"] = (hcat, 128, 0)
+            stages["head0"] = (h0, 128, 0)
+        call("tsr_head_fwd", ptr(h0), _I(128), _I(128), ptr(plan["head_w"]), ptr(out), _I(1), _I(B), _I(H), _I(W),
+             stream())
+
+    def forward(self, x):
+        assert x.shape[1] == self.seqsCnt * self.axisCnt, "input channel should be same with seqsCnt x axisCnt!"
+        if not x.is_cuda:
+            raise _lib.TactileSRHipError("TactileSR (tactilesr_amd) runs on MI355X only: move the model and "
+                                         "its input to a ROCm device (no CPU fallback)")
+        if self.training:
+            raise _lib.TactileSRHipError("train-mode forward (batch-statistics BatchNorm + backward) is not "
+                                         "built yet in this round; call model.eval() for inference")
+        x = x.detach().float().contiguous()
+        B = x.shape[0]
+        H, W = x.shape[2] * self.scale_factor, x.shape[3] * self.scale_factor
+        out = torch.empty(B, 1, H, W, dtype=torch.float32, device=x.device)
+        step = max(2, int(self.max_images_per_pass))
+        for b0 in range(0, B, step):
+            b1 = min(B, b0 + step)
+            self._infer_pass(x[b0:b1], out[b0:b1])
+        return out
+
+    @torch.no_grad()
+    def forward_with_stages(self, x):
+        """Eval forward that also returns named intermediate activations converted to
+        NCHW (parity probes against the oracle's ``stages``)."""
+        assert not self.training
+        x = x.detach().float().contiguous()
+        B = x.shape[0]
+        H, W = x.shape[2] * self.scale_factor, x.shape[3] * self.scale_factor
+        out = torch.empty(B, 1, H, W, dtype=torch.float32, device=x.device)
+        raw = {}
+        self._infer_pass(x, out, raw)
+        stages = {}
+        for name, spec in raw.items():
+            if name == "stems":
+                t, ctot = spec
+                for i in range(self.seqsCnt):
+                    stages[f"stem{i}"] = _to_nchw(t, B, 64, H * W, ctot, 64 * i).view(B, 64, H, W)
+                continue
+            t, ctot = spec[0], spec[1]
+            coff = spec[2] if len(spec) > 2 else 0
+            c = 64 if name != "head0" else 128
+            stages[name] = _to_nchw(t, B, c, H * W, ctot, coff).view(B, c, H, W)
+        return out, stages
+
+
+def _to_nchw(t, B, C, HW, ctot, coff):
+    dst = torch.empty(B * C * HW, dtype=torch.float32, device=t.device)
+    call("tsr_cb16_to_nchw", ptr(t), ptr(dst), _I(B), _I(C), _I(HW), _I(ctot), _I(coff), stream())
+    return dst
+
+
+def to_cb16(x: torch.Tensor, ctot: Optional[int] = None, coff: int = 0, dst: Optional[torch.Tensor] = None):
+    """NCHW (B,C,H,W) -> CB16 flat buffer (test plumbing)."""
+    B, C, H, W = x.shape
+    ctot = ctot or C
+    if dst is None:
+        dst = torch.zeros(B * ctot * H * W, dtype=torch.float32, device=x.device)
+    call("tsr_nchw_to_cb16", ptr(x.contiguous()), ptr(dst), _I(B), _I(C), _I(H * W), _I(ctot), _I(coff), stream())
+    return dst
+
+
+def from_cb16(t: torch.Tensor, B, C, H, W, ctot: Optional[int] = None, coff: int = 0):
+    return _to_nchw(t, B, C, H * W, ctot or C, coff).view(B, C, H, W)

@@ -128,17 +128,25 @@ def gen_eval():
             y = m(LR)
         for h in hs:
             h.remove()
+        # fp64 run of the same reference module: the conditioning yardstick (how far the
+        # reference's own fp32 CPU result is from exact arithmetic on these inputs)
+        with torch.no_grad():
+            y64 = m.double()(LR.double())
+        m.float()
+        out[f"{tag}/ref32_vs_f64"] = np.float64(((y.double() - y64).abs().max() / y64.abs().max()).item())
         out[f"{tag}/seed"] = np.int64(seed)
         out[f"{tag}/sha256"] = np.array(sd_hash(sd))
         out[f"{tag}/LR"] = LR.numpy()
         if tag == "sf25t8":
             flat(f"{tag}/out", probe(y), out)
             out[f"{tag}/out_full0"] = y[0, 0, ::2, ::2].numpy()
+            out[f"{tag}/out64_full0"] = y64[0, 0, ::2, ::2].numpy()
         else:
             out[f"{tag}/out"] = y.numpy()
+            out[f"{tag}/out64"] = y64.numpy()
         for name, t in stages.items():
             flat(f"{tag}/stage/{name}", probe(t), out)
-        print(tag, "out", tuple(y.shape), float(y.abs().max()))
+        print(tag, "out", tuple(y.shape), float(y.abs().max()), "ref32_vs_f64", out[f"{tag}/ref32_vs_f64"])
     np.savez_compressed(os.path.join(HERE, "eval.npz"), **out)
 
 

@@ -1,0 +1,194 @@
+"""GPU parity tests proper (run with -m gpu on an MI355X): every HIP entry point is
+called through the C ABI and compared with the CPU oracle / golden fixtures.
+Tolerance (north_star): 1e-5 relative fp32, measured as max|y-ref| / max|ref| per tensor."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import tactilesr_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def T():
+    import tactilesr_amd
+    from tactilesr_amd import _lib
+    from tactilesr_amd.model import tactileSR_model as M
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    _lib.load()
+    return M
+
+
+CONV_CASES = [
+    # ks, cin, cout, B, H, W, scale/shift, residual, relu
+    (3, 64, 64, 2, 40, 40, True, False, True),
+    (5, 64, 64, 3, 40, 40, True, False, True),
+    (3, 128, 128, 2, 40, 40, True, False, True),
+    (5, 128, 128, 1, 40, 40, True, False, True),
+    (1, 256, 64, 3, 40, 40, True, True, True),
+    (3, 64, 64, 2, 40, 40, False, True, True),
+    (3, 128, 128, 2, 40, 40, False, False, False),
+    (3, 448, 64, 1, 40, 40, True, False, True),     # T=7 fuse conv
+    (5, 16, 64, 5, 13, 21, True, True, False),      # ragged spatial, odd batch, one block
+    (3, 32, 128, 1, 100, 100, True, False, True),   # sf=25 image size (partial tiles)
+    (1, 64, 128, 2, 8, 8, False, False, False),
+]
+
+
+@pytest.mark.parametrize("ks,cin,cout,B,H,W,affine,residual,relu", CONV_CASES)
+def test_conv2d_fwd(T, ks, cin, cout, B, H, W, affine, residual, relu):
+    from tactilesr_amd._lib import call, ptr, stream, c_int as I
+    g = torch.Generator().manual_seed(ks * 1000 + cin + cout + B)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) * (2.0 / (cout * ks * ks)) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5 if affine else None
+    shift = torch.randn(cout, generator=g) * 0.3 if affine else None
+    res = torch.randn(B, cout, H, W, generator=g) if residual else None
+    ref = F.conv2d(x, w, None, padding=ks // 2)
+    if affine:
+        ref = ref * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if residual:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    # write into a channel slice of a wider buffer to exercise ctot/coff (cat elision)
+    out_ctot, out_coff = cout + 32, 16
+    in_ctot, in_coff = cin + 16, 16
+    dev = "cuda"
+    xin = T.to_cb16(x.to(dev), in_ctot, in_coff)
+    wp = torch.empty_like(w, device=dev)
+    wd = w.to(dev).contiguous()
+    call("tsr_pack_conv_weight", ptr(wd), ptr(wp), I(cout), I(cin), I(ks), stream())
+    out = torch.full((B * out_ctot * H * W,), float("nan"), device=dev)
+    rbuf = T.to_cb16(res.to(dev), cout + 16, 16) if residual else None
+    sc = scale.to(dev) if affine else None
+    sh = shift.to(dev) if affine else None
+    call("tsr_conv2d_fwd", ptr(xin), I(in_ctot), I(in_coff), I(cin), ptr(wp), I(cout), I(ks), ptr(sc), ptr(sh),
+         ptr(rbuf), I(cout + 16 if residual else 0), I(16 if residual else 0), ptr(out), I(out_ctot), I(out_coff),
+         I(int(relu)), I(B), I(H), I(W), stream())
+    got = T.from_cb16(out, B, cout, H, W, out_ctot, out_coff)
+    assert relerr(got, ref) < TOL
+    # channels outside the slice must be untouched
+    guard = T.from_cb16(out, B, 16, H, W, out_ctot, 0)
+    assert torch.isnan(guard).all()
+
+
+@pytest.mark.parametrize("sf,B,coff,ctot", [(10, 3, 0, 3), (10, 2, 3, 21), (25, 2, 0, 3)])
+def test_stem_fwd(T, sf, B, coff, ctot):
+    from tactilesr_amd._lib import call, ptr, stream, c_int as I
+    g = torch.Generator().manual_seed(sf + B)
+    lr = torch.rand(B, ctot, 4, 4, generator=g) * 8
+    w = torch.randn(64, 3, 3, 3, generator=g) * 0.2
+    scale = torch.rand(64, generator=g) + 0.5
+    shift = torch.randn(64, generator=g) * 0.3
+    up = O.bilinear_resize(lr[:, coff:coff + 3], (4 * sf, 4 * sf))
+    ref = F.relu(F.conv2d(up, w, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    H = W = 4 * sf
+    out = torch.zeros(B * 64 * H * W, device="cuda")
+    lr_d, w_d, sc_d, sh_d = lr.cuda(), w.cuda(), scale.cuda(), shift.cuda()   # keep alive across the launch
+    call("tsr_stem_fwd", ptr(lr_d), I(ctot), I(coff), I(3), I(4), I(4), I(sf), ptr(w_d),
+         ptr(sc_d), ptr(sh_d), ptr(out), I(64), I(0), I(1), I(B), stream())
+    assert relerr(T.from_cb16(out, B, 64, H, W), ref) < TOL
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 40, 40), (1, 100, 100), (3, 9, 17)])
+def test_head_fwd(T, B, H, W):
+    from tactilesr_amd._lib import call, ptr, stream, c_int as I
+    g = torch.Generator().manual_seed(B + H)
+    x = torch.randn(B, 128, H, W, generator=g)
+    w = torch.randn(1, 128, 3, 3, generator=g) * 0.05
+    ref = F.relu(F.conv2d(x, w, padding=1))
+    out = torch.zeros(B, 1, H, W, device="cuda")
+    x_d, w_d = T.to_cb16(x.cuda()), w.cuda()
+    call("tsr_head_fwd", ptr(x_d), I(128), I(128), ptr(w_d), ptr(out), I(1), I(B), I(H), I(W), stream())
+    assert relerr(out, ref) < TOL
+
+
+GOLD_CFG = {"t1": dict(), "t7": dict(seqsCnt=7), "sf25t8": dict(scale_factor=25, seqsCnt=8),
+            "t1_l2": dict(patternFeatureExtraLayerCnt=2)}
+
+
+def probe(t):
+    cs = max(1, t.shape[1] // 4)
+    return t[:, ::cs, ::3, ::3].contiguous()
+
+
+@pytest.mark.parametrize("tag", ["t1", "t1_l2", "t7", "sf25t8"])
+def test_model_eval_forward_vs_reference_golden(T, golden, tag):
+    """HIP eval forward vs outputs of the reference itself (tests/golden/eval.npz)."""
+    g = golden("eval")
+    cfg = GOLD_CFG[tag]
+    sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), int(g[f"{tag}/seed"]))
+    m = T.TactileSR(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    LR = torch.from_numpy(g[f"{tag}/LR"]).cuda()
+    y, stages = m.forward_with_stages(LR)
+    for name, t in stages.items():
+        ref = torch.from_numpy(g[f"{tag}/stage/{name}/probe"])
+        assert relerr(probe(t), ref) < TOL, name
+    # Final image: compare with the reference's fp32 CPU output AND with the reference run
+    # in fp64.  The fixture records how far the reference's own fp32 result is from fp64 on
+    # these inputs (2e-6..5e-6: randomised BN gains make the last conv cancellation-heavy);
+    # two fp32 evaluations may differ by the sum of their errors, so the bar is
+    # max(1e-5, 4 x that yardstick) against ref32 and the same against fp64.
+    yard = float(g[f"{tag}/ref32_vs_f64"])
+    tol = max(TOL, 4 * yard)
+    if tag == "sf25t8":
+        e32 = relerr(y[0, 0, ::2, ::2], torch.from_numpy(g[f"{tag}/out_full0"]))
+        e64 = relerr(y[0, 0, ::2, ::2], torch.from_numpy(g[f"{tag}/out64_full0"]))
+    else:
+        e32 = relerr(y, torch.from_numpy(g[f"{tag}/out"]))
+        e64 = relerr(y, torch.from_numpy(g[f"{tag}/out64"]))
+    print(f"[parity] {tag}: hip-vs-ref32 {e32:.2e}  hip-vs-f64 {e64:.2e}  ref32-vs-f64 {yard:.2e}")
+    assert e32 < tol and e64 < tol
+    y2 = m(LR)
+    assert torch.equal(y, y2)
+
+
+def test_model_eval_forward_vs_oracle_odd_batch(T):
+    """Fresh seeded input, odd batch (image-pair tail), seeded reference init + trained-like BN stats."""
+    torch.manual_seed(42)
+    m = T.TactileSR()
+    sd = m.state_dict()
+    g = torch.Generator().manual_seed(7)
+    for k in sd:
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.05
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(sd[k].shape, generator=g) * 0.5 + 0.75
+    m.load_state_dict(sd)
+    LR = torch.rand(5, 3, 4, 4, generator=g) * 8
+    with torch.no_grad():
+        ref = O.tactilesr_forward({k: v.clone() for k, v in sd.items()}, LR)
+    y = m.cuda().eval()(LR.cuda())
+    assert relerr(y, ref) < TOL
+    # weights changed in place -> plan must be rebuilt
+    with torch.no_grad():
+        m.output_layer[2].weight.mul_(2.0)
+    y3 = m(LR.cuda())
+    assert relerr(y3, ref * 2) < TOL
+
+
+def test_model_chunked_batch_and_linearity_property(T):
+    """Size-independent properties at a larger batch: chunked passes equal a single pass,
+    permuting the batch permutes the output (samples are independent in eval mode)."""
+    torch.manual_seed(1)
+    m = T.TactileSR(patternFeatureExtraLayerCnt=1).cuda().eval()
+    LR = torch.rand(67, 3, 4, 4, device="cuda") * 8
+    y = m(LR)
+    m.max_images_per_pass = 16
+    y2 = m(LR)
+    assert torch.equal(y, y2)
+    perm = torch.randperm(67, device="cuda")
+    y3 = m(LR[perm])
+    assert relerr(y3, y[perm]) < 1e-6
