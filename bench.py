@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Headline benchmark: TactileSR 4x4 -> 40x40 SR samples/s on MI355X (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (configs[1] of BASELINE.json): `tactileSR_model batch=4096 fp32 on 1xMI355X`:
+one step = one eval-mode forward of TactileSR(scale_factor=10, seqsCnt=1) over a
+synthetic batch of 4096 taxel frames per GPU, inputs resident in HBM, fp32 MFMA.
+N>1: one process per GPU (torch.distributed / RCCL rendezvous); inference shards by
+sample with no data-path collective ("weak" scaling, 4096 frames per GPU).
+
+One JSON line on rank 0 carries the contract fields plus
+  roofline     - the dominant kernel (5x5 128->128 conv, 54 % of all FLOPs), timed live
+                 with HIP events on the launch stream inside the timed region;
+  cpu_baseline - the CPU oracle (a port of the reference's torch CPU path) on the host
+                 cores, bounded sample (config[0]: B=32), rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FWD_FLOP_PER_SAMPLE = 14_642_380_800          # SURVEY.md section 8(d), sf=10, T=1, direct conv
+C5_FLOP_PER_SAMPLE = 2 * 1600 * 128 * 128 * 25  # one 5x5 128->128 conv launch, per sample
+PEAK_F32_MFMA = 157.3e12                      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+LAYER_BYTES_PER_SAMPLE = 48.38e6              # SURVEY.md section 8(d), layer-wise fp32 bytes
+
+
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/rNN_pmc_summary.json, made by tools/summarize_prof.py: separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 FETCH x2 correction).  PMC
+    counters cannot be read from inside the process, so bench.py cites the latest pass."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    for k, v in d.items():
+        if kernel_substr in k and "hbm_bytes_per_launch" in v:
+            return v["hbm_bytes_per_launch"], os.path.relpath(files[-1], REPO)
+    return None, None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import tactilesr_amd
+    torch.manual_seed(42)
+    model = tactilesr_amd.TactileSR().to(dev).eval()
+    B = args.batch
+    model.max_images_per_pass = B
+    g = torch.Generator().manual_seed(42 + rank)
+    LR = (torch.rand(B, 3, 4, 4, generator=g) * 8).to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model(LR)
+    barrier()
+    model._profile = {}          # HIP-event brackets around every conv launch, keyed (ks, cout)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = model(LR)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = model._profile
+    model._profile = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total = B * world * args.steps
+        value = total / dt
+        ev = prof.get((5, 128), [])
+        c5_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
+        achieved = B * C5_FLOP_PER_SAMPLE / (c5_ms * 1e-3) / 1e12 if ev else None
+        per_kernel = {f"conv{k[0]}x{k[0]}_c{k[1]}": round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 3)
+                      for k, v in sorted(prof.items())}
+        traffic, traffic_src = pmc_traffic("conv_mfma_f32_kernel<5, 128>") if B == 4096 else (None, None)
+        res = {
+            "metric": "SR samples/sec (4x4->40x40)", "value": round(value, 2), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "tactileSR_model eval forward 4x4->40x40, batch=4096/GPU fp32 (BASELINE configs[1])",
+                       "batch_per_gpu": B, "scale_factor": 10, "seqsCnt": 1, "parallelism": f"replicas x{world}"},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_f32_kernel<5,128> (5x5 128->128 conv+BN+ReLU)",
+                         "achieved": round(achieved, 2) if achieved else None, "peak": PEAK_F32_MFMA / 1e12,
+                         "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_F32_MFMA, 4) if achieved else None,
+                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": B * (2 * 128 * 1600 * 4) + 128 * 128 * 25 * 4,
+                         "avg_launch_ms": round(c5_ms, 3), "launches_timed": len(ev)},
+            "whole_step": {"tflops": round(value / world * FWD_FLOP_PER_SAMPLE / 1e12, 2),
+                           "frac_of_f32_mfma_peak": round(value / world * FWD_FLOP_PER_SAMPLE / PEAK_F32_MFMA, 4),
+                           "layerwise_GBps": round(value / world * LAYER_BYTES_PER_SAMPLE / 1e9, 1),
+                           "ms_per_step_by_kernel": per_kernel},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res.update(cpu_baseline_and_psnr(model, dev))
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline_and_psnr(model, dev):
+    """Oracle (port of the reference's CPU path) timed on the host cores on a bounded
+    sample -- BASELINE configs[0]: eval forward, B=32 fp32 -- and used as the checker for
+    'PSNR vs ref' of the HIP output on the same frames."""
+    from oracle import tactilesr_oracle as O
+    # the GPU box exposes all host cores but a 1-GPU job's CPU share is 16 of them
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(16, avail))
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(42)
+    LR = torch.rand(32, 3, 4, 4, generator=g) * 8
+    with torch.no_grad():
+        ref = O.tactilesr_forward(sd, LR)      # warm-up
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            ref = O.tactilesr_forward(sd, LR)
+            ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    y = model(LR.to(dev)).cpu()
+    err = float((y - ref).abs().max() / ref.abs().max())
+    psnr = [float(O.calculation_psnr(y[i, 0], ref[i, 0], 250.0 / 10)) for i in range(y.shape[0])
+            if float(((y[i] - ref[i]) ** 2).sum()) > 0]
+    return {
+        "cpu_baseline": {"value": round(32 / med, 2), "unit": "samples/s", "cores": torch.get_num_threads(),
+                         "kind": "port", "sample": "oracle eval forward, B=32 fp32, median of 5 (BASELINE configs[0])"},
+        "parity": {"max_rel_err_vs_oracle": err, "psnr_vs_ref_db_min": round(min(psnr), 2) if psnr else None,
+                   "frames": 32},
+    }
+
+
+if __name__ == "__main__":
+    main()

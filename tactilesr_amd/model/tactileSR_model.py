@@ -129,6 +129,7 @@ class TactileSR(nn.Module):
         self._init_network()
         self._plan = None
         self._plan_key = None
+        self._profile = None
         self.max_images_per_pass = 4096   # workspace bound: ~6.6 MB of CB16 activations per image
 
     def make_layer(self, block, num_of_layer):
@@ -169,11 +170,18 @@ class TactileSR(nn.Module):
             self._plan_key = key
         return self._plan
 
-    @staticmethod
-    def _conv(pc: _PackedConv, src, s_ctot, s_coff, dst, d_ctot, d_coff, relu, B, H, W, res=None, r_ctot=0, r_coff=0):
+    def _conv(self, pc: _PackedConv, src, s_ctot, s_coff, dst, d_ctot, d_coff, relu, B, H, W, res=None, r_ctot=0,
+              r_coff=0):
+        prof = self._profile
+        if prof is not None:     # bench.py: HIP-event bracket on the launch stream, per kernel instantiation
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         call("tsr_conv2d_fwd", ptr(src), _I(s_ctot), _I(s_coff), _I(pc.cin), ptr(pc.w), _I(pc.cout), _I(pc.ks),
              ptr(pc.scale), ptr(pc.shift), ptr(res), _I(r_ctot), _I(r_coff),
              ptr(dst), _I(d_ctot), _I(d_coff), _I(1 if relu else 0), _I(B), _I(H), _I(W), stream())
+        if prof is not None:
+            e1.record()
+            prof.setdefault((pc.ks, pc.cout), []).append((e0, e1))
 
     def _infer_pass(self, x: torch.Tensor, out: torch.Tensor, stages=None) -> None:
         """Eval-mode forward of one batch slice; mirrors reference forward :67-84."""
