@@ -67,6 +67,98 @@ int tsr_stem_fwd(const float* lr, int lr_ctot, int lr_coff, int axis_cnt, int hi
 int tsr_head_fwd(const float* in, int in_ctot, int cin, const float* w_oihw, float* out_nchw,
                  int relu, int B, int H, int W, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Training path (train/tactileSR_train.py:41-51 -> cpu/trainer.py:346-362): train-mode
+ * BatchNorm, convolution_backward (dgrad = tsr_conv2d_ex with tsr_pack_conv_weight_dgrad
+ * weights, wgrad = tsr_conv2d_wgrad), MSE, Adam.
+ * ------------------------------------------------------------------------------------- */
+
+/* Extended convolution launch descriptor (plain C, device pointers; NULL/0 = unused).
+ *  - in_scale/in_shift [cin]: x' = relu(x*s+t) applied to in-bounds input pixels while staging
+ *    (the producer stored its raw bias-free conv output; its train-mode BN+ReLU happens here);
+ *    res_scale/res_shift [cout]: same on the residual operand;
+ *  - epi_mode 0: out = act(acc*scale+shift (+res));
+ *    epi_mode 1: out = acc (raw); slab[(e*cout+c)*2+{0,1}] = (mean, M2) of the 64 pixels of entry
+ *                e = (workgroup, image), slab_cnt[e] = valid pixel count  (BatchNorm batch statistics;
+ *                entries = tsr_conv2d_slab_entries(B,H,W));
+ *    epi_mode 2: out = (acc*scale (+res)) * [mask*mask_scale+mask_shift > 0]  (ReLU backward by the stored
+ *                forward tensor `mask`); if bn_a: slab[(e*cout+c)*2+{0,1}] = (sum out, sum out*xhat),
+ *                xhat = mask*bn_a+bn_b  (the two reductions of BatchNorm backward). */
+typedef struct tsr_conv_desc {
+  const float* in; int in_ctot; int in_coff; int cin;
+  const float* w_packed; int cout; int ks;
+  const float* scale; const float* shift;
+  const float* res; int res_ctot; int res_coff;
+  float* out; int out_ctot; int out_coff; int relu;
+  int B; int H; int W;
+  const float* in_scale; const float* in_shift;
+  const float* res_scale; const float* res_shift;
+  int epi_mode;
+  const float* mask; int mask_ctot; int mask_coff;
+  const float* mask_scale; const float* mask_shift;
+  const float* bn_a; const float* bn_b;
+  float* slab; float* slab_cnt;
+} tsr_conv_desc;
+
+int tsr_conv2d_ex(const tsr_conv_desc* desc, void* stream);
+int tsr_conv2d_slab_entries(int B, int H, int W);
+
+/* Weights of the data-gradient convolution: W'[n][co][kh][kw] = W[co][ci0+n][K-1-kh][K-1-kw],
+ * n in [0,nprime), nprime in {64,128}; packed for tsr_conv2d_* with cin := cout, cout := nprime. */
+int tsr_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed, int cout, int cin, int ks,
+                               int ci0, int nprime, void* stream);
+
+/* Weight (and bias) gradient partials: slab[s][cout][cin][k][k] (s < nsplit, OIHW) with
+ * dW = sum_s slab[s] (tsr_reduce_splits), from a = conv input (CB16, optional relu(a*scale+shift)
+ * transform) and dz = gradient w.r.t. the conv output (CB16).  cin, cout multiples of 64.
+ * bias_slab[s][cout] (optional) receives sum over pixels of dz. */
+int tsr_conv2d_wgrad(const float* a, int a_ctot, int a_coff, int cin,
+                     const float* a_scale, const float* a_shift,
+                     const float* dz, int dz_ctot, int dz_coff, int cout, int ks,
+                     float* slab, float* bias_slab, int nsplit, int B, int H, int W, void* stream);
+int tsr_reduce_splits(const float* slab, float* out, long long n, int nsplit, float alpha, void* stream);
+
+/* nn.BatchNorm2d train mode (model/tactileSR_model.py:38,42,48,169,175,181,187), from the
+ * epi_mode-1 slabs: batch mean / biased variance -> scale = gamma*invstd, shift = beta-mean*scale
+ * (to apply on the bias-free conv output), xhat_a = invstd, xhat_b = -mean*invstd; running_mean/var
+ * updated in place (momentum, unbiased variance, +bias on the mean).  work: 64*C*3 doubles. */
+int tsr_bn_stats_finalize(const float* slab, const float* slab_cnt, int entries, int C,
+                          const float* bias, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps,
+                          float* scale, float* shift, float* xhat_a, float* xhat_b,
+                          double* work, void* stream);
+/* Same statistics slabs for a 64-channel CB16 slice produced by a kernel without a stats epilogue
+ * (the VALU stem): entries = tsr_cb16_stats_entries(B, HW). */
+int tsr_cb16_stats_entries(int B, int HW);
+int tsr_cb16_stats(const float* z, int z_ctot, int z_coff, int B, int HW, float* slab, float* slab_cnt,
+                   void* stream);
+/* BatchNorm backward reductions from the epi_mode-2 slabs: dgamma, dbeta and the coefficients of
+ * dz = c1*g + c2*z + c3 (N = B*H*W). */
+int tsr_bn_bwd_finalize(const float* slab, int entries, int C, double N, const float* scale,
+                        const float* xhat_a, const float* xhat_b, float* dgamma, float* dbeta,
+                        float* c1, float* c2, float* c3, double* work, void* stream);
+int tsr_bn_bwd_apply(float* g, int g_ctot, int g_coff, const float* z, int z_ctot, int z_coff,
+                     const float* c1, const float* c2, const float* c3, int C, int B, int HW, void* stream);
+
+/* Backward of tsr_stem_fwd's conv weight: slab[s][64][3][3][3] partials (taxels carry no gradient). */
+int tsr_stem_wgrad(const float* lr, int lr_ctot, int lr_coff, int hin, int win, int sf,
+                   const float* dz, int dz_ctot, int dz_coff, float* slab, int nsplit, int B, void* stream);
+/* Backward of tsr_head_fwd: dz_h0 = dgrad(dout*[out>0]) * [h0>0] (CB16) and weight partials
+ * wslab[s][cin][3][3]. */
+int tsr_head_bwd(const float* dout, const float* out, const float* h0, int h_ctot, int cin,
+                 const float* w_oihw, float* dz_h0, int dz_ctot, float* wslab, int nsplit,
+                 int B, int H, int W, void* stream);
+
+/* HR.float()/HR_scale_num + F.interpolate(size=(H,W), bilinear) (train/tactileSR_train.py:44-45). */
+int tsr_target_prep(const float* hr_raw, float* out, float inv_scale, int B, int hin, int win, int H, int W,
+                    void* stream);
+/* nn.MSELoss() forward (loss[0]) and backward (dy = grad_scale*2(y-t)/n; dy may be NULL).  work: 256 doubles. */
+int tsr_mse_fwd_bwd(const float* y, const float* target, float* dy, float* loss, long long n,
+                    float grad_scale, double* work, void* stream);
+/* torch.optim.Adam step with L2-in-gradient weight decay (train/tactileSR_train.py:212); step is 1-based. */
+int tsr_adam_l2_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
 /* Layout plumbing (tests, stage probes): NCHW (B,C,HW) <-> a channel slice of a CB16 buffer. */
 int tsr_nchw_to_cb16(const float* src, float* dst, int B, int C, int HW, int dst_ctot, int dst_coff, void* stream);
 int tsr_cb16_to_nchw(const float* src, float* dst, int B, int C, int HW, int src_ctot, int src_coff, void* stream);

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_int, c_void_p, c_float, c_longlong
+from ctypes import c_int, c_void_p, c_float, c_longlong, c_double
 
 import torch
 
@@ -24,6 +24,21 @@ SIGNATURES = {
     "tsr_conv2d_fwd": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "tsr_stem_fwd": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "tsr_head_fwd": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _P],
+    "tsr_conv2d_ex": [_P, _P],
+    "tsr_conv2d_slab_entries": [_I, _I, _I],
+    "tsr_pack_conv_weight_dgrad": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "tsr_conv2d_wgrad": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P],
+    "tsr_reduce_splits": [_P, _P, _L, _I, _F, _P],
+    "tsr_bn_stats_finalize": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P],
+    "tsr_cb16_stats_entries": [_I, _I],
+    "tsr_cb16_stats": [_P, _I, _I, _I, _I, _P, _P, _P],
+    "tsr_bn_bwd_finalize": [_P, _I, _I, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "tsr_bn_bwd_apply": [_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P],
+    "tsr_stem_wgrad": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P],
+    "tsr_head_bwd": [_P, _P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P],
+    "tsr_target_prep": [_P, _P, _F, _I, _I, _I, _I, _I, _P],
+    "tsr_mse_fwd_bwd": [_P, _P, _P, _P, _L, _F, _P, _P],
+    "tsr_adam_l2_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
     "tsr_nchw_to_cb16": [_P, _P, _I, _I, _I, _I, _I, _P],
     "tsr_cb16_to_nchw": [_P, _P, _I, _I, _I, _I, _I, _P],
 }

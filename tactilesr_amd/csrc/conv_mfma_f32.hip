@@ -17,6 +17,7 @@
 // 32x32 accumulator tiles.  f32 MFMA is an exact k-ordered fmaf chain, so results are
 // fp32-faithful (1e-5 relative parity with the reference's CPU path).
 #include "tsr_common.h"
+#include "tactilesr_hip.h"
 
 struct ConvArgs {
   const float* in;  int in_ctot;  int in_coff;  int cin;
@@ -27,6 +28,21 @@ struct ConvArgs {
   int relu;
   int B, H, W;
   int tiles_x, tiles_y;
+  // ---- training-path extensions (all optional; NULL/0 = inference behaviour) ----
+  // input transform applied while staging in-bounds halo pixels: x' = relu(x*in_scale[c]+in_shift[c])
+  // (the producer stored the raw, bias-free conv output; its train-mode BN+ReLU is applied here)
+  const float* in_scale; const float* in_shift;
+  // same transform on the residual operand
+  const float* res_scale; const float* res_shift;
+  // epi_mode 1: store the raw accumulator and emit per-(workgroup, image) Welford partials
+  //             (mean, M2) per channel to slab[(wg*2+wm)*COUT*2 ...], counts to slab_cnt
+  // epi_mode 2: v = (acc + res) * [mask*mask_scale+mask_shift > 0]  (ReLU backward by the stored
+  //             activation); if bn_a: also emit sum(v), sum(v*xhat), xhat = mask*bn_a+bn_b
+  int epi_mode;
+  const float* mask; int mask_ctot; int mask_coff;
+  const float* mask_scale; const float* mask_shift;
+  const float* bn_a; const float* bn_b;
+  float* slab; float* slab_cnt;
 };
 
 template <int KS, int COUT>
@@ -119,6 +135,18 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const ConvArgs a) {
       hv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (st_src[k] >= 0) hv[k] = *(const f32x4*)(inc + st_src[k]);
     }
+    if (a.in_scale) {   // wave-uniform branch: train-mode BN+ReLU of the producer, fused into the load
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        if (st_src[k] >= 0) {
+          const int cq = c * 16 + ((tid + k * 256) & 3) * 4;
+          const f32x4 sc = *(const f32x4*)(a.in_scale + cq);
+          const f32x4 sh = *(const f32x4*)(a.in_shift + cq);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) hv[k][j] = fmaxf(fmaf(hv[k][j], sc[j], sh[j]), 0.f);
+        }
+      }
+    }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NIT; ++k)
@@ -159,35 +187,129 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const ConvArgs a) {
     }
   }
 
-  // ---- epilogue: y = acc*scale + shift (+ residual) (ReLU) -> channel slice of out
+  // ---- epilogue
   const int b = b0 + wm;
-  if (b >= a.B) return;
+  const bool img_ok = b < a.B;
   const int out_blocks = a.out_ctot >> 4;
   const int res_blocks = a.res_ctot >> 4;
+  const int mask_blocks = a.mask_ctot >> 4;
+  const int bsafe = img_ok ? b : 0;
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int n = wn * (COUT / 2) + nb * 32 + li;
-    const float sc = a.scale ? a.scale[n] : 1.f;
-    const float sh = a.shift ? a.shift[n] : 0.f;
     const int oc = a.out_coff + n;
-    float* obase = a.out + (((size_t)b * out_blocks + (oc >> 4)) * HW) * 16 + (oc & 15);
+    float* obase = a.out + (((size_t)bsafe * out_blocks + (oc >> 4)) * HW) * 16 + (oc & 15);
     const float* rbase = nullptr;
     if (a.res) {
       const int rc = a.res_coff + n;
-      rbase = a.res + (((size_t)b * res_blocks + (rc >> 4)) * HW) * 16 + (rc & 15);
+      rbase = a.res + (((size_t)bsafe * res_blocks + (rc >> 4)) * HW) * 16 + (rc & 15);
     }
+    if (a.epi_mode == 0) {
+      // y = acc*scale + shift (+ residual) (ReLU) -> channel slice of out
+      if (!img_ok) continue;
+      const float sc = a.scale ? a.scale[n] : 1.f;
+      const float sh = a.shift ? a.shift[n] : 0.f;
+      const float rsc = a.res_scale ? a.res_scale[n] : 1.f;
+      const float rsh = a.res_scale ? a.res_shift[n] : 0.f;
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+      for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int gy = y0 + 4 * mb + (m >> 3), gx = x0 + (m & 7);
-        if (gy < a.H && gx < a.W) {
-          const size_t po = (size_t)(gy * a.W + gx) * 16;
-          float v = acc[mb][nb][r] * sc + sh;
-          if (rbase) v += rbase[po];
-          if (a.relu) v = fmaxf(v, 0.f);
-          obase[po] = v;
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int gy = y0 + 4 * mb + (m >> 3), gx = x0 + (m & 7);
+          if (gy < a.H && gx < a.W) {
+            const size_t po = (size_t)(gy * a.W + gx) * 16;
+            float v = acc[mb][nb][r] * sc + sh;
+            if (rbase) {
+              float rv = rbase[po];
+              if (a.res_scale) rv = fmaxf(fmaf(rv, rsc, rsh), 0.f);
+              v += rv;
+            }
+            if (a.relu) v = fmaxf(v, 0.f);
+            obase[po] = v;
+          }
+        }
+      }
+    } else if (a.epi_mode == 1) {
+      // raw accumulator out + Welford partial (mean, M2) of this wave's valid pixels
+      float cnt = 0.f, sum = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int gy = y0 + 4 * mb + (m >> 3), gx = x0 + (m & 7);
+          if (img_ok && gy < a.H && gx < a.W) {
+            const float v = acc[mb][nb][r];
+            obase[(size_t)(gy * a.W + gx) * 16] = v;
+            cnt += 1.f;
+            sum += v;
+          }
+        }
+      }
+      float mean = cnt > 0.f ? sum / cnt : 0.f;
+      float m2 = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int gy = y0 + 4 * mb + (m >> 3), gx = x0 + (m & 7);
+          if (img_ok && gy < a.H && gx < a.W) {
+            const float d = acc[mb][nb][r] - mean;
+            m2 = fmaf(d, d, m2);
+          }
+        }
+      }
+      // Chan merge with the partner half-wave (same channel, other 4 pixel columns)
+      const float cnt2 = __shfl_xor(cnt, 32), mean2 = __shfl_xor(mean, 32), m22 = __shfl_xor(m2, 32);
+      const float nt = cnt + cnt2;
+      const float dlt = mean2 - mean;
+      const float meanm = nt > 0.f ? mean + dlt * (cnt2 / nt) : 0.f;
+      const float m2m = nt > 0.f ? m2 + m22 + dlt * dlt * (cnt * cnt2 / nt) : 0.f;
+      if (h == 0) {
+        const size_t e = (size_t)bid * 2 + wm;
+        float* sl = a.slab + (e * COUT + n) * 2;
+        sl[0] = meanm;
+        sl[1] = m2m;
+        if (nb == 0 && li == 0 && wn == 0) a.slab_cnt[e] = nt;
+      }
+    } else {
+      // ReLU backward by the stored activation (+ optional BN-backward partial sums)
+      const int mc = a.mask_coff + n;
+      const float* mbase = a.mask + (((size_t)bsafe * mask_blocks + (mc >> 4)) * HW) * 16 + (mc & 15);
+      const float msc = a.mask_scale ? a.mask_scale[n] : 1.f;
+      const float msh = a.mask_scale ? a.mask_shift[n] : 0.f;
+      const float ba = a.bn_a ? a.bn_a[n] : 0.f;
+      const float bb = a.bn_a ? a.bn_b[n] : 0.f;
+      const float sc = a.scale ? a.scale[n] : 1.f;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int gy = y0 + 4 * mb + (m >> 3), gx = x0 + (m & 7);
+          if (img_ok && gy < a.H && gx < a.W) {
+            const size_t po = (size_t)(gy * a.W + gx) * 16;
+            float v = acc[mb][nb][r] * sc;
+            if (rbase) v += rbase[po];
+            const float mv = mbase[po];
+            if (!(fmaf(mv, msc, msh) > 0.f)) v = 0.f;
+            obase[po] = v;
+            s1 += v;
+            s2 = fmaf(v, fmaf(mv, ba, bb), s2);
+          }
+        }
+      }
+      if (a.bn_a) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (h == 0) {
+          const size_t e = (size_t)bid * 2 + wm;
+          float* sl = a.slab + (e * COUT + n) * 2;
+          sl[0] = s1;
+          sl[1] = s2;
         }
       }
     }
@@ -220,6 +342,37 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   return tsr_check_launch();
 }
 
+// Data-gradient weights: the dgrad of conv(W: OIHW) is itself a conv of dz with
+// W'[n=ci][k=co][kh][kw] = W[co][ci0+n][KS-1-kh][KS-1-kw]; pack a 64/128-wide slice of ci.
+__global__ void pack_conv_weight_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int cout_f,
+                                              int cin_f, int ks, int ci0, int nprime) {
+  const int T = ks * ks;
+  const size_t total = (size_t)nprime * cout_f * T;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int jj = i & 3;
+    size_t r = i >> 2;
+    const int n = r % nprime; r /= nprime;
+    const int kq = r & 3; r >>= 2;
+    const int tap = r % T;
+    const int chunk = r / T;
+    const int co = chunk * 16 + kq * 4 + jj;
+    wp[i] = w[((size_t)co * cin_f + ci0 + n) * T + (T - 1 - tap)];
+  }
+}
+
+extern "C" int tsr_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed, int cout, int cin, int ks,
+                                          int ci0, int nprime, void* stream) {
+  if (!w_oihw || !w_packed || (cout & 15) || (nprime != 64 && nprime != 128) || ci0 < 0 || ci0 + nprime > cin ||
+      (ks != 1 && ks != 3 && ks != 5))
+    return TSR_ERR_ARG;
+  const size_t total = (size_t)nprime * cout * ks * ks;
+  const int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(pack_conv_weight_dgrad_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
+                     (hipStream_t)stream, w_oihw, w_packed, cout, cin, ks, ci0, nprime);
+  return tsr_check_launch();
+}
+
 extern "C" int tsr_pack_conv_weight(const float* w_oihw, float* w_packed, int cout, int cin, int ks,
                                     void* stream) {
   if (!w_oihw || !w_packed || (cin & 15) || (cout != 64 && cout != 128) ||
@@ -232,25 +385,7 @@ extern "C" int tsr_pack_conv_weight(const float* w_oihw, float* w_packed, int co
   return tsr_check_launch();
 }
 
-extern "C" int tsr_conv2d_fwd(const float* in, int in_ctot, int in_coff, int cin,
-                              const float* w_packed, int cout, int ks,
-                              const float* scale, const float* shift,
-                              const float* res, int res_ctot, int res_coff,
-                              float* out, int out_ctot, int out_coff, int relu,
-                              int B, int H, int W, void* stream) {
-  if (!in || !w_packed || !out || B <= 0 || H <= 0 || W <= 0) return TSR_ERR_ARG;
-  if ((cin & 15) || (in_ctot & 15) || (in_coff & 15) || (out_ctot & 15) || (out_coff & 15) ||
-      cin <= 0 || in_coff + cin > in_ctot || out_coff + cout > out_ctot)
-    return TSR_ERR_ARG;
-  if (res && ((res_ctot & 15) || (res_coff & 15) || res_coff + cout > res_ctot)) return TSR_ERR_ARG;
-  ConvArgs a;
-  a.in = in; a.in_ctot = in_ctot; a.in_coff = in_coff; a.cin = cin;
-  a.wp = w_packed; a.scale = scale; a.shift = shift;
-  a.res = res; a.res_ctot = res_ctot; a.res_coff = res_coff;
-  a.out = out; a.out_ctot = out_ctot; a.out_coff = out_coff; a.relu = relu;
-  a.B = B; a.H = H; a.W = W;
-  a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8;
-  hipStream_t st = (hipStream_t)stream;
+static int dispatch_conv(const ConvArgs& a, int cout, int ks, hipStream_t st) {
   if (cout == 64) {
     if (ks == 1) return launch_conv<1, 64>(a, st);
     if (ks == 3) return launch_conv<3, 64>(a, st);
@@ -261,4 +396,64 @@ extern "C" int tsr_conv2d_fwd(const float* in, int in_ctot, int in_coff, int cin
     if (ks == 5) return launch_conv<5, 128>(a, st);
   }
   return TSR_ERR_ARG;
+}
+
+static int check_slices(int cin, int in_ctot, int in_coff, int cout, int out_ctot, int out_coff) {
+  if ((cin & 15) || (in_ctot & 15) || (in_coff & 15) || (out_ctot & 15) || (out_coff & 15) || cin <= 0 ||
+      in_coff + cin > in_ctot || out_coff + cout > out_ctot)
+    return TSR_ERR_ARG;
+  return TSR_OK;
+}
+
+extern "C" int tsr_conv2d_fwd(const float* in, int in_ctot, int in_coff, int cin,
+                              const float* w_packed, int cout, int ks,
+                              const float* scale, const float* shift,
+                              const float* res, int res_ctot, int res_coff,
+                              float* out, int out_ctot, int out_coff, int relu,
+                              int B, int H, int W, void* stream) {
+  if (!in || !w_packed || !out || B <= 0 || H <= 0 || W <= 0) return TSR_ERR_ARG;
+  if (check_slices(cin, in_ctot, in_coff, cout, out_ctot, out_coff)) return TSR_ERR_ARG;
+  if (res && ((res_ctot & 15) || (res_coff & 15) || res_coff + cout > res_ctot)) return TSR_ERR_ARG;
+  ConvArgs a = {};
+  a.in = in; a.in_ctot = in_ctot; a.in_coff = in_coff; a.cin = cin;
+  a.wp = w_packed; a.scale = scale; a.shift = shift;
+  a.res = res; a.res_ctot = res_ctot; a.res_coff = res_coff;
+  a.out = out; a.out_ctot = out_ctot; a.out_coff = out_coff; a.relu = relu;
+  a.B = B; a.H = H; a.W = W;
+  a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8;
+  return dispatch_conv(a, cout, ks, (hipStream_t)stream);
+}
+
+// Number of (workgroup, image) slab entries a tsr_conv2d_ex launch of this shape emits.
+extern "C" int tsr_conv2d_slab_entries(int B, int H, int W) {
+  return ((B + 1) / 2) * ((W + 7) / 8) * ((H + 7) / 8) * 2;
+}
+
+extern "C" int tsr_conv2d_ex(const tsr_conv_desc* d, void* stream) {
+  if (!d || !d->in || !d->w_packed || !d->out || d->B <= 0 || d->H <= 0 || d->W <= 0) return TSR_ERR_ARG;
+  if (check_slices(d->cin, d->in_ctot, d->in_coff, d->cout, d->out_ctot, d->out_coff)) return TSR_ERR_ARG;
+  if (d->res && ((d->res_ctot & 15) || (d->res_coff & 15) || d->res_coff + d->cout > d->res_ctot))
+    return TSR_ERR_ARG;
+  if (d->epi_mode < 0 || d->epi_mode > 2) return TSR_ERR_ARG;
+  if (d->epi_mode == 1 && (!d->slab || !d->slab_cnt)) return TSR_ERR_ARG;
+  if (d->epi_mode == 2 && (!d->mask || (d->mask_ctot & 15) || (d->mask_coff & 15) ||
+                           d->mask_coff + d->cout > d->mask_ctot || (d->bn_a && (!d->bn_b || !d->slab))))
+    return TSR_ERR_ARG;
+  if ((d->in_scale != nullptr) != (d->in_shift != nullptr)) return TSR_ERR_ARG;
+  if ((d->res_scale != nullptr) != (d->res_shift != nullptr)) return TSR_ERR_ARG;
+  ConvArgs a = {};
+  a.in = d->in; a.in_ctot = d->in_ctot; a.in_coff = d->in_coff; a.cin = d->cin;
+  a.wp = d->w_packed; a.scale = d->scale; a.shift = d->shift;
+  a.res = d->res; a.res_ctot = d->res_ctot; a.res_coff = d->res_coff;
+  a.out = d->out; a.out_ctot = d->out_ctot; a.out_coff = d->out_coff; a.relu = d->relu;
+  a.B = d->B; a.H = d->H; a.W = d->W;
+  a.tiles_x = (d->W + 7) / 8; a.tiles_y = (d->H + 7) / 8;
+  a.in_scale = d->in_scale; a.in_shift = d->in_shift;
+  a.res_scale = d->res_scale; a.res_shift = d->res_shift;
+  a.epi_mode = d->epi_mode;
+  a.mask = d->mask; a.mask_ctot = d->mask_ctot; a.mask_coff = d->mask_coff;
+  a.mask_scale = d->mask_scale; a.mask_shift = d->mask_shift;
+  a.bn_a = d->bn_a; a.bn_b = d->bn_b;
+  a.slab = d->slab; a.slab_cnt = d->slab_cnt;
+  return dispatch_conv(a, d->cout, d->ks, (hipStream_t)stream);
 }

@@ -1,0 +1,532 @@
+// Training-path kernels around the MFMA convolutions (all HBM-bound or tiny):
+//   BatchNorm2d train mode (batch statistics + running-stat update, backward coefficients),
+//   the 3->64 stem and 128->1 head backward, target preparation, MSE loss fwd/bwd, Adam(L2).
+// Reference semantics: nn.BatchNorm2d(eps=1e-5, momentum=0.1) inside model/tactileSR_model.py:
+// 38-49,167-189; nn.MSELoss + HR/10 + F.interpolate of train/tactileSR_train.py:39-49;
+// optim.Adam(lr, weight_decay) (L2-in-grad) of train/tactileSR_train.py:212; the step order of
+// cpu/trainer.py:346-362.
+#include "tsr_common.h"
+
+#define RED_BLOCKS 64
+
+// ------------------------------------------------------------------------------------------
+// per-channel fp64 reduction of the conv epilogue slabs: slab[entry][C][2]
+//   mode 0 (Welford partials mean,M2 with counts): S0 = sum n, S1 = sum n*mean, S2 = sum (M2 + n*mean^2)
+//   mode 1 (plain sums s1,s2):                      S0 = entries, S1 = sum s1, S2 = sum s2
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab,
+                                                          const float* __restrict__ cnt, int entries, int C,
+                                                          int mode, double* __restrict__ part) {
+  __shared__ double sh[256 * 3];
+  const int tid = threadIdx.x;
+  const int per = 256 / C;           // entries handled concurrently by one block (C in {64,128})
+  const int c = tid % C, el = tid / C;
+  double s0 = 0, s1 = 0, s2 = 0;
+  for (int e = blockIdx.x * per + el; e < entries; e += gridDim.x * per) {
+    const float2 v = *(const float2*)(slab + ((size_t)e * C + c) * 2);
+    if (mode == 0) {
+      const double n = (double)cnt[e], m = (double)v.x;
+      s0 += n; s1 += n * m; s2 += (double)v.y + n * m * m;
+    } else {
+      s0 += 1.0; s1 += (double)v.x; s2 += (double)v.y;
+    }
+  }
+  sh[tid * 3 + 0] = s0; sh[tid * 3 + 1] = s1; sh[tid * 3 + 2] = s2;
+  __syncthreads();
+  if (el == 0) {
+    for (int k = 1; k < per; ++k) {
+      s0 += sh[(k * C + c) * 3 + 0]; s1 += sh[(k * C + c) * 3 + 1]; s2 += sh[(k * C + c) * 3 + 2];
+    }
+    double* p = part + ((size_t)blockIdx.x * C + c) * 3;
+    p[0] = s0; p[1] = s1; p[2] = s2;
+  }
+}
+
+__global__ void bn_stats_final_kernel(const double* __restrict__ part, int nblocks, int C,
+                                      const float* __restrict__ bias, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, float* __restrict__ running_mean,
+                                      float* __restrict__ running_var, float momentum, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift,
+                                      float* __restrict__ xa, float* __restrict__ xb) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double n = 0, s1 = 0, s2 = 0;
+  for (int k = 0; k < nblocks; ++k) {
+    const double* p = part + ((size_t)k * C + c) * 3;
+    n += p[0]; s1 += p[1]; s2 += p[2];
+  }
+  const double mean = s1 / n;
+  double var = s2 / n - mean * mean;          // biased (normalisation)
+  var = var < 0 ? 0 : var;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const double sc = (double)gamma[c] * invstd;
+  scale[c] = (float)sc;
+  shift[c] = (float)((double)beta[c] - mean * sc);
+  xa[c] = (float)invstd;
+  xb[c] = (float)(-mean * invstd);
+  if (running_mean) {
+    const double mz = mean + (bias ? (double)bias[c] : 0.0);   // stats were taken on the bias-free accumulator
+    const double unbiased = n > 1 ? var * n / (n - 1) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mz);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
+}
+
+extern "C" int tsr_bn_stats_finalize(const float* slab, const float* slab_cnt, int entries, int C,
+                                     const float* bias, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, float momentum, float eps,
+                                     float* scale, float* shift, float* xhat_a, float* xhat_b,
+                                     double* work, void* stream) {
+  if (!slab || !slab_cnt || !gamma || !beta || !scale || !shift || !xhat_a || !xhat_b || !work || entries <= 0 ||
+      (C != 64 && C != 128))
+    return TSR_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(RED_BLOCKS), dim3(256), 0, st, slab, slab_cnt, entries, C, 0, work);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(1), dim3(128), 0, st, work, RED_BLOCKS, C, bias, gamma, beta,
+                     running_mean, running_var, momentum, eps, scale, shift, xhat_a, xhat_b);
+  return tsr_check_launch();
+}
+
+__global__ void bn_bwd_final_kernel(const double* __restrict__ part, int nblocks, int C, double N,
+                                    const float* __restrict__ scale, const float* __restrict__ xa,
+                                    const float* __restrict__ xb, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, float* __restrict__ c1, float* __restrict__ c2,
+                                    float* __restrict__ c3) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int k = 0; k < nblocks; ++k) {
+    const double* p = part + ((size_t)k * C + c) * 3;
+    s1 += p[1]; s2 += p[2];
+  }
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
+  // dz = scale*(g - dbeta/N - xhat*dgamma/N), xhat = z*xa + xb  ->  dz = c1*g + c2*z + c3
+  const double sc = scale[c];
+  c1[c] = (float)sc;
+  c2[c] = (float)(-sc * s2 / N * (double)xa[c]);
+  c3[c] = (float)(-sc * (s1 / N + (double)xb[c] * s2 / N));
+}
+
+extern "C" int tsr_bn_bwd_finalize(const float* slab, int entries, int C, double N, const float* scale,
+                                   const float* xhat_a, const float* xhat_b, float* dgamma, float* dbeta,
+                                   float* c1, float* c2, float* c3, double* work, void* stream) {
+  if (!slab || !scale || !xhat_a || !xhat_b || !dgamma || !dbeta || !c1 || !c2 || !c3 || !work || entries <= 0 ||
+      (C != 64 && C != 128))
+    return TSR_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(RED_BLOCKS), dim3(256), 0, st, slab, (const float*)nullptr, entries,
+                     C, 1, work);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(1), dim3(128), 0, st, work, RED_BLOCKS, C, N, scale, xhat_a, xhat_b,
+                     dgamma, dbeta, c1, c2, c3);
+  return tsr_check_launch();
+}
+
+// g[:, gcoff:gcoff+C] = c1*g + c2*z[:, zcoff:zcoff+C] + c3   (BN backward, elementwise, CB16, in place)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g, int g_ctot, int g_coff,
+                                                           const float* __restrict__ z, int z_ctot, int z_coff,
+                                                           const float* __restrict__ c1, const float* __restrict__ c2,
+                                                           const float* __restrict__ c3, int C, int HW, size_t total4) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+    const int q = i & 3;
+    size_t r = i >> 2;
+    const int pix = r % HW; r /= HW;
+    const int blk = r % (C >> 4);
+    const int b = r / (C >> 4);
+    const int c = blk * 16 + q * 4;
+    f32x4* gp = (f32x4*)(g + (((size_t)b * (g_ctot >> 4) + ((g_coff + c) >> 4)) * HW + pix) * 16 + q * 4);
+    const f32x4 zv = *(const f32x4*)(z + (((size_t)b * (z_ctot >> 4) + ((z_coff + c) >> 4)) * HW + pix) * 16 + q * 4);
+    const f32x4 k1 = *(const f32x4*)(c1 + c), k2 = *(const f32x4*)(c2 + c), k3 = *(const f32x4*)(c3 + c);
+    f32x4 gv = *gp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gv[j] = fmaf(k1[j], gv[j], fmaf(k2[j], zv[j], k3[j]));
+    *gp = gv;
+  }
+}
+
+extern "C" int tsr_bn_bwd_apply(float* g, int g_ctot, int g_coff, const float* z, int z_ctot, int z_coff,
+                                const float* c1, const float* c2, const float* c3, int C, int B, int HW,
+                                void* stream) {
+  if (!g || !z || !c1 || !c2 || !c3 || (C & 15) || (g_ctot & 15) || (g_coff & 15) || (z_ctot & 15) || (z_coff & 15) ||
+      g_coff + C > g_ctot || z_coff + C > z_ctot)
+    return TSR_ERR_ARG;
+  const size_t total4 = (size_t)B * C * HW / 4;
+  const size_t grid = (total4 + 255) / 256;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid > 16384 ? 16384 : (int)grid), dim3(256), 0, (hipStream_t)stream,
+                     g, g_ctot, g_coff, z, z_ctot, z_coff, c1, c2, c3, C, HW, total4);
+  return tsr_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// stem backward: dW[64][3][3][3] of Upsample+Conv2d(3->64) (no dgrad: taxels carry no grad)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bilin_src_t(int dst, float scale, int n_in, int& i0, int& i1, float& lam) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  i0 = i0 < n_in - 1 ? i0 : n_in - 1;
+  i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
+  lam = src - (float)i0;
+}
+
+// one workgroup per image-split; thread = (co = tid&63, pixel phase = tid>>6)
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ lr, int lr_ctot, int lr_coff,
+                                                         int hin, int win, int sf, const float* __restrict__ dz,
+                                                         int dz_ctot, int dz_coff, float* __restrict__ slab, int B,
+                                                         int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = hin * sf, W = win * sf, WP = W + 2, HP = H + 2;
+  float* tax = smem;                                   // [3][hin*win]
+  float* up = smem + ((3 * hin * win + 3) & ~3);       // [3][HP][WP] zero padded
+  const int tid = threadIdx.x;
+  const int co = tid & 63, ph = tid >> 6;
+  const int HW = H * W;
+  float acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+  const float sc = 1.0f / (float)sf;
+  const int oc = dz_coff + co;
+  for (int b = blockIdx.x; b < B; b += nsplit) {
+    __syncthreads();
+    for (int i = tid; i < 3 * hin * win; i += 256) tax[i] = lr[((size_t)b * lr_ctot + lr_coff) * hin * win + i];
+    __syncthreads();
+    for (int i = tid; i < 3 * HP * WP; i += 256) {
+      const int c = i / (HP * WP), rem = i - c * (HP * WP);
+      const int gy = rem / WP - 1, gx = rem % WP - 1;
+      float v = 0.f;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        int ya, yb, xa, xb; float ly, lx;
+        bilin_src_t(gy, sc, hin, ya, yb, ly);
+        bilin_src_t(gx, sc, win, xa, xb, lx);
+        const float* t = tax + c * hin * win;
+        const float top = (1.f - lx) * t[ya * win + xa] + lx * t[ya * win + xb];
+        const float bot = (1.f - lx) * t[yb * win + xa] + lx * t[yb * win + xb];
+        v = (1.f - ly) * top + ly * bot;
+      }
+      up[i] = v;
+    }
+    __syncthreads();
+    const float* dzp = dz + (((size_t)b * (dz_ctot >> 4) + (oc >> 4)) * HW) * 16 + (oc & 15);
+    for (int p = ph; p < HW; p += 4) {
+      const float d = dzp[(size_t)p * 16];
+      const int y = p / W, x = p - y * W;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw)
+            acc[(c * 3 + kh) * 3 + kw] = fmaf(d, up[(c * HP + y + kh) * WP + x + kw], acc[(c * 3 + kh) * 3 + kw]);
+    }
+  }
+  // combine the 4 pixel phases through LDS, write this split's OIHW partial
+  __syncthreads();
+  float* red = smem;   // reuse: [4][64][27]
+#pragma unroll
+  for (int k = 0; k < 27; ++k) red[(ph * 64 + co) * 27 + k] = acc[k];
+  __syncthreads();
+  for (int i = tid; i < 64 * 27; i += 256)
+    slab[(size_t)blockIdx.x * 64 * 27 + i] = (red[i] + red[64 * 27 + i]) + (red[2 * 64 * 27 + i] + red[3 * 64 * 27 + i]);
+}
+
+extern "C" int tsr_stem_wgrad(const float* lr, int lr_ctot, int lr_coff, int hin, int win, int sf,
+                              const float* dz, int dz_ctot, int dz_coff, float* slab, int nsplit, int B,
+                              void* stream) {
+  if (!lr || !dz || !slab || nsplit <= 0 || B <= 0 || (dz_ctot & 15) || (dz_coff & 15) || dz_coff + 64 > dz_ctot)
+    return TSR_ERR_ARG;
+  const int H = hin * sf, W = win * sf;
+  size_t fl = ((3 * hin * win + 3) & ~3) + (size_t)3 * (H + 2) * (W + 2);
+  if (fl < 4 * 64 * 27) fl = 4 * 64 * 27;
+  if (fl * 4 > 160 * 1024) return TSR_ERR_ARG;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)stem_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nsplit), dim3(256), fl * 4, (hipStream_t)stream, lr, lr_ctot, lr_coff,
+                     hin, win, sf, dz, dz_ctot, dz_coff, slab, B, nsplit);
+  return tsr_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// head backward.  out = relu(conv3x3(h0; w[1][C][3][3])), dout given NCHW (B,1,H,W).
+//   dpre = dout*[out>0];  dh0[c,q] = sum_tap dpre[q - tap + 1]*w[c][tap];  dz_h0 = dh0*[h0>0]
+//   dW[c][tap] = sum_{b,q} dpre[q - tap + 1]*h0[c][q]  (flipped correlation: out pixel p = q - (tap-1))
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                       const float* __restrict__ h0, int h_ctot, int cin,
+                                                       const float* __restrict__ w, float* __restrict__ dz,
+                                                       int dz_ctot, int B, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // [9][cin]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 9 * cin; i += 256) {
+    const int c = i % cin, tap = i / cin;
+    wl[i] = w[c * 9 + tap];
+  }
+  __syncthreads();
+  const int HW = H * W, b = blockIdx.y, nblk = cin >> 4;
+  const int item = blockIdx.x * 256 + tid;        // (pixel, channel block)
+  if (item >= HW * nblk) return;
+  const int blk = item / HW, q = item - blk * HW;
+  const int y = q / W, x = q - y * W;
+  float dp[9];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int py = y - kh + 1, px = x - kw + 1;
+      float v = 0.f;
+      if (py >= 0 && py < H && px >= 0 && px < W) {
+        const size_t o = (size_t)b * HW + py * W + px;
+        v = out[o] > 0.f ? dout[o] : 0.f;
+      }
+      dp[kh * 3 + kw] = v;
+    }
+  const f32x4* hp = (const f32x4*)(h0 + (((size_t)b * (h_ctot >> 4) + blk) * HW + q) * 16);
+  f32x4* dp4 = (f32x4*)(dz + (((size_t)b * (dz_ctot >> 4) + blk) * HW + q) * 16);
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    const f32x4 hv = hp[qd];
+    f32x4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = blk * 16 + qd * 4 + j;
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) s = fmaf(dp[t], wl[t * cin + c], s);
+      r[j] = hv[j] > 0.f ? s : 0.f;
+    }
+    dp4[qd] = r;
+  }
+}
+
+// thread = channel c (cin <= 256 => one thread per channel, remaining threads idle), grid = splits
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                         const float* __restrict__ h0, int h_ctot, int cin,
+                                                         float* __restrict__ slab, int B, int H, int W, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) float dpt[];   // [(H+2)*(W+2)] masked dout, zero padded
+  const int tid = threadIdx.x;
+  const int HW = H * W, WP = W + 2;
+  const int ngrp = 256 / cin;                     // pixel phases
+  const int c = tid % cin, ph = tid / cin;
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  for (int b = blockIdx.x; b < B; b += nsplit) {
+    __syncthreads();
+    for (int i = tid; i < (H + 2) * WP; i += 256) {
+      const int py = i / WP - 1, px = i % WP - 1;
+      float v = 0.f;
+      if (py >= 0 && py < H && px >= 0 && px < W) {
+        const size_t o = (size_t)b * HW + py * W + px;
+        v = out[o] > 0.f ? dout[o] : 0.f;
+      }
+      dpt[i] = v;
+    }
+    __syncthreads();
+    if (ph < ngrp) {
+      const float* hp = h0 + (((size_t)b * (h_ctot >> 4) + (c >> 4)) * HW) * 16 + (c & 15);
+      for (int q = ph; q < HW; q += ngrp) {
+        const float hv = hp[(size_t)q * 16];
+        const int y = q / W, x = q - y * W;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw)   // out pixel p = q - (tap - 1); padded index +1
+            acc[kh * 3 + kw] = fmaf(hv, dpt[(y - kh + 2) * WP + (x - kw + 2)], acc[kh * 3 + kw]);
+      }
+    }
+  }
+  __syncthreads();
+  float* red = dpt;     // [ngrp][cin][9]
+  if (ph < ngrp)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[(ph * cin + c) * 9 + t] = acc[t];
+  __syncthreads();
+  for (int i = tid; i < cin * 9; i += 256) {
+    float s = 0.f;
+    for (int k = 0; k < ngrp; ++k) s += red[k * cin * 9 + i];
+    slab[(size_t)blockIdx.x * cin * 9 + i] = s;
+  }
+}
+
+extern "C" int tsr_head_bwd(const float* dout, const float* out, const float* h0, int h_ctot, int cin,
+                            const float* w_oihw, float* dz_h0, int dz_ctot, float* wslab, int nsplit,
+                            int B, int H, int W, void* stream) {
+  if (!dout || !out || !h0 || !w_oihw || !dz_h0 || !wslab || nsplit <= 0 || (cin & 15) || cin > 256 || cin > h_ctot ||
+      cin > dz_ctot || (h_ctot & 15) || (dz_ctot & 15))
+    return TSR_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int items = H * W * (cin >> 4);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3((items + 255) / 256, B), dim3(256), (size_t)9 * cin * 4, st, dout, out,
+                     h0, h_ctot, cin, w_oihw, dz_h0, dz_ctot, B, H, W);
+  size_t fl = (size_t)(H + 2) * (W + 2);
+  const size_t redf = (size_t)(256 / cin) * cin * 9;
+  if (fl < redf) fl = redf;
+  if (fl * 4 > 64 * 1024) return TSR_ERR_ARG;
+  hipLaunchKernelGGL(head_wgrad_kernel, dim3(nsplit), dim3(256), fl * 4, st, dout, out, h0, h_ctot, cin, wslab, B, H,
+                     W, nsplit);
+  return tsr_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// target preparation: HR_raw (B,1,hin,win) * inv_scale -> bilinear (align_corners=False) to (H,W)
+// (train/tactileSR_train.py:44-45: HR/HR_scale_num, F.interpolate(size=(4sf,4sf)))
+// ------------------------------------------------------------------------------------------
+__global__ void target_prep_kernel(const float* __restrict__ hr, float* __restrict__ out, float inv_scale, int B,
+                                   int hin, int win, int H, int W) {
+  const size_t total = (size_t)B * H * W;
+  const float sy = (float)hin / (float)H, sx = (float)win / (float)W;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = i % W; size_t r = i / W;
+    const int y = r % H; const int b = r / H;
+    int ya, yb, xa, xb; float ly, lx;
+    bilin_src_t(y, sy, hin, ya, yb, ly);
+    bilin_src_t(x, sx, win, xa, xb, lx);
+    const float* t = hr + (size_t)b * hin * win;
+    const float v00 = t[ya * win + xa] * inv_scale, v01 = t[ya * win + xb] * inv_scale;
+    const float v10 = t[yb * win + xa] * inv_scale, v11 = t[yb * win + xb] * inv_scale;
+    out[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+  }
+}
+
+extern "C" int tsr_target_prep(const float* hr_raw, float* out, float inv_scale, int B, int hin, int win, int H,
+                               int W, void* stream) {
+  if (!hr_raw || !out || B <= 0) return TSR_ERR_ARG;
+  const size_t total = (size_t)B * H * W;
+  const size_t g = (total + 255) / 256;
+  hipLaunchKernelGGL(target_prep_kernel, dim3(g > 8192 ? 8192 : (int)g), dim3(256), 0, (hipStream_t)stream, hr_raw,
+                     out, inv_scale, B, hin, win, H, W);
+  return tsr_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// MSE loss (mean over all elements) forward + backward in one pass:
+//   partial[block] = sum (y-t)^2 (fp64), dy = gscale * 2 (y-t) / n ; loss = sum(partial)/n (second kernel)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ y, const float* __restrict__ t,
+                                                  float* __restrict__ dy, size_t n, float gcoef,
+                                                  double* __restrict__ part) {
+  __shared__ double sh[256];
+  double s = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = y[i] - t[i];
+    s += (double)d * (double)d;
+    if (dy) dy[i] = gcoef * d;
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+__global__ void mse_final_kernel(const double* __restrict__ part, int nb, double inv_n, float* __restrict__ loss) {
+  double s = 0;
+  for (int k = 0; k < nb; ++k) s += part[k];
+  loss[0] = (float)(s * inv_n);
+}
+
+extern "C" int tsr_mse_fwd_bwd(const float* y, const float* target, float* dy, float* loss, long long n,
+                               float grad_scale, double* work, void* stream) {
+  if (!y || !target || !loss || !work || n <= 0) return TSR_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = 256;
+  hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, st, y, target, dy, (size_t)n,
+                     (float)(2.0 * grad_scale / (double)n), work);
+  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(1), 0, st, work, nb, 1.0 / (double)n, loss);
+  return tsr_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam with L2-in-gradient weight decay (torch.optim.Adam, not AdamW), one tensor per launch.
+//   g' = g + wd*p ; m = b1 m + (1-b1) g' ; v = b2 v + (1-b2) g'^2
+//   p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// ------------------------------------------------------------------------------------------
+__global__ void adam_l2_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                               float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                               float bc1, float bc2_sqrt) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float w = p[i];
+    const float gg = fmaf(wd, w, g[i]);
+    const float mm = b1 * m[i] + (1.f - b1) * gg;
+    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    m[i] = mm;
+    v[i] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[i] = w - (lr / bc1) * (mm / denom);
+  }
+}
+
+extern "C" int tsr_adam_l2_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                                float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return TSR_ERR_ARG;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const size_t g = ((size_t)n + 255) / 256;
+  hipLaunchKernelGGL(adam_l2_kernel, dim3(g > 4096 ? 4096 : (int)g), dim3(256), 0, (hipStream_t)stream, param, grad,
+                     exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
+                     (float)sqrt(bc2));
+  return tsr_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// Welford batch statistics of a CB16 channel slice (for the VALU stem, which has no stats
+// epilogue): entry = (image, 64-pixel chunk); slab/slab_cnt in the tsr_conv2d_ex epi_mode-1 format.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cb16_stats_kernel(const float* __restrict__ z, int z_ctot, int z_coff,
+                                                         int HW, int chunks, float* __restrict__ slab,
+                                                         float* __restrict__ slab_cnt) {
+  __shared__ float sh[256 * 3];
+  const int tid = threadIdx.x, c = tid & 63, pg = tid >> 6;
+  const int e = blockIdx.x, b = e / chunks, ch = e - b * chunks;
+  const int oc = z_coff + c;
+  const float* zp = z + (((size_t)b * (z_ctot >> 4) + (oc >> 4)) * HW) * 16 + (oc & 15);
+  float v[16];
+  float cnt = 0.f, sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int p = ch * 64 + pg * 16 + k;
+    v[k] = 0.f;
+    if (p < HW) { v[k] = zp[(size_t)p * 16]; cnt += 1.f; sum += v[k]; }
+  }
+  const float mean = cnt > 0.f ? sum / cnt : 0.f;
+  float m2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int p = ch * 64 + pg * 16 + k;
+    if (p < HW) { const float d = v[k] - mean; m2 = fmaf(d, d, m2); }
+  }
+  sh[tid * 3] = cnt; sh[tid * 3 + 1] = mean; sh[tid * 3 + 2] = m2;
+  __syncthreads();
+  if (pg == 0) {
+    float n = cnt, mu = mean, M = m2;
+    for (int k = 1; k < 4; ++k) {
+      const float n2 = sh[(k * 64 + c) * 3], mu2 = sh[(k * 64 + c) * 3 + 1], M2 = sh[(k * 64 + c) * 3 + 2];
+      const float nt = n + n2;
+      if (nt > 0.f) {
+        const float d = mu2 - mu;
+        M = M + M2 + d * d * (n * n2 / nt);
+        mu = mu + d * (n2 / nt);
+      }
+      n = nt;
+    }
+    slab[((size_t)e * 64 + c) * 2] = mu;
+    slab[((size_t)e * 64 + c) * 2 + 1] = M;
+    if (c == 0) slab_cnt[e] = n;
+  }
+}
+
+extern "C" int tsr_cb16_stats_entries(int B, int HW) { return B * ((HW + 63) / 64); }
+
+extern "C" int tsr_cb16_stats(const float* z, int z_ctot, int z_coff, int B, int HW, float* slab, float* slab_cnt,
+                              void* stream) {
+  if (!z || !slab || !slab_cnt || (z_ctot & 15) || (z_coff & 15) || z_coff + 64 > z_ctot || B <= 0) return TSR_ERR_ARG;
+  const int chunks = (HW + 63) / 64;
+  hipLaunchKernelGGL(cb16_stats_kernel, dim3(B * chunks), dim3(256), 0, (hipStream_t)stream, z, z_ctot, z_coff, HW,
+                     chunks, slab, slab_cnt);
+  return tsr_check_launch();
+}

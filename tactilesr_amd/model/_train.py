@@ -1,0 +1,416 @@
+"""Train-mode forward (batch-statistics BatchNorm) and full backward of TactileSR on the HIP
+kernels, exposed to autograd as ONE ``torch.autograd.Function`` so that the reference's
+step protocol -- ``loss = criterion(model(LR), HR); loss.backward(); optimizer.step()``
+(train/tactileSR_train.py:41-51, cpu/trainer.py:346-362) -- works unchanged and ``.grad``
+appears on the registered ``nn.Parameter``s.
+
+Forward keeps, per BN layer, only the raw bias-free conv output ``z`` (CB16) plus four
+per-channel vectors; ``relu(bn(z))`` is never materialised -- consumers apply it while
+staging their input tiles.  Backward = dgrad (the same MFMA conv kernel with flipped /
+transposed weights and a ReLU-mask + BN-reduction epilogue) + wgrad (MFMA split-K over the
+batch) + a small elementwise BN-backward pass per BN layer.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_int, c_void_p, c_float, c_double, c_longlong, POINTER, byref
+
+import torch
+
+from .. import _lib
+from .._lib import call, ptr, stream
+
+_I, _F, _D, _L = c_int, c_float, c_double, c_longlong
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of ``tsr_conv_desc`` (include/tactilesr_hip.h)."""
+    _fields_ = [
+        ("in_", c_void_p), ("in_ctot", c_int), ("in_coff", c_int), ("cin", c_int),
+        ("w_packed", c_void_p), ("cout", c_int), ("ks", c_int),
+        ("scale", c_void_p), ("shift", c_void_p),
+        ("res", c_void_p), ("res_ctot", c_int), ("res_coff", c_int),
+        ("out", c_void_p), ("out_ctot", c_int), ("out_coff", c_int), ("relu", c_int),
+        ("B", c_int), ("H", c_int), ("W", c_int),
+        ("in_scale", c_void_p), ("in_shift", c_void_p),
+        ("res_scale", c_void_p), ("res_shift", c_void_p),
+        ("epi_mode", c_int),
+        ("mask", c_void_p), ("mask_ctot", c_int), ("mask_coff", c_int),
+        ("mask_scale", c_void_p), ("mask_shift", c_void_p),
+        ("bn_a", c_void_p), ("bn_b", c_void_p),
+        ("slab", c_void_p), ("slab_cnt", c_void_p),
+    ]
+
+
+def _p(t):
+    return None if t is None else ptr(t).value
+
+
+class Act:
+    """A CB16 activation slice, optionally 'virtual': value = relu(buf*scale+shift)."""
+    __slots__ = ("buf", "ctot", "coff", "c", "scale", "shift", "xa", "xb")
+
+    def __init__(self, buf, ctot, coff, c, scale=None, shift=None, xa=None, xb=None):
+        self.buf, self.ctot, self.coff, self.c = buf, ctot, coff, c
+        self.scale, self.shift, self.xa, self.xb = scale, shift, xa, xb
+
+
+def conv_ex(*, B, H, W, src: Act, w, cout, ks, out, out_ctot, out_coff, scale=None, shift=None, relu=0,
+            res: Act = None, epi_mode=0, mask: Act = None, bn=False, slab=None, slab_cnt=None):
+    d = ConvDesc()
+    d.in_, d.in_ctot, d.in_coff, d.cin = _p(src.buf), src.ctot, src.coff, src.c
+    d.w_packed, d.cout, d.ks = _p(w), cout, ks
+    d.scale, d.shift = _p(scale), _p(shift)
+    if res is not None:
+        d.res, d.res_ctot, d.res_coff = _p(res.buf), res.ctot, res.coff
+        d.res_scale, d.res_shift = _p(res.scale), _p(res.shift)
+    d.out, d.out_ctot, d.out_coff, d.relu = _p(out), out_ctot, out_coff, int(relu)
+    d.B, d.H, d.W = B, H, W
+    d.in_scale, d.in_shift = _p(src.scale), _p(src.shift)
+    d.epi_mode = epi_mode
+    if mask is not None:
+        d.mask, d.mask_ctot, d.mask_coff = _p(mask.buf), mask.ctot, mask.coff
+        d.mask_scale, d.mask_shift = _p(mask.scale), _p(mask.shift)
+        if bn:
+            d.bn_a, d.bn_b = _p(mask.xa), _p(mask.xb)
+    d.slab, d.slab_cnt = _p(slab), _p(slab_cnt)
+    st = _lib.load().tsr_conv2d_ex(byref(d), stream())
+    if st != 0:
+        raise _lib.TactileSRHipError(f"tsr_conv2d_ex failed: status {st}")
+
+
+def _pack(w, cout, cin, ks):
+    wp = torch.empty(cout * cin * ks * ks, dtype=torch.float32, device=w.device)
+    call("tsr_pack_conv_weight", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), stream())
+    return wp
+
+
+def _pack_dgrad(w, cout, cin, ks, ci0, nprime):
+    wp = torch.empty(nprime * cout * ks * ks, dtype=torch.float32, device=w.device)
+    call("tsr_pack_conv_weight_dgrad", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), _I(ci0), _I(nprime), stream())
+    return wp
+
+
+class _Ctx:
+    """Everything backward needs (device buffers stay alive through this object)."""
+
+
+class TrainEngine:
+    """Runs one train-mode forward / backward of a ``TactileSR`` module."""
+
+    def __init__(self, model):
+        self.m = model
+
+    # ------------------------------------------------------------------ helpers
+    def _bn_finalize(self, c: _Ctx, conv_bias, bn, slab, cnt, entries, C):
+        dev = slab.device
+        vec = torch.empty(4, C, dtype=torch.float32, device=dev)
+        call("tsr_bn_stats_finalize", ptr(slab), ptr(cnt), _I(entries), _I(C),
+             ptr(conv_bias.detach() if conv_bias is not None else None), ptr(bn.weight.detach()),
+             ptr(bn.bias.detach()), ptr(bn.running_mean), ptr(bn.running_var), _F(bn.momentum), _F(bn.eps),
+             ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), ptr(c.work), stream())
+        bn.num_batches_tracked.add_(1)
+        return vec   # rows: scale, shift, xhat_a, xhat_b
+
+    def _conv_bn(self, c: _Ctx, src: Act, conv, bn, out, out_ctot, out_coff):
+        """conv (bias-free raw output) + batch statistics; returns the 4xC BN vectors."""
+        w = conv.weight.detach()
+        cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
+        wp = _pack(w.contiguous(), cout, cin, ks)
+        conv_ex(B=c.B, H=c.H, W=c.W, src=src, w=wp, cout=cout, ks=ks, out=out, out_ctot=out_ctot,
+                out_coff=out_coff, epi_mode=1, slab=c.slab, slab_cnt=c.slab_cnt)
+        return self._bn_finalize(c, conv.bias, bn, c.slab, c.slab_cnt, c.entries, cout)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor):
+        m = self.m
+        c = _Ctx()
+        dev = x.device
+        B, hin, win = x.shape[0], x.shape[2], x.shape[3]
+        sf, T, A = m.scale_factor, m.seqsCnt, m.axisCnt
+        H, W = hin * sf, win * sf
+        HW = H * W
+        c.B, c.H, c.W, c.HW, c.x, c.hin, c.win = B, H, W, HW, x, hin, win
+        lib = _lib.load()
+        c.entries = lib.tsr_conv2d_slab_entries(B, H, W)
+        st_entries = lib.tsr_cb16_stats_entries(B, HW)
+        c.slab = torch.empty(max(c.entries * 128 * 2, st_entries * 64 * 2), dtype=torch.float32, device=dev)
+        c.slab_cnt = torch.empty(max(c.entries, st_entries), dtype=torch.float32, device=dev)
+        c.work = torch.empty(64 * 128 * 3, dtype=torch.float64, device=dev)
+
+        def buf(ch):
+            return torch.empty(B * ch * HW, dtype=torch.float32, device=dev)
+
+        ctot_in = x.shape[1]
+        # ---- pattern stems
+        c.z1, c.bn1 = [], []
+        c.catT = buf(64 * T)
+        c.bn2 = torch.empty(4, 64 * T, dtype=torch.float32, device=dev)
+        for t, seq in enumerate(m.inputLayer_pattern_list):
+            z1 = buf(64)
+            call("tsr_stem_fwd", ptr(x), _I(ctot_in), _I(A * t), _I(A), _I(hin), _I(win), _I(sf),
+                 ptr(seq[1].weight.detach()), ptr(None), ptr(None), ptr(z1), _I(64), _I(0), _I(0), _I(B), stream())
+            call("tsr_cb16_stats", ptr(z1), _I(64), _I(0), _I(B), _I(HW), ptr(c.slab), ptr(c.slab_cnt), stream())
+            v1 = self._bn_finalize(c, None, seq[2], c.slab, c.slab_cnt, st_entries, 64)
+            c.z1.append(z1)
+            c.bn1.append(v1)
+            v2 = self._conv_bn(c, Act(z1, 64, 0, 64, v1[0], v1[1]), seq[4], seq[5], c.catT, 64 * T, 64 * t)
+            c.bn2[:, 64 * t:64 * (t + 1)] = v2
+        # ---- fuse conv
+        c.zf = buf(64)
+        c.bnf = self._conv_bn(c, Act(c.catT, 64 * T, 0, 64 * T, c.bn2[0], c.bn2[1]), m.inputContact_layer[0],
+                              m.inputContact_layer[1], c.zf, 64, 0)
+        X = Act(c.zf, 64, 0, 64, c.bnf[0], c.bnf[1], c.bnf[2], c.bnf[3])
+        # ---- MSRB chain
+        c.hcat = buf(128)
+        c.blocks = []
+        n_msrb = len(m.patternFeatureExtra_layer)
+        for i, blk in enumerate(m.patternFeatureExtra_layer):
+            s = _Ctx()
+            s.X = X
+            s.cat1, s.cat2 = buf(128), buf(256)
+            s.bn_c1 = torch.empty(4, 128, dtype=torch.float32, device=dev)
+            s.bn_c2 = torch.empty(4, 256, dtype=torch.float32, device=dev)
+            s.bn_c1[:, 0:64] = self._conv_bn(c, X, blk.conv_3_1[0], blk.conv_3_1[1], s.cat1, 128, 0)
+            s.bn_c1[:, 64:128] = self._conv_bn(c, X, blk.conv_5_1[0], blk.conv_5_1[1], s.cat1, 128, 64)
+            A1 = Act(s.cat1, 128, 0, 128, s.bn_c1[0], s.bn_c1[1], s.bn_c1[2], s.bn_c1[3])
+            s.bn_c2[:, 0:128] = self._conv_bn(c, A1, blk.conv_3_2[0], blk.conv_3_2[1], s.cat2, 256, 0)
+            s.bn_c2[:, 128:256] = self._conv_bn(c, A1, blk.conv_5_2[0], blk.conv_5_2[1], s.cat2, 256, 128)
+            A2 = Act(s.cat2, 256, 0, 256, s.bn_c2[0], s.bn_c2[1], s.bn_c2[2], s.bn_c2[3])
+            s.A1, s.A2 = A1, A2
+            wconf = blk.confusion.weight.detach().contiguous()
+            wp = _pack(wconf, 64, 256, 1)
+            if i == n_msrb - 1:
+                out, octot, ocoff = c.hcat, 128, 64
+            else:
+                out, octot, ocoff = buf(64), 64, 0
+            conv_ex(B=B, H=H, W=W, src=A2, w=wp, cout=64, ks=1, out=out, out_ctot=octot, out_coff=ocoff,
+                    shift=blk.confusion.bias.detach(), relu=1, res=X)
+            X = Act(out, octot, ocoff, 64)
+            s.Y = X
+            c.blocks.append(s)
+        if n_msrb == 0:
+            raise _lib.TactileSRHipError("train path needs patternFeatureExtraLayerCnt >= 1")
+        # ---- force branch
+        c.f0 = buf(64)
+        call("tsr_stem_fwd", ptr(x), _I(ctot_in), _I(0), _I(A), _I(hin), _I(win), _I(sf),
+             ptr(m.input_layer_force[1].weight.detach()), ptr(None), ptr(None), ptr(c.f0), _I(64), _I(0), _I(1),
+             _I(B), stream())
+        F0 = Act(c.f0, 64, 0, 64)
+        c.res = []
+        n_res = len(m.forceFeatureExtra_layer)
+        if n_res == 0:
+            raise _lib.TactileSRHipError("train path needs forceFeatureExtraLayerCnt >= 1")
+        for i, rb in enumerate(m.forceFeatureExtra_layer):
+            s = _Ctx()
+            s.X = F0
+            s.f1 = buf(64)
+            w1 = _pack(rb.conv1.weight.detach().contiguous(), 64, 64, 3)
+            conv_ex(B=B, H=H, W=W, src=F0, w=w1, cout=64, ks=3, out=s.f1, out_ctot=64, out_coff=0,
+                    shift=rb.conv1.bias.detach(), relu=1)
+            w2 = _pack(rb.conv2.weight.detach().contiguous(), 64, 64, 3)
+            if i == n_res - 1:
+                out, octot, ocoff = c.hcat, 128, 0
+            else:
+                out, octot, ocoff = buf(64), 64, 0
+            conv_ex(B=B, H=H, W=W, src=Act(s.f1, 64, 0, 64), w=w2, cout=64, ks=3, out=out, out_ctot=octot,
+                    out_coff=ocoff, shift=rb.conv2.bias.detach(), relu=1, res=F0)
+            F0 = Act(out, octot, ocoff, 64)
+            s.Y = F0
+            c.res.append(s)
+        # ---- head
+        c.h0 = buf(128)
+        wh = _pack(m.output_layer[0].weight.detach().contiguous(), 128, 128, 3)
+        conv_ex(B=B, H=H, W=W, src=Act(c.hcat, 128, 0, 128), w=wh, cout=128, ks=3, out=c.h0, out_ctot=128,
+                out_coff=0, relu=1)
+        out = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
+        call("tsr_head_fwd", ptr(c.h0), _I(128), _I(128), ptr(m.output_layer[2].weight.detach()), ptr(out), _I(1),
+             _I(B), _I(H), _I(W), stream())
+        c.out = out
+        return out, c
+
+    # ------------------------------------------------------------------ backward pieces
+    @staticmethod
+    def _nsplit(B, ks, cout, cin):
+        slices = ks * (cout // 64) * (cin // 64)
+        return max(1, min(B, 1024 // slices))
+
+    def _wgrad(self, c, a: Act, dz: Act, conv, grads, name, with_bias):
+        w = conv.weight
+        cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
+        ns = self._nsplit(c.B, ks, cout, cin)
+        n = cout * cin * ks * ks
+        slab = torch.empty(ns * n, dtype=torch.float32, device=w.device)
+        bslab = torch.empty(ns * cout, dtype=torch.float32, device=w.device) if with_bias else None
+        call("tsr_conv2d_wgrad", ptr(a.buf), _I(a.ctot), _I(a.coff), _I(cin), ptr(a.scale), ptr(a.shift),
+             ptr(dz.buf), _I(dz.ctot), _I(dz.coff), _I(cout), _I(ks), ptr(slab), ptr(bslab), _I(ns),
+             _I(c.B), _I(c.H), _I(c.W), stream())
+        gw = torch.empty_like(w)
+        call("tsr_reduce_splits", ptr(slab), ptr(gw), _L(n), _I(ns), _F(1.0), stream())
+        grads[name + ".weight"] = gw
+        if with_bias:
+            gb = torch.empty(cout, dtype=torch.float32, device=w.device)
+            call("tsr_reduce_splits", ptr(bslab), ptr(gb), _L(cout), _I(ns), _F(1.0), stream())
+            grads[name + ".bias"] = gb
+
+    def _dgrad(self, c, dz: Act, conv, ci0, nprime, out, out_ctot, out_coff, res: Act = None, mask: Act = None,
+               bn=False):
+        """d(input)[ci0:ci0+nprime] of conv given dz; optional + res, ReLU mask, BN-backward sums."""
+        w = conv.weight.detach().contiguous()
+        cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
+        wp = _pack_dgrad(w, cout, cin, ks, ci0, nprime)
+        conv_ex(B=c.B, H=c.H, W=c.W, src=dz, w=wp, cout=nprime, ks=ks, out=out, out_ctot=out_ctot,
+                out_coff=out_coff, res=res, epi_mode=2 if mask is not None else 0, mask=mask, bn=bn,
+                slab=c.slab if bn else None, slab_cnt=None)
+
+    def _bn_bwd(self, c, g_buf, g_ctot, g_coff, z: Act, zoff, C, bn_vec, bn_mod, grads, name):
+        """Finish BatchNorm backward for C channels whose masked gradient g sits in g_buf (slab sums
+        were just produced by the dgrad epilogue over the same C channels)."""
+        dev = g_buf.device
+        out = torch.empty(5, C, dtype=torch.float32, device=dev)
+        call("tsr_bn_bwd_finalize", ptr(c.slab), _I(c.entries), _I(C), _D(float(c.B * c.HW)),
+             ptr(bn_vec[0]), ptr(bn_vec[2]), ptr(bn_vec[3]), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]),
+             ptr(out[4]), ptr(c.work), stream())
+        call("tsr_bn_bwd_apply", ptr(g_buf), _I(g_ctot), _I(g_coff), ptr(z.buf), _I(z.ctot), _I(z.coff + zoff),
+             ptr(out[2]), ptr(out[3]), ptr(out[4]), _I(C), _I(c.B), _I(c.HW), stream())
+        return out   # rows 0,1 = dgamma, dbeta
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, c: _Ctx, dout: torch.Tensor):
+        m = self.m
+        dev = dout.device
+        B, H, W, HW = c.B, c.H, c.W, c.HW
+        grads = {}
+
+        def buf(ch):
+            return torch.empty(B * ch * HW, dtype=torch.float32, device=dev)
+
+        dout = dout.contiguous().float()
+        # ---- head: out = relu(conv(h0)), h0 = relu(conv(hcat))
+        ns = max(1, min(B, 256))
+        dz_h0 = buf(128)
+        wslab = torch.empty(ns * 128 * 9, dtype=torch.float32, device=dev)
+        call("tsr_head_bwd", ptr(dout), ptr(c.out), ptr(c.h0), _I(128), _I(128),
+             ptr(m.output_layer[2].weight.detach()), ptr(dz_h0), _I(128), ptr(wslab), _I(ns), _I(B), _I(H), _I(W),
+             stream())
+        gw = torch.empty_like(m.output_layer[2].weight)
+        call("tsr_reduce_splits", ptr(wslab), ptr(gw), _L(128 * 9), _I(ns), _F(1.0), stream())
+        grads["output_layer.2.weight"] = gw
+        DZ = Act(dz_h0, 128, 0, 128)
+        HC = Act(c.hcat, 128, 0, 128)
+        self._wgrad(c, HC, DZ, m.output_layer[0], grads, "output_layer.0", False)
+        g_hcat = buf(128)
+        self._dgrad(c, DZ, m.output_layer[0], 0, 128, g_hcat, 128, 0, mask=HC)
+        del dz_h0
+
+        # ---- force branch (ResBlocks, reversed); gradient w.r.t. block output pre-ReLU in `dpre`
+        dpre = Act(g_hcat, 128, 0, 64)
+        for i in reversed(range(len(c.res))):
+            s, rb = c.res[i], m.forceFeatureExtra_layer[i]
+            name = f"forceFeatureExtra_layer.{i}"
+            F1 = Act(s.f1, 64, 0, 64)
+            self._wgrad(c, F1, dpre, rb.conv2, grads, name + ".conv2", True)
+            d1 = buf(64)
+            self._dgrad(c, dpre, rb.conv2, 0, 64, d1, 64, 0, mask=F1)
+            D1 = Act(d1, 64, 0, 64)
+            self._wgrad(c, s.X, D1, rb.conv1, grads, name + ".conv1", True)
+            d0 = buf(64)
+            self._dgrad(c, D1, rb.conv1, 0, 64, d0, 64, 0, res=dpre, mask=s.X)
+            dpre = Act(d0, 64, 0, 64)
+        ns = max(1, min(B, 256))
+        sslab = torch.empty(ns * 64 * 27, dtype=torch.float32, device=dev)
+        call("tsr_stem_wgrad", ptr(c.x), _I(c.x.shape[1]), _I(0), _I(c.hin), _I(c.win), _I(m.scale_factor),
+             ptr(dpre.buf), _I(dpre.ctot), _I(dpre.coff), ptr(sslab), _I(ns), _I(B), stream())
+        gw = torch.empty_like(m.input_layer_force[1].weight)
+        call("tsr_reduce_splits", ptr(sslab), ptr(gw), _L(64 * 27), _I(ns), _F(1.0), stream())
+        grads["input_layer_force.1.weight"] = gw
+
+        # ---- pattern branch: MSRB blocks reversed
+        dpre = Act(g_hcat, 128, 64, 64)
+        for i in reversed(range(len(c.blocks))):
+            s, blk = c.blocks[i], m.patternFeatureExtra_layer[i]
+            name = f"patternFeatureExtra_layer.{i}"
+            # confusion 1x1: a = relu(bn(cat2)), dz = dpre
+            self._wgrad(c, s.A2, dpre, blk.confusion, grads, name + ".confusion", True)
+            g2 = buf(256)
+            for half, (cv, bnm, nm) in enumerate(((blk.conv_3_2[0], blk.conv_3_2[1], "conv_3_2"),
+                                                  (blk.conv_5_2[0], blk.conv_5_2[1], "conv_5_2"))):
+                o = 128 * half
+                mk = Act(s.cat2, 256, o, 128, s.bn_c2[0, o:o + 128], s.bn_c2[1, o:o + 128], s.bn_c2[2, o:o + 128],
+                         s.bn_c2[3, o:o + 128])
+                self._dgrad(c, dpre, blk.confusion, o, 128, g2, 256, o, mask=mk, bn=True)
+                r = self._bn_bwd(c, g2, 256, o, Act(s.cat2, 256, 0, 256), o, 128, s.bn_c2[:, o:o + 128], bnm, grads,
+                                 nm)
+                grads[f"{name}.{nm}.1.weight"], grads[f"{name}.{nm}.1.bias"] = r[0].clone(), r[1].clone()
+            DZ32, DZ52 = Act(g2, 256, 0, 128), Act(g2, 256, 128, 128)
+            self._wgrad(c, s.A1, DZ32, blk.conv_3_2[0], grads, f"{name}.conv_3_2.0", True)
+            self._wgrad(c, s.A1, DZ52, blk.conv_5_2[0], grads, f"{name}.conv_5_2.0", True)
+            g1 = buf(128)
+            self._dgrad(c, DZ32, blk.conv_3_2[0], 0, 128, g1, 128, 0)
+            mk = Act(s.cat1, 128, 0, 128, s.bn_c1[0], s.bn_c1[1], s.bn_c1[2], s.bn_c1[3])
+            self._dgrad(c, DZ52, blk.conv_5_2[0], 0, 128, g1, 128, 0, res=Act(g1, 128, 0, 128), mask=mk, bn=True)
+            r = self._bn_bwd(c, g1, 128, 0, Act(s.cat1, 128, 0, 128), 0, 128, s.bn_c1, None, grads, "")
+            grads[f"{name}.conv_3_1.1.weight"], grads[f"{name}.conv_3_1.1.bias"] = r[0, :64].clone(), r[1, :64].clone()
+            grads[f"{name}.conv_5_1.1.weight"], grads[f"{name}.conv_5_1.1.bias"] = r[0, 64:].clone(), r[1, 64:].clone()
+            del g2
+            DZ31, DZ51 = Act(g1, 128, 0, 64), Act(g1, 128, 64, 64)
+            self._wgrad(c, s.X, DZ31, blk.conv_3_1[0], grads, f"{name}.conv_3_1.0", True)
+            self._wgrad(c, s.X, DZ51, blk.conv_5_1[0], grads, f"{name}.conv_5_1.0", True)
+            dx = buf(64)
+            self._dgrad(c, DZ31, blk.conv_3_1[0], 0, 64, dx, 64, 0, res=dpre)
+            virtual = s.X.scale is not None
+            self._dgrad(c, DZ51, blk.conv_5_1[0], 0, 64, dx, 64, 0, res=Act(dx, 64, 0, 64), mask=s.X, bn=virtual)
+            dpre = Act(dx, 64, 0, 64)
+            del g1
+        # X of block 0 is the fuse conv's relu(bn(zf)): finish its BN backward -> dzf
+        r = self._bn_bwd(c, dpre.buf, 64, 0, Act(c.zf, 64, 0, 64), 0, 64, c.bnf, None, grads, "")
+        grads["inputContact_layer.1.weight"], grads["inputContact_layer.1.bias"] = r[0].clone(), r[1].clone()
+        T = m.seqsCnt
+        AT = Act(c.catT, 64 * T, 0, 64 * T, c.bn2[0], c.bn2[1], c.bn2[2], c.bn2[3])
+        self._wgrad(c, AT, dpre, m.inputContact_layer[0], grads, "inputContact_layer.0", False)
+        gT = buf(64 * T)
+        for t, seq in enumerate(m.inputLayer_pattern_list):
+            name = f"inputLayer_pattern_list.{t}"
+            o = 64 * t
+            mk = Act(c.catT, 64 * T, o, 64, c.bn2[0, o:o + 64], c.bn2[1, o:o + 64], c.bn2[2, o:o + 64],
+                     c.bn2[3, o:o + 64])
+            self._dgrad(c, dpre, m.inputContact_layer[0], o, 64, gT, 64 * T, o, mask=mk, bn=True)
+            r = self._bn_bwd(c, gT, 64 * T, o, Act(c.catT, 64 * T, 0, 64 * T), o, 64, c.bn2[:, o:o + 64], None, grads,
+                             "")
+            grads[name + ".5.weight"], grads[name + ".5.bias"] = r[0].clone(), r[1].clone()
+            DZ2 = Act(gT, 64 * T, o, 64)
+            v1 = c.bn1[t]
+            A1 = Act(c.z1[t], 64, 0, 64, v1[0], v1[1], v1[2], v1[3])
+            self._wgrad(c, A1, DZ2, seq[4], grads, name + ".4", False)
+            g1 = buf(64)
+            self._dgrad(c, DZ2, seq[4], 0, 64, g1, 64, 0, mask=A1, bn=True)
+            r = self._bn_bwd(c, g1, 64, 0, Act(c.z1[t], 64, 0, 64), 0, 64, v1, None, grads, "")
+            grads[name + ".2.weight"], grads[name + ".2.bias"] = r[0].clone(), r[1].clone()
+            ns = max(1, min(B, 256))
+            sslab = torch.empty(ns * 64 * 27, dtype=torch.float32, device=dev)
+            call("tsr_stem_wgrad", ptr(c.x), _I(c.x.shape[1]), _I(m.axisCnt * t), _I(c.hin), _I(c.win),
+                 _I(m.scale_factor), ptr(g1), _I(64), _I(0), ptr(sslab), _I(ns), _I(B), stream())
+            gw = torch.empty_like(seq[1].weight)
+            call("tsr_reduce_splits", ptr(sslab), ptr(gw), _L(64 * 27), _I(ns), _F(1.0), stream())
+            grads[name + ".1.weight"] = gw
+        return grads
+
+
+class TactileSRTrainFn(torch.autograd.Function):
+    """out = TactileSR_train_forward(x; params).  ``params`` are passed only so that autograd
+    routes their gradients; the engine reads them from the module."""
+
+    @staticmethod
+    def forward(ctx, engine: TrainEngine, names, x, *params):
+        out, c = engine.forward(x)
+        ctx.engine, ctx.c, ctx.names = engine, c, names
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        grads = ctx.engine.backward(ctx.c, dout)
+        ctx.c = None
+        missing = [n for n in ctx.names if n not in grads]
+        if missing:
+            raise _lib.TactileSRHipError(f"backward produced no gradient for {missing[:4]}...")
+        return (None, None, None) + tuple(grads[n] for n in ctx.names)

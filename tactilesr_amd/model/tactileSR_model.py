@@ -130,6 +130,7 @@ class TactileSR(nn.Module):
         self._plan = None
         self._plan_key = None
         self._profile = None
+        self._train_engine = None
         self.max_images_per_pass = 4096   # workspace bound: ~6.6 MB of CB16 activations per image
 
     def make_layer(self, block, num_of_layer):
@@ -264,8 +265,15 @@ class TactileSR(nn.Module):
             raise _lib.TactileSRHipError("TactileSR (tactilesr_amd) runs on MI355X only: move the model and "
                                          "its input to a ROCm device (no CPU fallback)")
         if self.training:
-            raise _lib.TactileSRHipError("train-mode forward (batch-statistics BatchNorm + backward) is not "
-                                         "built yet in this round; call model.eval() for inference")
+            # batch-statistics BatchNorm + autograd through the HIP backward (model/_train.py)
+            from ._train import TrainEngine, TactileSRTrainFn
+            if self._train_engine is None:
+                self._train_engine = TrainEngine(self)
+            named = list(self.named_parameters())
+            out = TactileSRTrainFn.apply(self._train_engine, [n for n, _ in named],
+                                         x.detach().float().contiguous(), *[p for _, p in named])
+            self._plan = None      # running statistics were updated in place by the kernels
+            return out
         x = x.detach().float().contiguous()
         B = x.shape[0]
         H, W = x.shape[2] * self.scale_factor, x.shape[3] * self.scale_factor

@@ -173,6 +173,20 @@ def gen_train():
     g = torch.Generator().manual_seed(seed + 1)
     LR = torch.rand(B, 3, 4, 4, generator=g) * 8
     HR_raw = torch.rand(B, 1, 100, 100, generator=g) * 250
+    # conditioning yardstick: the same reference step in fp64 (ReLU-mask flips make fp32 gradients of
+    # this net differ from exact arithmetic by 1e-4..1e-3 of their max; a faithful fp32 implementation
+    # can only be asked to sit as close to fp64 as the reference's own fp32 run does)
+    m64 = TactileSR(**cfg).double()
+    m64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()})
+    m64.train()
+    HR64 = F.interpolate(HR_raw.double() / 10, size=(40, 40), mode="bilinear", align_corners=False)
+    l64 = torch.nn.MSELoss()(m64(LR[:, :3].double()), HR64)
+    l64.backward()
+    named64 = dict(m64.named_parameters())
+    for k in keys:
+        gk = named64[k].grad
+        out[f"grad64/{k}"] = gk.flatten()[:: max(1, gk.numel() // 512)].numpy().copy()
+    out["loss64"] = np.float64(l64.item())
     losses = []
     named = dict(m.named_parameters())
     for step in range(2):
