@@ -55,7 +55,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer = BASELINE configs[1] (headline); train = data-parallel train step "
+                         "(train_cal_loss + backward + RCCL grad all-reduce + Adam), configs[3] shape")
     args = ap.parse_args()
+    if args.mode == "train":
+        return main_train(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -128,6 +133,69 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res.update(cpu_baseline_and_psnr(model, dev))
         print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_train(args):
+    """One step = Trainer_tactileSR.train_cal_loss + zero_grad/backward/Adam (reference
+    train/tactileSR_train.py:41-51, cpu/trainer.py:346-362) on a per-GPU shard of `--batch` frames;
+    N>1 adds the bucketed RCCL all-reduce of the 18.33 MB gradient (tactilesr_amd.ddp)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from tactilesr_amd import ddp, optim
+    from tactilesr_amd.train import tactileSR_train as TR
+    import tactilesr_amd
+    if world > 1:
+        import torch.distributed as dist
+        ddp.init_distributed("nccl")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(42)
+    model = tactilesr_amd.TactileSR().to(dev).train()
+    opt = optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-2)
+    sync = ddp.GradSync(model.parameters(), n_buckets=4) if world > 1 else None
+    if sync:
+        sync.broadcast_parameters(0)
+    B = args.batch if args.batch != 4096 else 2048
+    g = torch.Generator().manual_seed(42 + rank)
+    batch = ((torch.rand(B, 3, 4, 4, generator=g) * 8).to(dev), (torch.rand(B, 1, 100, 100, generator=g) * 250).to(dev))
+    conf = TR.default_config()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        TR.train_one_iter(model, opt, batch, conf, sync)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ld = TR.train_one_iter(model, opt, batch, conf, sync)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        value = B * world * args.steps / dt
+        train_flop = 3 * FWD_FLOP_PER_SAMPLE - 2 * 5_529_600 * 2
+        print(json.dumps({
+            "metric": "SR train samples/sec (4x4->40x40)", "value": round(value, 2), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "TactileSR train step (fwd+bwd+Adam L2), fp32, batch/GPU=%d (BASELINE configs[3] shape)" % B,
+                       "batch_per_gpu": B, "parallelism": f"dp{world}", "grad_allreduce_MB": 18.33},
+            "roofline": {"bound": "mfma", "achieved": round(value / world * train_flop / 1e12, 2),
+                         "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                         "frac": round(value / world * train_flop / PEAK_F32_MFMA, 4), "traffic": None,
+                         "kernel": "whole train step (43.9 GFLOP/sample algorithmic)"},
+            "loss": float(ld["total_loss"]),
+        }), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

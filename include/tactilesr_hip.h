@@ -159,6 +159,12 @@ int tsr_mse_fwd_bwd(const float* y, const float* target, float* dy, float* loss,
 int tsr_adam_l2_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
                      float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
 
+/* Per-sample PSNR / SSIM of eval_func (train/tactileSR_train.py:87-94, utility/tools.py:49-81) for B samples
+ * of n elements: PSNR = 10log10(max^2/(sum(a-b)^2/psnr_div)) with psnr_div = shape[0]*shape[1] of what the
+ * reference passes ((1,H,W) -> H, its /40 quirk; (H,W) -> H*W); SSIM = one global window. */
+int tsr_psnr_ssim(const float* a, const float* b, int B, int n, double psnr_div, double max_value,
+                  double C1, double C2, float* psnr, float* ssim, void* stream);
+
 /* Layout plumbing (tests, stage probes): NCHW (B,C,HW) <-> a channel slice of a CB16 buffer. */
 int tsr_nchw_to_cb16(const float* src, float* dst, int B, int C, int HW, int dst_ctot, int dst_coff, void* stream);
 int tsr_cb16_to_nchw(const float* src, float* dst, int B, int C, int HW, int src_ctot, int src_coff, void* stream);

@@ -530,3 +530,45 @@ extern "C" int tsr_cb16_stats(const float* z, int z_ctot, int z_coff, int B, int
                      chunks, slab, slab_cnt);
   return tsr_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------
+// Per-sample PSNR / SSIM of eval_func (train/tactileSR_train.py:87-94; utility/tools.py:49-81).
+//   PSNR = 10 log10(max^2 / (sum (a-b)^2 / psnr_div)),  psnr_div = shape[0]*shape[1] of the tensor the
+//   reference passes ((1,H,W) in eval_func -> H: the reference's /40 quirk; (H,W) -> H*W).
+//   SSIM = single global window with C1, C2.
+// One workgroup per sample, fp64 accumulation.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void psnr_ssim_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        int n, double psnr_div, double maxv, double C1, double C2,
+                                                        float* __restrict__ psnr, float* __restrict__ ssim) {
+  __shared__ double sh[256 * 6];
+  const float* pa = a + (size_t)blockIdx.x * n;
+  const float* pb = b + (size_t)blockIdx.x * n;
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double x = pa[i], y = pb[i];
+    s[0] += (x - y) * (x - y); s[1] += x; s[2] += y; s[3] += x * x; s[4] += y * y; s[5] += x * y;
+  }
+  for (int k = 0; k < 6; ++k) sh[threadIdx.x * 6 + k] = s[k];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st)
+      for (int k = 0; k < 6; ++k) sh[threadIdx.x * 6 + k] += sh[(threadIdx.x + st) * 6 + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double mse = sh[0] / psnr_div;
+    psnr[blockIdx.x] = (float)(10.0 * log10(maxv * maxv / mse));
+    const double mu1 = sh[1] / n, mu2 = sh[2] / n;
+    const double s1 = sh[3] / n - mu1 * mu1, s2 = sh[4] / n - mu2 * mu2, s12 = sh[5] / n - mu1 * mu2;
+    ssim[blockIdx.x] = (float)(((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s1 + s2 + C2)));
+  }
+}
+
+extern "C" int tsr_psnr_ssim(const float* a, const float* b, int B, int n, double psnr_div, double max_value,
+                             double C1, double C2, float* psnr, float* ssim, void* stream) {
+  if (!a || !b || !psnr || !ssim || B <= 0 || n <= 0 || psnr_div <= 0) return TSR_ERR_ARG;
+  hipLaunchKernelGGL(psnr_ssim_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a, b, n, psnr_div, max_value, C1,
+                     C2, psnr, ssim);
+  return tsr_check_launch();
+}

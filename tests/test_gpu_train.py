@@ -150,3 +150,74 @@ def test_train_forward_backward_vs_reference_golden(T, golden):
         assert int(new_sd[s + ".num_batches_tracked"]) == int(g[f"stat/{s}.num_batches_tracked"])
     # every parameter received a gradient
     assert all(p.grad is not None for p in m.parameters())
+
+
+def test_full_step_adam_vs_reference_golden(T, golden):
+    """train_cal_loss + zero_grad/backward/Adam(L2) step through the HIP path, twice; post-step weights,
+    running stats and the second-step loss vs the reference's own run."""
+    from tactilesr_amd import optim
+    from tactilesr_amd.train import tactileSR_train as TR
+    g = golden("train")
+    cfg = dict(patternFeatureExtraLayerCnt=2)
+    sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), int(g["seed"]))
+    m = T.TactileSR(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    opt = optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-2)
+    conf = TR.default_config()
+    batch = (torch.from_numpy(g["LR"]), torch.from_numpy(g["HR_raw"]))
+    l0 = TR.train_one_iter(m, opt, batch, conf)["total_loss"].item()
+    assert abs(l0 - g["losses"][0]) <= 1e-5 * abs(g["losses"][0])
+    new_sd = m.state_dict()
+    for k in [str(k) for k in g["keys"]]:
+        w = new_sd[k]
+        # Adam's first step moves every weight by ~lr*sign(g): a sign flip of a ~0 gradient moves a weight by 2*lr
+        diff = np.abs(_subs(w) - g[f"w1/{k}"])
+        frac_off = float((diff > 1e-6 + 1e-5 * np.abs(g[f"w1/{k}"])).mean())
+        assert diff.max() <= 2.1e-3 and frac_off < 0.02, (k, diff.max(), frac_off)
+    l1 = TR.train_one_iter(m, opt, batch, conf)["total_loss"].item()
+    assert abs(l1 - g["losses"][1]) <= 2e-4 * abs(g["losses"][1])
+    assert int(opt.state[next(iter(m.parameters()))]["step"]) == 2
+
+
+def test_target_prep_mse_and_metrics(T, golden):
+    from tactilesr_amd import functional as Fh
+    g = golden("train")
+    HR = Fh.prepare_target(torch.from_numpy(g["HR_raw"]).cuda(), 10.0, 10)
+    assert relerr(HR, torch.from_numpy(g["HR_prepared"])) < 1e-6
+    gm = golden("metrics")
+    a, b = torch.from_numpy(gm["a"]).cuda(), torch.from_numpy(gm["b"]).cuda()
+    ps, ss = Fh.psnr_ssim(a, b, 250.0, reference_quirk=True)
+    assert np.abs(ps.cpu().numpy() - gm["psnr_140"]).max() < 1e-3
+    assert np.abs(ss.cpu().numpy() - gm["ssim_140"]).max() < 1e-6
+    ps2, _ = Fh.psnr_ssim(a, b, 250.0, reference_quirk=False)
+    assert np.abs(ps2.cpu().numpy() - gm["psnr_40"]).max() < 1e-3
+    y = a.clone().requires_grad_(True)
+    loss = Fh.mse_loss(y, b)
+    ref = torch.nn.functional.mse_loss(a.cpu(), b.cpu())
+    assert abs(loss.item() - ref.item()) < 1e-6 * ref.item()
+    loss.backward()
+    assert relerr(y.grad, 2 * (a - b).cpu() / a.numel()) < 1e-6
+
+
+def test_eval_func_after_training_uses_updated_running_stats(T):
+    """eval after a train step must see the running statistics the kernels updated in place."""
+    from tactilesr_amd import optim
+    from tactilesr_amd.train import tactileSR_train as TR
+    torch.manual_seed(3)
+    m = T.TactileSR(patternFeatureExtraLayerCnt=1).cuda()
+    conf = TR.default_config()
+    g = torch.Generator().manual_seed(5)
+    batch = (torch.rand(6, 3, 4, 4, generator=g) * 8, torch.rand(6, 1, 100, 100, generator=g) * 250)
+    m.eval()
+    y0 = m(batch[0].cuda())
+    m.train()
+    opt = optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-2)
+    TR.train_one_iter(m, opt, batch, conf)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    loss, ssim, psnr = TR.eval_func(m, [batch], conf)
+    with torch.no_grad():
+        ref_mse, ref_psnr, ref_ssim = O.eval_batch(sd, batch[0], batch[1], 250.0)
+    assert abs(loss - ref_mse) < 1e-4 * ref_mse
+    assert abs(psnr - ref_psnr) < 1e-2 and abs(ssim - ref_ssim) < 1e-4
+    assert not torch.equal(m(batch[0].cuda()), y0)
