@@ -165,6 +165,26 @@ int tsr_adam_l2_step(float* param, const float* grad, float* exp_avg, float* exp
 int tsr_psnr_ssim(const float* a, const float* b, int B, int n, double psnr_div, double max_value,
                   double C1, double C2, float* psnr, float* ssim, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * tPSFNet (model/tPSFNet.py): batched, one workgroup per sample (the reference loops over the
+ * batch in python, :118-125).  size is fixed at 100x100 depth / 99x99 PSF / 4x4 taxels, as the
+ * reference's geometry constants are (:40-55).
+ * ------------------------------------------------------------------------------------- */
+/* tactilePSF + depth2tactile + degradation_process (:78-100,129-141) from alpha_beta (B,3) =
+ * (alpha, beta, gamma): HR (B,1,100,100), LR_deg (B,1,4,4), psf (B,1,99,99).  Separable form. */
+int tpsf_forward(const float* depth, const float* alpha_beta, float* HR, float* LR_deg, float* psf,
+                 int B, void* stream);
+/* d loss / d (alpha, beta, gamma) (B,3) given d loss / d LR_deg (B,16); plateau pixels carry no
+ * gradient, depth carries none (autograd of :118-125 as used by train/tPSFNet_train.py:180-190). */
+int tpsf_backward(const float* depth, const float* alpha_beta, const float* dLR_deg, float* d_alpha_beta,
+                  int B, void* stream);
+/* C[i][j] = act(sum_k A(i,k)B(k,j) + bias[j]), A(i,k)=A[i*sa0+k*sa1], B(k,j)=B[k*sb0+j*sb1]; act 0 none,
+ * 1 ReLU, 2 Softplus: the nn.Linear layers of MLP_layer (:26-36) and their backward GEMMs. */
+int tsr_sgemm(const float* A, long long sa0, long long sa1, const float* B, long long sb0, long long sb1,
+              const float* bias, float* C, int M, int N, int K, int act, void* stream);
+/* dy *= act'(.) in place from the stored activation output (1 ReLU, 2 Softplus). */
+int tsr_act_bwd(float* dy, const float* y, long long n, int mode, void* stream);
+
 /* Layout plumbing (tests, stage probes): NCHW (B,C,HW) <-> a channel slice of a CB16 buffer. */
 int tsr_nchw_to_cb16(const float* src, float* dst, int B, int C, int HW, int dst_ctot, int dst_coff, void* stream);
 int tsr_cb16_to_nchw(const float* src, float* dst, int B, int C, int HW, int src_ctot, int src_coff, void* stream);

@@ -6,5 +6,6 @@ HIP kernel in ``lib/libtactilesr_hip.so`` reached through the C ABI of
 """
 from . import _lib  # noqa: F401
 from .model.tactileSR_model import TactileSR, MSRB, ResBlock  # noqa: F401
+from .model.tPSFNet import tPSFNet  # noqa: F401
 
-__all__ = ["TactileSR", "MSRB", "ResBlock"]
+__all__ = ["TactileSR", "MSRB", "ResBlock", "tPSFNet"]

@@ -40,6 +40,10 @@ SIGNATURES = {
     "tsr_mse_fwd_bwd": [_P, _P, _P, _P, _L, _F, _P, _P],
     "tsr_adam_l2_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
     "tsr_psnr_ssim": [_P, _P, _I, _I, c_double, c_double, c_double, c_double, _P, _P, _P],
+    "tpsf_forward": [_P, _P, _P, _P, _P, _I, _P],
+    "tpsf_backward": [_P, _P, _P, _P, _I, _P],
+    "tsr_sgemm": [_P, _L, _L, _P, _L, _L, _P, _P, _I, _I, _I, _I, _P],
+    "tsr_act_bwd": [_P, _P, _L, _I, _P],
     "tsr_nchw_to_cb16": [_P, _P, _I, _I, _I, _I, _I, _P],
     "tsr_cb16_to_nchw": [_P, _P, _I, _I, _I, _I, _I, _P],
 }

@@ -1,0 +1,369 @@
+// tPSFNet on MI355X: the tactile point-spread-function forward model
+// (reference model/tPSFNet.py:78-141) and its backward, batched -- one workgroup per sample, no
+// python loop over the batch (the reference iterates samples at :118-125).
+//
+//   alphaBeta = MLP(x)                           (tsr_sgemm below: Linear+ReLU x3, Linear+Softplus)
+//   psf  = a * exp(-sdf^2 / b^2),  sdf = 10*dist((u,v),(49,49))/dist_max            (:43-46,78-83)
+//   HR   = conv2d(ZeroPad48(depth), psf, padding=1)  -> 100x100                      (:85-89)
+//   HR[mask] = max(HR outside mask, 0), mask = depth > depth.max() - 1e-3            (:86,95-97)
+//   LRd[i][j] = 1e-4 * sum(HR * m'_ij), m' = minmax-normalised exp(-msdf^2 / gamma)  (:129-141)
+//
+// The PSF is separable, psf[u][v] = a*g(u)*g(v), g(t) = exp(-Kp (t-49)^2 / b^2), Kp = 100/(2*49^2),
+// so the 99x99 per-sample convolution (196 MFLOP direct) is two 99-tap passes (3.96 MFLOP) held in
+// LDS; the 16 Gaussian masks are separable too, and their global min-max normaliser is analytic:
+// max = 1 (d = 0), min = exp(-100/gamma) (the farthest pixel, where the scaled sdf is exactly 10).
+// HBM traffic: depth in (40 KB), HR out (40 KB), psf out (39 KB) per sample -> HBM-bound.
+#include "tsr_common.h"
+
+#define PS 99
+#define HS 100
+#define NPIX (HS * HS)
+#define KP (100.0f / 4802.0f)      // 10^2 / (49^2 + 49^2)
+#define KM (100.0f / 15138.0f)     // 10^2 / (87^2 + 87^2): farthest pixel (99,99) from centre (12,12)
+
+__device__ __forceinline__ float block_reduce_max(float v, float* sh) {
+  const int tid = threadIdx.x;
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  __syncthreads();
+  if ((tid & 63) == 0) sh[tid >> 6] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int k = 1; k < (int)(blockDim.x >> 6); ++k) r = fmaxf(r, sh[k]);
+  return r;
+}
+
+__device__ __forceinline__ double block_reduce_sum(double v, double* sh) {
+  const int tid = threadIdx.x;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((tid & 63) == 0) sh[tid >> 6] = v;
+  __syncthreads();
+  double r = 0;
+  for (int k = 0; k < (int)(blockDim.x >> 6); ++k) r += sh[k];
+  return r;
+}
+
+// row pass: R[y][x] = sum_v D[y][x+v-49] * f[v]  (zero padded)
+__device__ __forceinline__ void row_pass(const float* __restrict__ D, const float* __restrict__ f,
+                                         float* __restrict__ R) {
+  for (int i = threadIdx.x; i < NPIX; i += blockDim.x) {
+    const int y = i / HS, x = i - y * HS;
+    const int v0 = 49 - x > 0 ? 49 - x : 0;
+    const int v1 = 148 - x < PS - 1 ? 148 - x : PS - 1;
+    const float* dr = D + y * HS + x - 49;
+    float s = 0.f;
+    for (int v = v0; v <= v1; ++v) s = fmaf(dr[v], f[v], s);
+    R[i] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void tpsf_fwd_kernel(const float* __restrict__ depth,
+                                                       const float* __restrict__ ab,   // (B,3)
+                                                       float* __restrict__ HR, float* __restrict__ LRd,
+                                                       float* __restrict__ psf) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* D = sm;                 // [100][100] depth, later the final HR
+  float* R = sm + NPIX;          // [100][100] row pass
+  float* g = R + NPIX;           // [99]
+  float* ea = g + 128;           // [4][100] mask factors
+  float* P = ea + 400;           // [4][100]
+  float* red = P + 400;          // [8]
+  double* redd = (double*)(red + 8);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float alpha = ab[b * 3 + 0], beta = ab[b * 3 + 1], gamma = ab[b * 3 + 2];
+  const float cpsf = KP / (beta * beta);
+  const float cm = KM / gamma;
+  for (int i = tid; i < PS; i += 256) { const float t = (float)(i - 49); g[i] = expf(-cpsf * t * t); }
+  for (int i = tid; i < 400; i += 256) {
+    const int a = i / 100, x = i - a * 100;
+    const float t = (float)(x - (12 + 25 * a));
+    ea[i] = expf(-cm * t * t);
+  }
+  const float* dp = depth + (size_t)b * NPIX;
+  float dmax = -INFINITY;
+  for (int i = tid; i < NPIX; i += 256) { const float v = dp[i]; D[i] = v; dmax = fmaxf(dmax, v); }
+  dmax = block_reduce_max(dmax, red);
+  __syncthreads();
+  // psf output (B,1,99,99)
+  float* pp = psf + (size_t)b * PS * PS;
+  for (int i = tid; i < PS * PS; i += 256) { const int u = i / PS, v = i - u * PS; pp[i] = alpha * (g[u] * g[v]); }
+  row_pass(D, g, R);
+  __syncthreads();
+  // column pass + plateau mask; raw HR kept in registers (40 px / thread)
+  float hr[40];
+  float fmax_out = 0.f;          // tmp[mask] = 0 takes part in the max (the mask is never empty)
+  const float thr = dmax - 1e-3f;
+#pragma unroll
+  for (int k = 0; k < 40; ++k) {
+    const int i = tid + k * 256;
+    hr[k] = 0.f;
+    if (i < NPIX) {
+      const int y = i / HS, x = i - y * HS;
+      const int u0 = 49 - y > 0 ? 49 - y : 0;
+      const int u1 = 148 - y < PS - 1 ? 148 - y : PS - 1;
+      float s = 0.f;
+      for (int u = u0; u <= u1; ++u) s = fmaf(R[(y + u - 49) * HS + x], g[u], s);
+      hr[k] = alpha * s;
+      if (!(D[i] > thr)) fmax_out = fmaxf(fmax_out, hr[k]);
+    }
+  }
+  const float fill = block_reduce_max(fmax_out, red);
+  __syncthreads();
+  float* hp = HR + (size_t)b * NPIX;
+  double s0 = 0;
+#pragma unroll
+  for (int k = 0; k < 40; ++k) {
+    const int i = tid + k * 256;
+    if (i < NPIX) {
+      const float v = D[i] > thr ? fill : hr[k];
+      hp[i] = v;
+      s0 += (double)v;
+      R[i] = v;               // final HR for the pooling (R is free now)
+    }
+  }
+  const double S0 = block_reduce_sum(s0, redd);
+  __syncthreads();
+  // separable Gaussian-masked pooling: P[a][col] = sum_row ea[a][row] * HR[row][col]
+  for (int i = tid; i < 400; i += 256) {
+    const int a = i / 100, col = i - a * 100;
+    float s = 0.f;
+    for (int row = 0; row < HS; ++row) s = fmaf(ea[a * 100 + row], R[row * HS + col], s);
+    P[i] = s;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const int a = tid >> 2, c = tid & 3;
+    float s = 0.f;
+    for (int col = 0; col < HS; ++col) s = fmaf(P[a * 100 + col], ea[c * 100 + col], s);
+    const float mn = expf(-100.0f / gamma);
+    LRd[b * 16 + tid] = (s - mn * (float)S0) / (1.0f - mn) * 1e-4f;
+  }
+}
+
+// Backward of the forward model w.r.t. (alpha, beta, gamma) for one sample, given dL/dLRd (16).
+__global__ __launch_bounds__(256) void tpsf_bwd_kernel(const float* __restrict__ depth, const float* __restrict__ ab,
+                                                       const float* __restrict__ dLRd, float* __restrict__ dab) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* D = sm;                 // depth, later final HR
+  float* Rg = sm + NPIX;         // row pass with g
+  float* Rh = Rg + NPIX;         // row pass with h = (t-49)^2 g
+  float* g = Rh + NPIX;          // [99]
+  float* h = g + 128;            // [99]
+  float* ea = h + 128;           // [4][100]
+  float* ea2 = ea + 400;         // [4][100]  ea * (x-cx)^2
+  float* P = ea2 + 400;          // [4][100]  sum_row ea*HR
+  float* P2 = P + 400;           // [4][100]  sum_row ea2*HR
+  float* dl = P2 + 400;          // [16]
+  float* red = dl + 16;          // [8]
+  double* redd = (double*)(red + 8);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float alpha = ab[b * 3 + 0], beta = ab[b * 3 + 1], gamma = ab[b * 3 + 2];
+  const float cpsf = KP / (beta * beta);
+  const float cm = KM / gamma;
+  const float mn = expf(-100.0f / gamma);
+  for (int i = tid; i < PS; i += 256) {
+    const float t = (float)(i - 49);
+    g[i] = expf(-cpsf * t * t);
+    h[i] = t * t * g[i];
+  }
+  for (int i = tid; i < 400; i += 256) {
+    const int a = i / 100, x = i - a * 100;
+    const float t = (float)(x - (12 + 25 * a));
+    ea[i] = expf(-cm * t * t);
+    ea2[i] = t * t * ea[i];
+  }
+  if (tid < 16) dl[tid] = dLRd[b * 16 + tid];
+  const float* dp = depth + (size_t)b * NPIX;
+  float dmax = -INFINITY;
+  for (int i = tid; i < NPIX; i += 256) { const float v = dp[i]; D[i] = v; dmax = fmaxf(dmax, v); }
+  dmax = block_reduce_max(dmax, red);
+  __syncthreads();
+  row_pass(D, g, Rg);
+  row_pass(D, h, Rh);
+  __syncthreads();
+  const float thr = dmax - 1e-3f;
+  float hr[40], dhb[40];
+  float fmax_out = 0.f;
+#pragma unroll
+  for (int k = 0; k < 40; ++k) {
+    const int i = tid + k * 256;
+    hr[k] = 0.f; dhb[k] = 0.f;
+    if (i < NPIX) {
+      const int y = i / HS, x = i - y * HS;
+      const int u0 = 49 - y > 0 ? 49 - y : 0;
+      const int u1 = 148 - y < PS - 1 ? 148 - y : PS - 1;
+      float s = 0.f, sb = 0.f;
+      for (int u = u0; u <= u1; ++u) {
+        const float rg = Rg[(y + u - 49) * HS + x], rh = Rh[(y + u - 49) * HS + x];
+        s = fmaf(rg, g[u], s);
+        sb = fmaf(rg, h[u], fmaf(rh, g[u], sb));
+      }
+      hr[k] = alpha * s;
+      dhb[k] = sb;                              // d(raw conv)/d(cpsf) = -sb ; times dcpsf/dbeta below
+      if (!(D[i] > thr)) fmax_out = fmaxf(fmax_out, hr[k]);
+    }
+  }
+  const float fill = block_reduce_max(fmax_out, red);
+  __syncthreads();
+  // G[row][col] = dL/dHR = 1e-4/(1-mn) * sum_ab dl_ab (ea_a(row) eb_b(col) - mn), zero on the plateau
+  const float k0 = 1e-4f / (1.0f - mn);
+  float dlsum = 0.f;
+  for (int t = 0; t < 16; ++t) dlsum += dl[t];
+  double da = 0, db = 0, s0 = 0;
+#pragma unroll
+  for (int k = 0; k < 40; ++k) {
+    const int i = tid + k * 256;
+    if (i < NPIX) {
+      const int row = i / HS, col = i - row * HS;
+      const bool plateau = D[i] > thr;
+      const float v = plateau ? fill : hr[k];
+      s0 += (double)v;
+      if (!plateau) {
+        float gsum = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const float er = ea[a * 100 + row];
+          gsum += er * (dl[a * 4 + 0] * ea[0 * 100 + col] + dl[a * 4 + 1] * ea[1 * 100 + col] +
+                        dl[a * 4 + 2] * ea[2 * 100 + col] + dl[a * 4 + 3] * ea[3 * 100 + col]);
+        }
+        const float G = k0 * (gsum - mn * dlsum);
+        da += (double)(G * hr[k]);
+        db += (double)(G * dhb[k]);
+      }
+      Rg[i] = v;      // final HR; every column-pass read of Rg finished before the fill reduction's barrier
+    }
+  }
+  __syncthreads();
+  const double S0 = block_reduce_sum(s0, redd);
+  const double DA = block_reduce_sum(da, redd);
+  const double DB = block_reduce_sum(db, redd);
+  __syncthreads();
+  for (int i = tid; i < 400; i += 256) {
+    const int a = i / 100, col = i - a * 100;
+    float s = 0.f, s2 = 0.f;
+    for (int row = 0; row < HS; ++row) {
+      const float v = Rg[row * HS + col];
+      s = fmaf(ea[a * 100 + row], v, s);
+      s2 = fmaf(ea2[a * 100 + row], v, s2);
+    }
+    P[i] = s; P2[i] = s2;
+  }
+  __syncthreads();
+  double dg = 0;
+  if (tid < 16) {
+    const int a = tid >> 2, c = tid & 3;
+    float S = 0.f, Sd = 0.f;    // S_ab = sum HR m_ab ; Sd = sum HR m_ab d^2_ab
+    for (int col = 0; col < HS; ++col) {
+      S = fmaf(P[a * 100 + col], ea[c * 100 + col], S);
+      Sd = fmaf(P2[a * 100 + col], ea[c * 100 + col], fmaf(P[a * 100 + col], ea2[c * 100 + col], Sd));
+    }
+    const double gm = gamma, mnd = mn;
+    const double mnp = mnd * 100.0 / (gm * gm);                 // d mn / d gamma
+    const double dS = (double)Sd * (double)KM / (gm * gm);      // d S_ab / d gamma
+    const double num = (double)S - mnd * S0, den = 1.0 - mnd;
+    const double dLR = 1e-4 * ((dS - mnp * S0) * den + num * mnp) / (den * den);
+    dg = (double)dl[tid] * dLR;
+  }
+  const double DG = block_reduce_sum(dg, redd);
+  if (tid == 0) {
+    dab[b * 3 + 0] = (float)(DA / (double)alpha);
+    // raw = sum D e^{-cpsf r^2}: d raw/d beta = sum D e r^2 * 2 KP / beta^3 ; HR = alpha*raw
+    dab[b * 3 + 1] = (float)(DB * (double)alpha * 2.0 * (double)KP / ((double)beta * beta * beta));
+    dab[b * 3 + 2] = (float)DG;
+  }
+}
+
+extern "C" int tpsf_forward(const float* depth, const float* alpha_beta, float* HR, float* LR_deg, float* psf,
+                            int B, void* stream) {
+  if (!depth || !alpha_beta || !HR || !LR_deg || !psf || B <= 0) return TSR_ERR_ARG;
+  const size_t smem = (size_t)(2 * NPIX + 128 + 400 + 400 + 8 + 16) * 4;
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)tpsf_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(tpsf_fwd_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, depth, alpha_beta, HR, LR_deg, psf);
+  return tsr_check_launch();
+}
+
+extern "C" int tpsf_backward(const float* depth, const float* alpha_beta, const float* dLR_deg, float* d_alpha_beta,
+                             int B, void* stream) {
+  if (!depth || !alpha_beta || !dLR_deg || !d_alpha_beta || B <= 0) return TSR_ERR_ARG;
+  const size_t smem = (size_t)(3 * NPIX + 256 + 1600 + 16 + 8 + 16) * 4;
+  static bool attr = false;
+  if (!attr) { hipFuncSetAttribute((const void*)tpsf_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(tpsf_bwd_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, depth, alpha_beta, dLR_deg,
+                     d_alpha_beta);
+  return tsr_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// small strided SGEMM with fused bias + activation, for the 48-256-1024-256-3 MLP and its backward:
+//   C[i][j] = act( sum_k A(i,k) B(k,j) + bias[j] ),  A(i,k) = A[i*sa0+k*sa1], B(k,j) = B[k*sb0+j*sb1]
+// act: 0 none, 1 ReLU, 2 Softplus(beta=1, threshold=20).  64x64 tile, 4x4 per thread, fp32 fma.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, long sa0, long sa1,
+                                                    const float* __restrict__ Bm, long sb0, long sb1,
+                                                    const float* __restrict__ bias, float* __restrict__ C, int M,
+                                                    int N, int K, int act) {
+  __shared__ float As[16][65], Bs[16][65];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    for (int t = tid; t < 16 * 64; t += 256) {
+      const int kk = t & 15, ii = t >> 4;
+      const int gi = i0 + ii, gk = k0 + kk;
+      As[kk][ii] = (gi < M && gk < K) ? A[gi * sa0 + gk * sa1] : 0.f;
+      const int gj = j0 + ii;
+      Bs[kk][ii] = (gj < N && gk < K) ? Bm[gk * sb0 + gj * sb1] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], bb[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { a[r] = As[kk][ty * 4 + r]; bb[r] = Bs[kk][tx * 4 + r]; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(a[r], bb[c], acc[r][c]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int gi = i0 + ty * 4 + r, gj = j0 + tx * 4 + c;
+      if (gi < M && gj < N) {
+        float v = acc[r][c] + (bias ? bias[gj] : 0.f);
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = v > 20.f ? v : log1pf(expf(v));
+        C[(size_t)gi * N + gj] = v;
+      }
+    }
+}
+
+extern "C" int tsr_sgemm(const float* A, long long sa0, long long sa1, const float* B, long long sb0, long long sb1,
+                         const float* bias, float* C, int M, int N, int K, int act, void* stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return TSR_ERR_ARG;
+  hipLaunchKernelGGL(sgemm_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, A, (long)sa0,
+                     (long)sa1, B, (long)sb0, (long)sb1, bias, C, M, N, K, act);
+  return tsr_check_launch();
+}
+
+// dz = dy * act'(.)  in place, from the stored OUTPUT y of the activation: mode 1 ReLU (y > 0);
+// mode 2 Softplus: y = log(1+e^z)  =>  sigmoid(z) = 1 - e^{-y} = -expm1(-y).
+__global__ void act_bwd_kernel(float* __restrict__ dy, const float* __restrict__ ref, size_t n, int mode) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float r = ref[i];
+    if (mode == 1) dy[i] = r > 0.f ? dy[i] : 0.f;
+    else dy[i] = dy[i] * (-expm1f(-r));
+  }
+}
+
+extern "C" int tsr_act_bwd(float* dy, const float* ref, long long n, int mode, void* stream) {
+  if (!dy || !ref || n <= 0 || (mode != 1 && mode != 2)) return TSR_ERR_ARG;
+  const size_t g = ((size_t)n + 255) / 256;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(g > 4096 ? 4096 : (int)g), dim3(256), 0, (hipStream_t)stream, dy, ref,
+                     (size_t)n, mode);
+  return tsr_check_launch();
+}

@@ -1,0 +1,61 @@
+"""GPU parity of the batched tPSFNet path against the reference's own outputs (tests/golden/tpsf.npz:
+forward 4-tuple, trainer loss, MLP gradients)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tactilesr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def test_tpsf_forward_backward_vs_reference_golden(golden):
+    import tactilesr_amd
+    from tactilesr_amd.train import tPSFNet_train as TP
+    g = golden("tpsf")
+    sd = O.random_state_dict(O.tpsf_state_shapes(), int(g["seed"]))
+    net = tactilesr_amd.tPSFNet(gama=1.4, perception_scale=None, device="cuda")
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda()
+    LR_raw, depth = torch.from_numpy(g["LR_raw"]).cuda(), torch.from_numpy(g["depth"]).cuda()
+    HR, LRd, psf, ab = net(LR_raw / 100, depth.unsqueeze(1))
+    assert HR.shape == (4, 1, 100, 100) and LRd.shape == (4, 1, 4, 4) and psf.shape == (4, 1, 99, 99) \
+        and ab.shape == (4, 1, 3)
+    assert relerr(ab, torch.from_numpy(g["alphaBeta"])) < 1e-5
+    assert relerr(HR, torch.from_numpy(g["HR"])) < 1e-5
+    assert relerr(LRd, torch.from_numpy(g["LR_deg"])) < 1e-5
+    assert relerr(psf[:, 0, ::7, ::7], torch.from_numpy(g["psf_probe"])) < 1e-5
+    assert np.abs(psf.double().sum(dim=(1, 2, 3)).cpu().numpy() - g["psf_sum"]).max() < 1e-5 * np.abs(g["psf_sum"]).max()
+    loss, _ = TP.train_cal_loss(net, (LR_raw, depth), 100.0)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    loss.backward()
+    for k, p in net.named_parameters():
+        ref = torch.from_numpy(g[f"grad/{k}"])
+        err = relerr(p.grad, ref)
+        print(f"[tpsf grad] {k}: {err:.2e}")
+        assert err < 1e-4, (k, err)
+
+
+def test_tpsf_large_batch_properties():
+    """Batch independence at a size the oracle cannot run in seconds: any sample's outputs equal the same
+    sample processed alone; psf is symmetric; plateau pixels all hold one value."""
+    import tactilesr_amd
+    torch.manual_seed(0)
+    net = tactilesr_amd.tPSFNet(1.4, None).cuda()
+    B = 257
+    g = torch.Generator().manual_seed(1)
+    depth = (torch.rand(B, 1, 100, 100, generator=g) > 0.7).float().cuda()
+    x = (torch.rand(B, 3, 4, 4, generator=g) * 8).cuda()
+    with torch.no_grad():
+        HR, LRd, psf, ab = net(x, depth)
+        HR1, LRd1, psf1, ab1 = net(x[200:201], depth[200:201])
+    assert torch.equal(HR[200:201], HR1) and torch.equal(LRd[200:201], LRd1) and torch.equal(psf[200:201], psf1)
+    assert torch.equal(psf, psf.transpose(2, 3))
+    m = depth[5, 0] > depth[5, 0].max() - 1e-3
+    assert HR[5, 0][m].unique().numel() == 1
