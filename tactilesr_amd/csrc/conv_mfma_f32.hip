@@ -18,6 +18,7 @@
 // fp32-faithful (1e-5 relative parity with the reference's CPU path).
 #include "tsr_common.h"
 #include "tactilesr_hip.h"
+#include <stdlib.h>
 
 struct ConvArgs {
   const float* in;  int in_ctot;  int in_coff;  int cin;
@@ -45,8 +46,10 @@ struct ConvArgs {
   float* slab; float* slab_cnt;
 };
 
-template <int KS, int COUT>
-__global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const ConvArgs a) {
+// EXT = training-path extensions compiled in (input/residual transforms, epi_mode 1/2);
+// PF  = prefetch the next channel block's halo slab into registers during the current block.
+template <int KS, int COUT, bool EXT, bool PF>
+__global__ __launch_bounds__(256, 3) void conv_mfma_f32_kernel(const ConvArgs a) {
   constexpr int IMG = 2;
   constexpr int P = KS / 2;
   constexpr int HH = 8 + KS - 1;       // halo edge
@@ -125,17 +128,26 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const ConvArgs a) {
     for (int v = 0; v < WV; ++v) wreg[v] = src[tid + v * 256];
   }
 
+  // halo slab of channel block 0 -> registers; block c+1 is fetched while block c's taps compute
+  f32x4 hv[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    hv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (PF && st_src[k] >= 0) hv[k] = *(const f32x4*)(in_base + st_src[k]);
+  }
+
   int s = 0;
   for (int c = 0; c < nchunk; ++c) {
     // ---- stage the halo slab of channel block c (previous block's readers must be done)
-    f32x4 hv[NIT];
-    const float* inc = in_base + (size_t)c * HW * 16;
+    if (!PF) {
+      const float* inc = in_base + (size_t)c * HW * 16;
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      hv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (st_src[k] >= 0) hv[k] = *(const f32x4*)(inc + st_src[k]);
+      for (int k = 0; k < NIT; ++k) {
+        hv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (st_src[k] >= 0) hv[k] = *(const f32x4*)(inc + st_src[k]);
+      }
     }
-    if (a.in_scale) {   // wave-uniform branch: train-mode BN+ReLU of the producer, fused into the load
+    if (EXT && a.in_scale) {   // wave-uniform branch: train-mode BN+ReLU of the producer, fused into the load
 #pragma unroll
       for (int k = 0; k < NIT; ++k) {
         if (st_src[k] >= 0) {
@@ -151,6 +163,12 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const ConvArgs a) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k)
       if (st_dst[k] >= 0) *(f32x4*)(halo + st_dst[k]) = hv[k];
+    if (PF && c + 1 < nchunk) {   // next block's slab: in flight during this block's k*k tap steps
+      const float* inc = in_base + (size_t)(c + 1) * HW * 16;
+#pragma unroll
+      for (int k = 0; k < NIT; ++k)
+        if (st_src[k] >= 0) hv[k] = *(const f32x4*)(inc + st_src[k]);
+    }
 
 #pragma unroll
     for (int kh = 0; kh < KS; ++kh) {
@@ -204,13 +222,13 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const ConvArgs a) {
       const int rc = a.res_coff + n;
       rbase = a.res + (((size_t)bsafe * res_blocks + (rc >> 4)) * HW) * 16 + (rc & 15);
     }
-    if (a.epi_mode == 0) {
+    if (!EXT || a.epi_mode == 0) {
       // y = acc*scale + shift (+ residual) (ReLU) -> channel slice of out
       if (!img_ok) continue;
       const float sc = a.scale ? a.scale[n] : 1.f;
       const float sh = a.shift ? a.shift[n] : 0.f;
-      const float rsc = a.res_scale ? a.res_scale[n] : 1.f;
-      const float rsh = a.res_scale ? a.res_shift[n] : 0.f;
+      const float rsc = (EXT && a.res_scale) ? a.res_scale[n] : 1.f;
+      const float rsh = (EXT && a.res_scale) ? a.res_shift[n] : 0.f;
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
@@ -222,7 +240,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const ConvArgs a) {
             float v = acc[mb][nb][r] * sc + sh;
             if (rbase) {
               float rv = rbase[po];
-              if (a.res_scale) rv = fmaxf(fmaf(rv, rsc, rsh), 0.f);
+              if (EXT && a.res_scale) rv = fmaxf(fmaf(rv, rsc, rsh), 0.f);
               v += rv;
             }
             if (a.relu) v = fmaxf(v, 0.f);
@@ -230,7 +248,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const ConvArgs a) {
           }
         }
       }
-    } else if (a.epi_mode == 1) {
+    } else if (EXT && a.epi_mode == 1) {
       // raw accumulator out + Welford partial (mean, M2) of this wave's valid pixels
       float cnt = 0.f, sum = 0.f;
 #pragma unroll
@@ -274,7 +292,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(const ConvArgs a) {
         sl[1] = m2m;
         if (nb == 0 && li == 0 && wn == 0) a.slab_cnt[e] = nt;
       }
-    } else {
+    } else if (EXT) {
       // ReLU backward by the stored activation (+ optional BN-backward partial sums)
       const int mc = a.mask_coff + n;
       const float* mbase = a.mask + (((size_t)bsafe * mask_blocks + (mc >> 4)) * HW) * 16 + (mc & 15);
@@ -334,11 +352,20 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
   }
 }
 
-template <int KS, int COUT>
+static int g_prefetch = -1;   // TSR_CONV_PREFETCH=0/1 (tuning knob; default per instantiation below)
+
+template <int KS, int COUT, bool EXT>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
   const int groups = (a.B + 1) / 2;
   const int grid = groups * a.tiles_x * a.tiles_y;
-  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, COUT>), dim3(grid), dim3(256), 0, st, a);
+  if (g_prefetch < 0) {
+    const char* e = getenv("TSR_CONV_PREFETCH");
+    g_prefetch = e ? atoi(e) : 0;
+  }
+  if (g_prefetch)
+    hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, COUT, EXT, true>), dim3(grid), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, COUT, EXT, false>), dim3(grid), dim3(256), 0, st, a);
   return tsr_check_launch();
 }
 
@@ -385,15 +412,16 @@ extern "C" int tsr_pack_conv_weight(const float* w_oihw, float* w_packed, int co
   return tsr_check_launch();
 }
 
+template <bool EXT>
 static int dispatch_conv(const ConvArgs& a, int cout, int ks, hipStream_t st) {
   if (cout == 64) {
-    if (ks == 1) return launch_conv<1, 64>(a, st);
-    if (ks == 3) return launch_conv<3, 64>(a, st);
-    if (ks == 5) return launch_conv<5, 64>(a, st);
+    if (ks == 1) return launch_conv<1, 64, EXT>(a, st);
+    if (ks == 3) return launch_conv<3, 64, EXT>(a, st);
+    if (ks == 5) return launch_conv<5, 64, EXT>(a, st);
   } else if (cout == 128) {
-    if (ks == 1) return launch_conv<1, 128>(a, st);
-    if (ks == 3) return launch_conv<3, 128>(a, st);
-    if (ks == 5) return launch_conv<5, 128>(a, st);
+    if (ks == 1) return launch_conv<1, 128, EXT>(a, st);
+    if (ks == 3) return launch_conv<3, 128, EXT>(a, st);
+    if (ks == 5) return launch_conv<5, 128, EXT>(a, st);
   }
   return TSR_ERR_ARG;
 }
@@ -421,7 +449,7 @@ extern "C" int tsr_conv2d_fwd(const float* in, int in_ctot, int in_coff, int cin
   a.out = out; a.out_ctot = out_ctot; a.out_coff = out_coff; a.relu = relu;
   a.B = B; a.H = H; a.W = W;
   a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8;
-  return dispatch_conv(a, cout, ks, (hipStream_t)stream);
+  return dispatch_conv<false>(a, cout, ks, (hipStream_t)stream);
 }
 
 // Number of (workgroup, image) slab entries a tsr_conv2d_ex launch of this shape emits.
@@ -455,5 +483,5 @@ extern "C" int tsr_conv2d_ex(const tsr_conv_desc* d, void* stream) {
   a.mask_scale = d->mask_scale; a.mask_shift = d->mask_shift;
   a.bn_a = d->bn_a; a.bn_b = d->bn_b;
   a.slab = d->slab; a.slab_cnt = d->slab_cnt;
-  return dispatch_conv(a, d->cout, d->ks, (hipStream_t)stream);
+  return dispatch_conv<true>(a, d->cout, d->ks, (hipStream_t)stream);
 }

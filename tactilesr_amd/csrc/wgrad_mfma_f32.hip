@@ -27,7 +27,7 @@ struct WgradArgs {
 };
 
 template <int KS>
-__global__ __launch_bounds__(256) void wgrad_mfma_f32_kernel(const WgradArgs g) {
+__global__ __launch_bounds__(256, 3) void wgrad_mfma_f32_kernel(const WgradArgs g) {
   constexpr int P = KS / 2;
   constexpr int HWD = 8 + KS - 1;   // staged input columns
   constexpr int DS = 68;            // floats per pixel row (64 ch + 4 pad)
@@ -65,10 +65,18 @@ __global__ __launch_bounds__(256) void wgrad_mfma_f32_kernel(const WgradArgs g) 
   float bsum = 0.f;
   const bool do_bias = g.bslab && cib == 0 && kh == 0 && wi == 0;
 
-  // staging item -> (pixel, channel quad): item = (px*4 + blk)*4 + q ; channel = blk*16 + q*4
-  for (int b = sp; b < g.B; b += g.nsplit) {
-    for (int ty = 0; ty < g.tiles_y; ++ty) {
-      for (int tx = 0; tx < g.tiles_x; ++tx) {
+  // work items = (image, patch), split evenly (+-1 patch) over the nsplit batch splits
+  const int tpi = g.tiles_x * g.tiles_y;
+  const long total_items = (long)g.B * tpi;
+  const long per = (total_items + g.nsplit - 1) / g.nsplit;
+  const long it0 = (long)sp * per;
+  const long it1 = it0 + per < total_items ? it0 + per : total_items;
+  for (long item = it0; item < it1; ++item) {
+    {
+      {
+        const int b = (int)(item / tpi);
+        const int trem = (int)(item - (long)b * tpi);
+        const int ty = trem / g.tiles_x, tx = trem - ty * g.tiles_x;
         const int y0 = ty * 8, x0 = tx * 8;
         f32x4 dv[NITD], av[NITA];
 #pragma unroll
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_f32_kernel(const WgradArgs g) 
         __syncthreads();
         const float* ap = dzt + h * DS + wc * 32 + li;
         const float* bp = at + h * DS + wi * 32 + li;
-#pragma unroll
+#pragma unroll 2
         for (int y = 0; y < 8; ++y) {
 #pragma unroll
           for (int xp = 0; xp < 4; ++xp) {

@@ -231,14 +231,16 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ backward pieces
     @staticmethod
-    def _nsplit(B, ks, cout, cin):
+    def _nsplit(B, tiles, ks, cout, cin):
+        """Batch splits of the wgrad launch: slices*nsplit ~ 2 x (3 workgroups x 256 CUs) resident slots;
+        work items are (image, 8x8 patch) pairs, so splits may outnumber images."""
         slices = ks * (cout // 64) * (cin // 64)
-        return max(1, min(B, 1024 // slices))
+        return max(1, min(B * tiles, 1536 // slices))
 
     def _wgrad(self, c, a: Act, dz: Act, conv, grads, name, with_bias):
         w = conv.weight
         cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
-        ns = self._nsplit(c.B, ks, cout, cin)
+        ns = self._nsplit(c.B, ((c.H + 7) // 8) * ((c.W + 7) // 8), ks, cout, cin)
         n = cout * cin * ks * ks
         slab = torch.empty(ns * n, dtype=torch.float32, device=w.device)
         bslab = torch.empty(ns * cout, dtype=torch.float32, device=w.device) if with_bias else None
