@@ -54,6 +54,21 @@ int tsr_conv2d_fwd(const float* in, int in_ctot, int in_coff, int cin,
                    float* out, int out_ctot, int out_coff, int relu,
                    int B, int H, int W, void* stream);
 
+/* Split-bf16 variant of tsr_conv2d_fwd on the bf16 matrix cores (16x the fp32-MFMA rate on gfx950):
+ * fp32 operands are split into nsplit bf16 planes and the significant cross products are accumulated in
+ * fp32.  nsplit = 3 ("bf16x6": 6 products, 24 significand bits -> fp32-equivalent results, error <= the fp32
+ * MFMA path's); nsplit = 2 ("bf16x3": 3 products, ~4e-6 per layer); nsplit = 1 (plain bf16 operands).
+ * Same arguments and semantics as tsr_conv2d_fwd; weights come from tsr_pack_conv_weight_bf16s
+ * (nsplit*Cout*Cin*k*k bf16 values). */
+int tsr_pack_conv_weight_bf16s(const float* w_oihw, void* w_packed, int cout, int cin, int ks, int nsplit,
+                               void* stream);
+int tsr_conv2d_fwd_bf16s(const float* in, int in_ctot, int in_coff, int cin,
+                         const void* w_packed, int cout, int ks, int nsplit,
+                         const float* scale, const float* shift,
+                         const float* res, int res_ctot, int res_coff,
+                         float* out, int out_ctot, int out_coff, int relu,
+                         int B, int H, int W, void* stream);
+
 /* nn.Upsample(scale_factor=sf, bilinear, align_corners=False) + Conv2d(3->64, 3x3, pad 1, no bias)
  * + scale/shift + optional ReLU: the pattern stem's first conv (model/tactileSR_model.py:34-39)
  * and the force stem (:59-63).  lr is the NCHW taxel tensor (B, lr_ctot, hin, win); channels

@@ -22,6 +22,8 @@ SIGNATURES = {
     "tsr_abi_version": [],
     "tsr_pack_conv_weight": [_P, _P, _I, _I, _I, _P],
     "tsr_conv2d_fwd": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "tsr_pack_conv_weight_bf16s": [_P, _P, _I, _I, _I, _I, _P],
+    "tsr_conv2d_fwd_bf16s": [_P, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "tsr_stem_fwd": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "tsr_head_fwd": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _P],
     "tsr_conv2d_ex": [_P, _P],

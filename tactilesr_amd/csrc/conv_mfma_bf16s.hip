@@ -1,0 +1,332 @@
+// Split-bf16 implicit-GEMM convolution on the CDNA4 bf16 matrix cores (v_mfma_f32_32x32x16_bf16),
+// a drop-in alternative to conv_mfma_f32_kernel for the inference epilogue.
+//
+// gfx950 runs bf16 MFMA at 16x the fp32-MFMA rate, so fp32 operands are split on the fly into NS
+// bf16 planes  x = x1 + x2 + x3  (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 24
+// significand bits for NS = 3, exact for every fp32 value whose low planes stay normal) and each K = 16
+// step issues the bf16 products that matter, all accumulated in fp32 inside the MFMA:
+//   NS = 3 ("bf16x6"): x1w1 + x1w2 + x2w1 + x1w3 + x3w1 + x2w2  -> error <= the fp32 MFMA path's
+//                      (measured 1.4e-7 vs 2.9e-7 at K = 3200), at 16/6 = 2.67x its MFMA rate;
+//   NS = 2 ("bf16x3"): x1w1 + x1w2 + x2w1                         -> ~4e-6 per layer (16 significand bits);
+//   NS = 1 ("bf16"):   x1w1                                       -> plain bf16 inputs, fp32 accumulate.
+// bf16 has fp32's exponent range, so no scaling is needed.  Activations stay fp32 CB16 in HBM (the
+// path is MFMA-bound, not HBM-bound); the split happens while the halo slab is staged into LDS,
+// weights are split once by tsr_pack_conv_weight_bf16s.
+//
+// Tiling is the fp32 kernel's: 8x8 patch x 2 images (M = 128) x all C_out per 256-thread workgroup,
+// waves 2 (image) x 2 (C_out half), per C_in block of 16 (= one MFMA K step) the halo slab sits in
+// LDS as [pixel][plane][16 bf16] with a 112/64/48-B pixel stride and a row stride chosen so that the
+// ds_read_b128 A fragments of all 64 lanes are bank-conflict free; per (block, tap) the
+// [plane][2][C_out][8] weight slab goes through a 2-deep LDS ring.
+#include "tsr_common.h"
+#include "conv_args.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int NS> struct SplitGeom;
+template <> struct SplitGeom<1> { static constexpr int PIXS = 3, RMOD = 8; };
+template <> struct SplitGeom<2> { static constexpr int PIXS = 4, RMOD = 1; };
+template <> struct SplitGeom<3> { static constexpr int PIXS = 7, RMOD = 8; };
+
+constexpr int row_slots(int hh, int pixs, int rmod) {
+  int rs = hh * pixs;
+  while ((rs & 15) != rmod) ++rs;
+  return rs;
+}
+
+template <int KS, int COUT, int NS>
+__global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs a) {
+  constexpr int IMG = 2;
+  constexpr int P = KS / 2;
+  constexpr int HH = 8 + KS - 1;
+  constexpr int T = KS * KS;
+  constexpr int NB = COUT / 64;
+  constexpr int PIXB = SplitGeom<NS>::PIXS * 16;                               // bytes per halo pixel
+  constexpr int ROWB = row_slots(HH, SplitGeom<NS>::PIXS, SplitGeom<NS>::RMOD) * 16;
+  constexpr int IMGB = HH * ROWB;
+  constexpr int HALO_B = IMG * IMGB;
+  constexpr int WSLAB_B = NS * 16 * COUT * 2;                                  // bytes per (block, tap)
+  constexpr int WITEMS = WSLAB_B / 16;
+  constexpr int WV = (WITEMS + 255) / 256;
+  constexpr int NITEM = IMG * HH * HH * 4;
+  constexpr int NIT = (NITEM + 255) / 256;
+  constexpr int NPROD = NS == 3 ? 6 : (NS == 2 ? 3 : 1);
+  // products ordered small -> large so the fp32 accumulator sees the low-order terms first
+  constexpr int PA[6] = {NS == 3 ? 2 : (NS == 2 ? 1 : 0), NS == 3 ? 0 : 0, NS == 3 ? 1 : 0, 1, 0, 0};
+  constexpr int PB[6] = {0, NS == 3 ? 2 : (NS == 2 ? 1 : 0), NS == 3 ? 1 : 0, 0, 1, 0};
+
+  __shared__ __attribute__((aligned(16))) char lds[HALO_B + 3 * WSLAB_B];
+  char* halo = lds;
+  char* wbuf = lds + HALO_B;        // 3-slot ring: slab s lives in slot s % 3
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int h = lane >> 5, li = lane & 31;
+
+  int bid;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tpi = a.tiles_x * a.tiles_y;
+  const int ig = bid / tpi;
+  const int trem = bid - ig * tpi;
+  const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+  const int y0 = ty * 8, x0 = tx * 8, b0 = ig * IMG;
+  const int HW = a.H * a.W;
+  const int in_blocks = a.in_ctot >> 4;
+
+  int st_src[NIT], st_dst[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int it = tid + k * 256;
+    st_src[k] = -1;
+    st_dst[k] = -1;
+    if (it < NITEM) {
+      const int qd = it & 3, px = it >> 2;
+      const int img = px / (HH * HH), rem = px - img * (HH * HH);
+      const int hy = rem / HH, hx = rem - hy * HH;
+      const int gy = y0 - P + hy, gx = x0 - P + hx, b = b0 + img;
+      st_dst[k] = img * IMGB + hy * ROWB + hx * PIXB + qd * 8;
+      if (b < a.B && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+        st_src[k] = ((img * in_blocks) * HW + gy * a.W + gx) * 16 + qd * 4;
+    }
+  }
+  const float* in_base = a.in + ((size_t)b0 * in_blocks + (a.in_coff >> 4)) * HW * 16;
+
+  const int laneA = wm * IMGB + (li >> 3) * ROWB + (li & 7) * PIXB + h * 16;
+  const int laneB = (h * COUT + wn * (COUT / 2) + li) * 16;
+
+  f32x16 acc[2][NB];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+  const int nchunk = a.cin >> 4;
+  const int S = nchunk * T;
+  const char* wsrc = (const char*)a.wp;
+
+  // ---- helpers (all loops fully unrolled: fragment registers are plain SSA values)
+  auto load_halo = [&](int c, f32x4* hv) {
+    const float* inc = in_base + (size_t)c * HW * 16;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      hv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (st_src[k] >= 0) hv[k] = *(const f32x4*)(inc + st_src[k]);
+    }
+  };
+  auto store_halo = [&](const f32x4* hv) {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      if (st_dst[k] >= 0) {
+        f32x4 v = hv[k];
+#pragma unroll
+        for (int p = 0; p < NS; ++p) {
+          bf16x4 bq;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            bq[j] = (__bf16)v[j];
+            v[j] -= (float)bq[j];
+          }
+          *(bf16x4*)(halo + st_dst[k] + p * 32) = bq;
+        }
+      }
+    }
+  };
+  // W ring helpers; the (v+1)*256 <= WITEMS test folds the bounds check away for full passes
+#define LOAD_W(sidx)                                                                     \
+  {                                                                                      \
+    const f32x4* src_ = (const f32x4*)(wsrc + (size_t)(sidx) * WSLAB_B);                  \
+    _Pragma("unroll") for (int v = 0; v < WV; ++v)                                       \
+      if ((v + 1) * 256 <= WITEMS || tid + v * 256 < WITEMS) wreg[v] = src_[tid + v * 256]; \
+  }
+#define STORE_W(slot)                                                                    \
+  {                                                                                      \
+    char* wb_ = wbuf + (slot) * WSLAB_B;                                                 \
+    _Pragma("unroll") for (int v = 0; v < WV; ++v)                                       \
+      if ((v + 1) * 256 <= WITEMS || tid + v * 256 < WITEMS) ((f32x4*)wb_)[tid + v * 256] = wreg[v]; \
+  }
+  // fragments of one (block, tap) step -> register set `set` (compile-time index after unrolling)
+#define LOAD_FRAGS(set, slot, kh_, kw_)                                                  \
+  {                                                                                      \
+    const char* wb_ = wbuf + (slot) * WSLAB_B;                                           \
+    _Pragma("unroll") for (int p = 0; p < NS; ++p) {                                     \
+      _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                   \
+        fa[set][p][mb] = *(const bf16x8*)(halo + laneA + (4 * mb + (kh_)) * ROWB + (kw_) * PIXB + p * 32); \
+      _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                  \
+        fb[set][p][nb] = *(const bf16x8*)(wb_ + laneB + p * (2 * COUT * 16) + nb * (32 * 16)); \
+    }                                                                                    \
+  }
+
+  // ---- prologue: halo(0), W(0), W(1) in LDS; W(2) in flight
+  f32x4 hv[NIT], wreg[WV];
+  load_halo(0, hv);
+  LOAD_W(0);
+  STORE_W(0);
+  if (S > 1) { LOAD_W(1); STORE_W(1); }
+  store_halo(hv);
+  if (S > 2) LOAD_W(2);
+  __syncthreads();
+
+  bf16x8 fa[2][NS][2], fb[2][NS][NB];     // ping-pong fragment sets, statically indexed
+  LOAD_FRAGS(0, 0, 0, 0);
+
+  int s = 0;
+  int slot = 0;                            // s % 3, kept incrementally
+  for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int kh = t / KS, kw = t - kh * KS;
+      const int cur = t & 1, nxt = cur ^ 1;
+      const int slot1 = slot == 2 ? 0 : slot + 1;
+      const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
+      if (t + 1 < T) {          // next tap's fragments: W(s+1) was published by the previous barrier
+        const int nkh = (t + 1) / KS, nkw = (t + 1) - nkh * KS;
+        LOAD_FRAGS(nxt, slot1, nkh, nkw);
+      } else if (c + 1 < nchunk) {
+        load_halo(c + 1, hv);   // next block's slab: global loads fly under this step's MFMAs
+      }
+#pragma unroll
+      for (int q = 0; q < NPROD; ++q)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][PA[6 - NPROD + q]][mb],
+                                                                  fb[cur][PB[6 - NPROD + q]][nb], acc[mb][nb], 0, 0, 0);
+      if (s + 2 < S) STORE_W(slot2);           // slot (s+2)%3 was last read one barrier ago
+      if (s + 3 < S) LOAD_W(s + 3);
+      __syncthreads();
+      if (t + 1 == T && c + 1 < nchunk) {
+        store_halo(hv);         // every wave is past its last read of the old slab (barrier above)
+        __syncthreads();
+        LOAD_FRAGS(0, slot1, 0, 0);            // T odd or even: a block always starts on set 0
+      }
+      ++s;
+      slot = slot1;
+    }
+  }
+#undef LOAD_W
+#undef STORE_W
+#undef LOAD_FRAGS
+
+  // ---- epilogue (inference form): y = acc*scale + shift (+ residual) (ReLU) -> channel slice of out
+  const int b = b0 + wm;
+  if (b >= a.B) return;
+  const int out_blocks = a.out_ctot >> 4;
+  const int res_blocks = a.res_ctot >> 4;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = wn * (COUT / 2) + nb * 32 + li;
+    const float sc = a.scale ? a.scale[n] : 1.f;
+    const float sh = a.shift ? a.shift[n] : 0.f;
+    const int oc = a.out_coff + n;
+    float* obase = a.out + (((size_t)b * out_blocks + (oc >> 4)) * HW) * 16 + (oc & 15);
+    const float* rbase = nullptr;
+    if (a.res) {
+      const int rc = a.res_coff + n;
+      rbase = a.res + (((size_t)b * res_blocks + (rc >> 4)) * HW) * 16 + (rc & 15);
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int gy = y0 + 4 * mb + (m >> 3), gx = x0 + (m & 7);
+        if (gy < a.H && gx < a.W) {
+          const size_t po = (size_t)(gy * a.W + gx) * 16;
+          float v = acc[mb][nb][r] * sc + sh;
+          if (rbase) v += rbase[po];
+          if (a.relu) v = fmaxf(v, 0.f);
+          obase[po] = v;
+        }
+      }
+    }
+  }
+}
+
+// OIHW fp32 -> [C_in/16][tap][plane][2 (k half)][C_out][8] bf16 split planes.
+__global__ void pack_conv_weight_bf16s_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int cout,
+                                              int cin, int ks, int ns) {
+  const int T = ks * ks;
+  const size_t total = (size_t)cout * cin * T;      // one thread per fp32 weight -> ns outputs
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i & 7;
+    size_t r = i >> 3;
+    const int n = r % cout; r /= cout;
+    const int kh = r & 1; r >>= 1;
+    const int tap = r % T;
+    const int chunk = r / T;
+    const int ci = chunk * 16 + kh * 8 + j;
+    float v = w[((size_t)n * cin + ci) * T + tap];
+    for (int p = 0; p < ns; ++p) {
+      const __bf16 bq = (__bf16)v;
+      v -= (float)bq;
+      wp[((((size_t)(chunk * T + tap) * ns + p) * 2 + kh) * cout + n) * 8 + j] = bq;
+    }
+  }
+}
+
+extern "C" int tsr_pack_conv_weight_bf16s(const float* w_oihw, void* w_packed, int cout, int cin, int ks,
+                                          int nsplit, void* stream) {
+  if (!w_oihw || !w_packed || (cin & 15) || (cout != 64 && cout != 128) || (ks != 1 && ks != 3 && ks != 5) ||
+      nsplit < 1 || nsplit > 3)
+    return TSR_ERR_ARG;
+  const size_t total = (size_t)cout * cin * ks * ks;
+  const int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
+                     (hipStream_t)stream, w_oihw, (__bf16*)w_packed, cout, cin, ks, nsplit);
+  return tsr_check_launch();
+}
+
+template <int KS, int COUT, int NS>
+static int launch_bf16s(const ConvArgs& a, hipStream_t st) {
+  const int grid = ((a.B + 1) / 2) * a.tiles_x * a.tiles_y;
+  hipLaunchKernelGGL((conv_mfma_bf16s_kernel<KS, COUT, NS>), dim3(grid), dim3(256), 0, st, a);
+  return tsr_check_launch();
+}
+
+template <int NS>
+static int dispatch_bf16s(const ConvArgs& a, int cout, int ks, hipStream_t st) {
+  if (cout == 64) {
+    if (ks == 1) return launch_bf16s<1, 64, NS>(a, st);
+    if (ks == 3) return launch_bf16s<3, 64, NS>(a, st);
+    if (ks == 5) return launch_bf16s<5, 64, NS>(a, st);
+  } else if (cout == 128) {
+    if (ks == 1) return launch_bf16s<1, 128, NS>(a, st);
+    if (ks == 3) return launch_bf16s<3, 128, NS>(a, st);
+    if (ks == 5) return launch_bf16s<5, 128, NS>(a, st);
+  }
+  return TSR_ERR_ARG;
+}
+
+extern "C" int tsr_conv2d_fwd_bf16s(const float* in, int in_ctot, int in_coff, int cin,
+                                    const void* w_packed, int cout, int ks, int nsplit,
+                                    const float* scale, const float* shift,
+                                    const float* res, int res_ctot, int res_coff,
+                                    float* out, int out_ctot, int out_coff, int relu,
+                                    int B, int H, int W, void* stream) {
+  if (!in || !w_packed || !out || B <= 0 || H <= 0 || W <= 0 || nsplit < 1 || nsplit > 3) return TSR_ERR_ARG;
+  if ((cin & 15) || (in_ctot & 15) || (in_coff & 15) || (out_ctot & 15) || (out_coff & 15) || cin <= 0 ||
+      in_coff + cin > in_ctot || out_coff + cout > out_ctot)
+    return TSR_ERR_ARG;
+  if (res && ((res_ctot & 15) || (res_coff & 15) || res_coff + cout > res_ctot)) return TSR_ERR_ARG;
+  ConvArgs a = {};
+  a.in = in; a.in_ctot = in_ctot; a.in_coff = in_coff; a.cin = cin;
+  a.wp = (const float*)w_packed; a.scale = scale; a.shift = shift;
+  a.res = res; a.res_ctot = res_ctot; a.res_coff = res_coff;
+  a.out = out; a.out_ctot = out_ctot; a.out_coff = out_coff; a.relu = relu;
+  a.B = B; a.H = H; a.W = W;
+  a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8;
+  hipStream_t st = (hipStream_t)stream;
+  if (nsplit == 3) return dispatch_bf16s<3>(a, cout, ks, st);
+  if (nsplit == 2) return dispatch_bf16s<2>(a, cout, ks, st);
+  return dispatch_bf16s<1>(a, cout, ks, st);
+}

@@ -20,31 +20,7 @@
 #include "tactilesr_hip.h"
 #include <stdlib.h>
 
-struct ConvArgs {
-  const float* in;  int in_ctot;  int in_coff;  int cin;
-  const float* wp;
-  const float* scale; const float* shift;
-  const float* res; int res_ctot; int res_coff;
-  float* out; int out_ctot; int out_coff;
-  int relu;
-  int B, H, W;
-  int tiles_x, tiles_y;
-  // ---- training-path extensions (all optional; NULL/0 = inference behaviour) ----
-  // input transform applied while staging in-bounds halo pixels: x' = relu(x*in_scale[c]+in_shift[c])
-  // (the producer stored the raw, bias-free conv output; its train-mode BN+ReLU is applied here)
-  const float* in_scale; const float* in_shift;
-  // same transform on the residual operand
-  const float* res_scale; const float* res_shift;
-  // epi_mode 1: store the raw accumulator and emit per-(workgroup, image) Welford partials
-  //             (mean, M2) per channel to slab[(wg*2+wm)*COUT*2 ...], counts to slab_cnt
-  // epi_mode 2: v = (acc + res) * [mask*mask_scale+mask_shift > 0]  (ReLU backward by the stored
-  //             activation); if bn_a: also emit sum(v), sum(v*xhat), xhat = mask*bn_a+bn_b
-  int epi_mode;
-  const float* mask; int mask_ctot; int mask_coff;
-  const float* mask_scale; const float* mask_shift;
-  const float* bn_a; const float* bn_b;
-  float* slab; float* slab_cnt;
-};
+#include "conv_args.h"
 
 // EXT = training-path extensions compiled in (input/residual transforms, epi_mode 1/2);
 // PF  = prefetch the next channel block's halo slab into registers during the current block.

@@ -68,15 +68,24 @@ class ResBlock(nn.Module):
         raise _lib.TactileSRHipError("ResBlock is executed by TactileSR's fused HIP engine, not standalone")
 
 
+CONV_IMPLS = {"f32": 0, "bf16x6": 3, "bf16x3": 2, "bf16": 1}   # name -> bf16 split planes (0 = fp32 MFMA)
+
+
 class _PackedConv:
     """Device-side constants of one conv launch: packed weight, folded scale/shift."""
-    __slots__ = ("w", "scale", "shift", "cin", "cout", "ks")
+    __slots__ = ("w", "scale", "shift", "cin", "cout", "ks", "nsplit")
 
-    def __init__(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d]):
+    def __init__(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], nsplit: int = 0):
         w = conv.weight.detach().float().contiguous()
         self.cout, self.cin, self.ks = w.shape[0], w.shape[1], w.shape[2]
-        self.w = torch.empty_like(w)
-        call("tsr_pack_conv_weight", ptr(w), ptr(self.w), _I(self.cout), _I(self.cin), _I(self.ks), stream())
+        self.nsplit = nsplit
+        if nsplit == 0:
+            self.w = torch.empty_like(w)
+            call("tsr_pack_conv_weight", ptr(w), ptr(self.w), _I(self.cout), _I(self.cin), _I(self.ks), stream())
+        else:
+            self.w = torch.empty(nsplit * w.numel(), dtype=torch.bfloat16, device=w.device)
+            call("tsr_pack_conv_weight_bf16s", ptr(w), ptr(self.w), _I(self.cout), _I(self.cin), _I(self.ks),
+                 _I(nsplit), stream())
         self.scale, self.shift = _fold(conv.bias, bn, self.cout, w.device)
 
 
@@ -131,6 +140,11 @@ class TactileSR(nn.Module):
         self._plan_key = None
         self._profile = None
         self._train_engine = None
+        # eval-mode conv arithmetic: "f32" = fp32 MFMA (exact fp32 fma chain); "bf16x6" = 3-way bf16 split, six
+        # bf16 MFMA products per K step (fp32-equivalent, faster); "bf16x3" / "bf16" = reduced precision
+        import os
+        self.conv_impl = os.environ.get("TSR_CONV_IMPL", "f32")
+        assert self.conv_impl in CONV_IMPLS, self.conv_impl
         self.max_images_per_pass = 4096   # workspace bound: ~6.6 MB of CB16 activations per image
 
     def make_layer(self, block, num_of_layer):
@@ -141,26 +155,28 @@ class TactileSR(nn.Module):
 
     # ------------------------------------------------------------------ engine
     def _param_key(self):
-        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        return (self.conv_impl,) + tuple((t.data_ptr(), t._version)
+                                         for t in list(self.parameters()) + list(self.buffers()))
 
     def _build_plan(self):
         """Pack weights / fold eval-mode BN once per parameter version."""
         plan: Dict[str, object] = {}
+        ns = CONV_IMPLS[self.conv_impl]
         stems = []
         for seq in self.inputLayer_pattern_list:
             s1, sh1 = _fold(None, seq[2], 64, seq[1].weight.device)
-            stems.append((seq[1].weight.detach().float().contiguous(), s1, sh1, _PackedConv(seq[4], seq[5])))
+            stems.append((seq[1].weight.detach().float().contiguous(), s1, sh1, _PackedConv(seq[4], seq[5], ns)))
         plan["stems"] = stems
-        plan["fuse"] = _PackedConv(self.inputContact_layer[0], self.inputContact_layer[1])
+        plan["fuse"] = _PackedConv(self.inputContact_layer[0], self.inputContact_layer[1], ns)
         msrbs = []
         for blk in self.patternFeatureExtra_layer:
-            msrbs.append((_PackedConv(blk.conv_3_1[0], blk.conv_3_1[1]), _PackedConv(blk.conv_5_1[0], blk.conv_5_1[1]),
-                          _PackedConv(blk.conv_3_2[0], blk.conv_3_2[1]), _PackedConv(blk.conv_5_2[0], blk.conv_5_2[1]),
-                          _PackedConv(blk.confusion, None)))
+            msrbs.append((_PackedConv(blk.conv_3_1[0], blk.conv_3_1[1], ns), _PackedConv(blk.conv_5_1[0], blk.conv_5_1[1], ns),
+                          _PackedConv(blk.conv_3_2[0], blk.conv_3_2[1], ns), _PackedConv(blk.conv_5_2[0], blk.conv_5_2[1], ns),
+                          _PackedConv(blk.confusion, None, ns)))
         plan["msrb"] = msrbs
         plan["force_w"] = self.input_layer_force[1].weight.detach().float().contiguous()
-        plan["res"] = [(_PackedConv(b.conv1, None), _PackedConv(b.conv2, None)) for b in self.forceFeatureExtra_layer]
-        plan["head0"] = _PackedConv(self.output_layer[0], None)
+        plan["res"] = [(_PackedConv(b.conv1, None, ns), _PackedConv(b.conv2, None, ns)) for b in self.forceFeatureExtra_layer]
+        plan["head0"] = _PackedConv(self.output_layer[0], None, ns)
         plan["head_w"] = self.output_layer[2].weight.detach().float().contiguous()
         return plan
 
@@ -177,9 +193,14 @@ class TactileSR(nn.Module):
         if prof is not None:     # bench.py: HIP-event bracket on the launch stream, per kernel instantiation
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        call("tsr_conv2d_fwd", ptr(src), _I(s_ctot), _I(s_coff), _I(pc.cin), ptr(pc.w), _I(pc.cout), _I(pc.ks),
-             ptr(pc.scale), ptr(pc.shift), ptr(res), _I(r_ctot), _I(r_coff),
-             ptr(dst), _I(d_ctot), _I(d_coff), _I(1 if relu else 0), _I(B), _I(H), _I(W), stream())
+        if pc.nsplit == 0:
+            call("tsr_conv2d_fwd", ptr(src), _I(s_ctot), _I(s_coff), _I(pc.cin), ptr(pc.w), _I(pc.cout), _I(pc.ks),
+                 ptr(pc.scale), ptr(pc.shift), ptr(res), _I(r_ctot), _I(r_coff),
+                 ptr(dst), _I(d_ctot), _I(d_coff), _I(1 if relu else 0), _I(B), _I(H), _I(W), stream())
+        else:
+            call("tsr_conv2d_fwd_bf16s", ptr(src), _I(s_ctot), _I(s_coff), _I(pc.cin), ptr(pc.w), _I(pc.cout),
+                 _I(pc.ks), _I(pc.nsplit), ptr(pc.scale), ptr(pc.shift), ptr(res), _I(r_ctot), _I(r_coff),
+                 ptr(dst), _I(d_ctot), _I(d_coff), _I(1 if relu else 0), _I(B), _I(H), _I(W), stream())
         if prof is not None:
             e1.record()
             prof.setdefault((pc.ks, pc.cout), []).append((e0, e1))

@@ -192,3 +192,60 @@ def test_model_chunked_batch_and_linearity_property(T):
     perm = torch.randperm(67, device="cuda")
     y3 = m(LR[perm])
     assert relerr(y3, y[perm]) < 1e-6
+
+
+BF16S_CASES = [(3, 64, 64, 3, 40, 40), (5, 128, 128, 1, 40, 40), (1, 256, 64, 2, 40, 40), (3, 128, 128, 2, 13, 21),
+               (5, 64, 64, 5, 9, 40), (3, 448, 64, 1, 40, 40)]
+
+
+@pytest.mark.parametrize("nsplit,tol", [(3, 1e-5), (2, 1e-4), (1, 2e-2)])
+@pytest.mark.parametrize("ks,cin,cout,B,H,W", BF16S_CASES)
+def test_conv2d_fwd_bf16_split(T, ks, cin, cout, B, H, W, nsplit, tol):
+    """Split-bf16 MFMA conv: nsplit=3 (six products) must meet the fp32 bar; 2 / 1 are the documented
+    reduced-precision modes (tolerance vs the fp32 reference stated here)."""
+    from tactilesr_amd._lib import call, ptr, stream, c_int as I
+    g = torch.Generator().manual_seed(ks * 100 + cin + B)
+    x = torch.randn(B, cin, H, W, generator=g) * 3
+    x[0, 0, 0, 0] = 1e4          # wide dynamic range inside one tile
+    x[0, 1, 1, 1] = 1e-6
+    w = torch.randn(cout, cin, ks, ks, generator=g) * (2.0 / (cout * ks * ks)) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    res = torch.randn(B, cout, H, W, generator=g)
+    ref64 = F.relu(F.conv2d(x.double(), w.double(), padding=ks // 2) * scale.double().view(1, -1, 1, 1)
+                   + shift.double().view(1, -1, 1, 1) + res.double())
+    xin, rbuf = T.to_cb16(x.cuda()), T.to_cb16(res.cuda())
+    wd = w.cuda().contiguous()
+    wp = torch.empty(nsplit * w.numel(), dtype=torch.bfloat16, device="cuda")
+    call("tsr_pack_conv_weight_bf16s", ptr(wd), ptr(wp), I(cout), I(cin), I(ks), I(nsplit), stream())
+    out = torch.empty(B * cout * H * W, device="cuda")
+    sc, sh = scale.cuda(), shift.cuda()
+    call("tsr_conv2d_fwd_bf16s", ptr(xin), I(cin), I(0), I(cin), ptr(wp), I(cout), I(ks), I(nsplit), ptr(sc), ptr(sh),
+         ptr(rbuf), I(cout), I(0), ptr(out), I(cout), I(0), I(1), I(B), I(H), I(W), stream())
+    got = T.from_cb16(out, B, cout, H, W)
+    err = relerr(got, ref64)
+    if nsplit == 3:
+        ref32 = F.relu(F.conv2d(x, w, padding=ks // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+        print(f"[bf16x6] k{ks} {cin}->{cout}: err vs f64 {err:.2e}  (torch fp32 CPU vs f64 {relerr(ref32, ref64):.2e})")
+    assert err < tol
+
+
+@pytest.mark.parametrize("tag", ["t1", "t7"])
+def test_model_eval_forward_bf16x6_vs_reference_golden(T, golden, tag):
+    """Whole eval forward with the split-bf16 (six-product) convolutions: same 1e-5 bar as the fp32 MFMA path."""
+    g = golden("eval")
+    cfg = GOLD_CFG[tag]
+    sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), int(g[f"{tag}/seed"]))
+    m = T.TactileSR(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    m.conv_impl = "bf16x6"
+    LR = torch.from_numpy(g[f"{tag}/LR"]).cuda()
+    y = m(LR)
+    yard = float(g[f"{tag}/ref32_vs_f64"])
+    e32 = relerr(y, torch.from_numpy(g[f"{tag}/out"]))
+    e64 = relerr(y, torch.from_numpy(g[f"{tag}/out64"]))
+    print(f"[parity bf16x6] {tag}: vs-ref32 {e32:.2e}  vs-f64 {e64:.2e}  ref32-vs-f64 {yard:.2e}")
+    assert e32 < max(TOL, 4 * yard) and e64 < max(TOL, 4 * yard)
+    m.conv_impl = "f32"
+    y32 = m(LR)                      # two fp32-grade evaluations: within the sum of their errors to fp64
+    assert relerr(y, y32) < 2 * max(TOL, 4 * yard)
