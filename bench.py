@@ -29,6 +29,7 @@ sys.path.insert(0, REPO)
 FWD_FLOP_PER_SAMPLE = 14_642_380_800          # SURVEY.md section 8(d), sf=10, T=1, direct conv
 C5_FLOP_PER_SAMPLE = 2 * 1600 * 128 * 128 * 25  # one 5x5 128->128 conv launch, per sample
 PEAK_F32_MFMA = 157.3e12                      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_BF16_MFMA = 2500e12                      # MI355X_MICROARCH.md: dense bf16 MFMA peak
 LAYER_BYTES_PER_SAMPLE = 48.38e6              # SURVEY.md section 8(d), layer-wise fp32 bytes
 
 
@@ -55,6 +56,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--impl", choices=["bf16x6", "f32", "bf16x3", "bf16"], default="bf16x6",
+                    help="conv arithmetic of the timed path: bf16x6 = fp32 operands split into 3 bf16 planes, "
+                         "6 bf16-MFMA products, fp32 accumulate (fp32-equivalent, default); f32 = fp32 MFMA; "
+                         "bf16x3 / bf16 = reduced precision (not the headline)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = BASELINE configs[1] (headline); train = data-parallel train step "
                          "(train_cal_loss + backward + RCCL grad all-reduce + Adam), configs[3] shape")
@@ -77,6 +82,7 @@ def main():
     import tactilesr_amd
     torch.manual_seed(42)
     model = tactilesr_amd.TactileSR().to(dev).eval()
+    model.conv_impl = args.impl
     B = args.batch
     model.max_images_per_pass = B
     g = torch.Generator().manual_seed(42 + rank)
@@ -103,33 +109,66 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # secondary measurement: the strict fp32-MFMA path (v_mfma_f32_32x32x2_f32), 2 steps, same inputs
+    f32_ref = None
+    if args.impl != "f32":
+        model.conv_impl = "f32"
+        model(LR)
+        barrier()
+        model._profile = {}
+        t1 = time.perf_counter()
+        for _ in range(2):
+            model(LR)
+        barrier()
+        dt32 = (time.perf_counter() - t1) / 2
+        ev32 = model._profile.get((5, 128), [])
+        model._profile = None
+        model.conv_impl = args.impl
+        c5 = sum(a.elapsed_time(b) for a, b in ev32) / max(1, len(ev32))
+        f32_ref = {"value": round(B / dt32, 2), "unit": "samples/s per GPU", "ms_per_step": round(dt32 * 1e3, 3),
+                   "kernel": "conv_mfma_f32_kernel<5,128>", "kernel_tflops": round(B * C5_FLOP_PER_SAMPLE / (c5 * 1e-3) / 1e12, 2),
+                   "kernel_frac_of_f32_mfma_peak": round(B * C5_FLOP_PER_SAMPLE / (c5 * 1e-3) / PEAK_F32_MFMA, 4)}
+
     if rank == 0:
         total = B * world * args.steps
         value = total / dt
         ev = prof.get((5, 128), [])
         c5_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
-        achieved = B * C5_FLOP_PER_SAMPLE / (c5_ms * 1e-3) / 1e12 if ev else None
+        nprod = {"bf16x6": 6, "bf16x3": 3, "bf16": 1, "f32": 1}[args.impl]
+        peak = PEAK_F32_MFMA if args.impl == "f32" else PEAK_BF16_MFMA
+        alg = B * C5_FLOP_PER_SAMPLE / (c5_ms * 1e-3) if ev else None       # algorithmic FLOP/s of the launch
+        achieved = alg * nprod / 1e12 if ev else None                        # MFMA FLOP/s actually executed
+        kname = ("conv_mfma_f32_kernel<5, 128" if args.impl == "f32" else
+                 "conv_mfma_bf16s_kernel<5, 128, %d" % {"bf16x6": 3, "bf16x3": 2, "bf16": 1}[args.impl])
         per_kernel = {f"conv{k[0]}x{k[0]}_c{k[1]}": round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 3)
                       for k, v in sorted(prof.items())}
-        traffic, traffic_src = pmc_traffic("conv_mfma_f32_kernel<5, 128>") if B == 4096 else (None, None)
+        traffic, traffic_src = pmc_traffic(kname) if B == 4096 else (None, None)
+        dtype = {"bf16x6": "f32 as 3 bf16 planes x 6 MFMA products, fp32 accumulate (fp32-equivalent)",
+                 "f32": "f32", "bf16x3": "bf16x3 (reduced: ~16 significand bits)", "bf16": "bf16"}[args.impl]
         res = {
             "metric": "SR samples/sec (4x4->40x40)", "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "tactileSR_model eval forward 4x4->40x40, batch=4096/GPU fp32 (BASELINE configs[1])",
-                       "batch_per_gpu": B, "scale_factor": 10, "seqsCnt": 1, "parallelism": f"replicas x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "conv_mfma_f32_kernel<5,128> (5x5 128->128 conv+BN+ReLU)",
-                         "achieved": round(achieved, 2) if achieved else None, "peak": PEAK_F32_MFMA / 1e12,
-                         "unit": "TFLOP/s", "frac": round(achieved * 1e12 / PEAK_F32_MFMA, 4) if achieved else None,
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": "tactileSR_model eval forward 4x4->40x40, batch=4096/GPU, fp32 in/out (BASELINE configs[1])",
+                       "batch_per_gpu": B, "scale_factor": 10, "seqsCnt": 1, "parallelism": f"replicas x{world}",
+                       "conv_impl": args.impl},
+            "roofline": {"bound": "mfma", "kernel": kname + "> (5x5 128->128 conv+BN+ReLU, 54% of all FLOPs)",
+                         "achieved": round(achieved, 2) if achieved else None, "peak": peak / 1e12,
+                         "unit": "TFLOP/s", "frac": round(achieved * 1e12 / peak, 4) if achieved else None,
+                         "mfma_products_per_mac": nprod,
+                         "algorithmic_tflops": round(alg / 1e12, 2) if alg else None,
+                         "algorithmic_vs_f32_mfma_peak": round(alg / PEAK_F32_MFMA, 4) if alg else None,
                          "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": B * (2 * 128 * 1600 * 4) + 128 * 128 * 25 * 4,
                          "avg_launch_ms": round(c5_ms, 3), "launches_timed": len(ev)},
-            "whole_step": {"tflops": round(value / world * FWD_FLOP_PER_SAMPLE / 1e12, 2),
-                           "frac_of_f32_mfma_peak": round(value / world * FWD_FLOP_PER_SAMPLE / PEAK_F32_MFMA, 4),
+            "whole_step": {"algorithmic_tflops": round(value / world * FWD_FLOP_PER_SAMPLE / 1e12, 2),
+                           "algorithmic_vs_f32_mfma_peak": round(value / world * FWD_FLOP_PER_SAMPLE / PEAK_F32_MFMA, 4),
                            "layerwise_GBps": round(value / world * LAYER_BYTES_PER_SAMPLE / 1e9, 1),
                            "ms_per_step_by_kernel": per_kernel},
         }
+        if f32_ref is not None:
+            res["f32_mfma_path"] = f32_ref
         if world == 1 and not args.no_cpu_baseline:
             res.update(cpu_baseline_and_psnr(model, dev))
         print(json.dumps(res), flush=True)

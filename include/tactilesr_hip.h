@@ -59,7 +59,8 @@ int tsr_conv2d_fwd(const float* in, int in_ctot, int in_coff, int cin,
  * fp32.  nsplit = 3 ("bf16x6": 6 products, 24 significand bits -> fp32-equivalent results, error <= the fp32
  * MFMA path's); nsplit = 2 ("bf16x3": 3 products, ~4e-6 per layer); nsplit = 1 (plain bf16 operands).
  * Same arguments and semantics as tsr_conv2d_fwd; weights come from tsr_pack_conv_weight_bf16s
- * (nsplit*Cout*Cin*k*k bf16 values). */
+ * (tsr_conv_weight_bf16s_elems() bf16 values: taps padded to the kernel's step size). */
+long long tsr_conv_weight_bf16s_elems(int cout, int cin, int ks, int nsplit);   /* bf16 elements of w_packed */
 int tsr_pack_conv_weight_bf16s(const float* w_oihw, void* w_packed, int cout, int cin, int ks, int nsplit,
                                void* stream);
 int tsr_conv2d_fwd_bf16s(const float* in, int in_ctot, int in_coff, int cin,

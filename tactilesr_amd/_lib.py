@@ -22,6 +22,7 @@ SIGNATURES = {
     "tsr_abi_version": [],
     "tsr_pack_conv_weight": [_P, _P, _I, _I, _I, _P],
     "tsr_conv2d_fwd": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "tsr_conv_weight_bf16s_elems": [_I, _I, _I, _I],
     "tsr_pack_conv_weight_bf16s": [_P, _P, _I, _I, _I, _I, _P],
     "tsr_conv2d_fwd_bf16s": [_P, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "tsr_stem_fwd": [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -69,7 +70,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)           # AttributeError if the symbol is missing
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_longlong if name.endswith("_elems") else c_int
     v = lib.tsr_abi_version()
     if v != ABI_VERSION:
         raise TactileSRHipError(f"libtactilesr_hip.so ABI {v} != expected {ABI_VERSION}: rebuild")

@@ -20,6 +20,7 @@
 // [plane][2][C_out][8] weight slab goes through a 2-deep LDS ring.
 #include "tsr_common.h"
 #include "conv_args.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -29,13 +30,20 @@ template <> struct SplitGeom<1> { static constexpr int PIXS = 3, RMOD = 8; };
 template <> struct SplitGeom<2> { static constexpr int PIXS = 4, RMOD = 1; };
 template <> struct SplitGeom<3> { static constexpr int PIXS = 7, RMOD = 8; };
 
+// taps per barrier step: enough MFMA work between two barriers (>= 24 MFMAs per wave where LDS allows)
+__host__ __device__ constexpr int taps_per_step(int ks, int cout, int ns) {
+  const int t = ks * ks;
+  const int want = ns == 3 ? 1 : (ns == 2 ? 2 : ks);   // measured: ns = 3 is fastest at 1 (occupancy), 2 and 1 gain from grouping
+  return want < t ? want : t;
+}
+
 constexpr int row_slots(int hh, int pixs, int rmod) {
   int rs = hh * pixs;
   while ((rs & 15) != rmod) ++rs;
   return rs;
 }
 
-template <int KS, int COUT, int NS>
+template <int KS, int COUT, int NS, bool SETPRIO>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs a) {
   constexpr int IMG = 2;
   constexpr int P = KS / 2;
@@ -46,7 +54,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
   constexpr int ROWB = row_slots(HH, SplitGeom<NS>::PIXS, SplitGeom<NS>::RMOD) * 16;
   constexpr int IMGB = HH * ROWB;
   constexpr int HALO_B = IMG * IMGB;
-  constexpr int WSLAB_B = NS * 16 * COUT * 2;                                  // bytes per (block, tap)
+  constexpr int TPS = taps_per_step(KS, COUT, NS);
+  constexpr int NSTEP = (T + TPS - 1) / TPS;                                   // barrier steps per channel block
+  constexpr int WTAP_B = NS * 16 * COUT * 2;                                   // bytes per (block, tap)
+  constexpr int WSLAB_B = TPS * WTAP_B;                                        // bytes per step
   constexpr int WITEMS = WSLAB_B / 16;
   constexpr int WV = (WITEMS + 255) / 256;
   constexpr int NITEM = IMG * HH * HH * 4;
@@ -110,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
   const int nchunk = a.cin >> 4;
-  const int S = nchunk * T;
+  const int S = nchunk * NSTEP;
   const char* wsrc = (const char*)a.wp;
 
   // ---- helpers (all loops fully unrolled: fragment registers are plain SSA values)
@@ -154,9 +165,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
       if ((v + 1) * 256 <= WITEMS || tid + v * 256 < WITEMS) ((f32x4*)wb_)[tid + v * 256] = wreg[v]; \
   }
   // fragments of one (block, tap) step -> register set `set` (compile-time index after unrolling)
-#define LOAD_FRAGS(set, slot, kh_, kw_)                                                  \
+#define LOAD_FRAGS(set, slot, tapoff, kh_, kw_)                                          \
   {                                                                                      \
-    const char* wb_ = wbuf + (slot) * WSLAB_B;                                           \
+    const char* wb_ = wbuf + (slot) * WSLAB_B + (tapoff) * WTAP_B;                       \
     _Pragma("unroll") for (int p = 0; p < NS; ++p) {                                     \
       _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                   \
         fa[set][p][mb] = *(const bf16x8*)(halo + laneA + (4 * mb + (kh_)) * ROWB + (kw_) * PIXB + p * 32); \
@@ -176,38 +187,46 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
   __syncthreads();
 
   bf16x8 fa[2][NS][2], fb[2][NS][NB];     // ping-pong fragment sets, statically indexed
-  LOAD_FRAGS(0, 0, 0, 0);
+  LOAD_FRAGS(0, 0, 0, 0, 0);
 
   int s = 0;
   int slot = 0;                            // s % 3, kept incrementally
   for (int c = 0; c < nchunk; ++c) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int kh = t / KS, kw = t - kh * KS;
-      const int cur = t & 1, nxt = cur ^ 1;
+    for (int st = 0; st < NSTEP; ++st) {
       const int slot1 = slot == 2 ? 0 : slot + 1;
       const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
-      if (t + 1 < T) {          // next tap's fragments: W(s+1) was published by the previous barrier
-        const int nkh = (t + 1) / KS, nkw = (t + 1) - nkh * KS;
-        LOAD_FRAGS(nxt, slot1, nkh, nkw);
-      } else if (c + 1 < nchunk) {
-        load_halo(c + 1, hv);   // next block's slab: global loads fly under this step's MFMAs
+#pragma unroll
+      for (int tt = 0; tt < TPS; ++tt) {
+        const int t = st * TPS + tt;
+        if (t < T) {
+          const int cur = t & 1, nxt = cur ^ 1;
+          if (t + 1 < T) {        // next tap's fragments: its weights were published by an earlier barrier
+            const int nkh = (t + 1) / KS, nkw = (t + 1) - nkh * KS;
+            if (tt + 1 < TPS) { LOAD_FRAGS(nxt, slot, tt + 1, nkh, nkw); }
+            else { LOAD_FRAGS(nxt, slot1, 0, nkh, nkw); }
+          } else if (c + 1 < nchunk) {
+            load_halo(c + 1, hv); // next block's slab: global loads fly under this tap's MFMAs
+          }
+          if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int q = 0; q < NPROD; ++q)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb)
+                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][PA[6 - NPROD + q]][mb],
+                                                                      fb[cur][PB[6 - NPROD + q]][nb], acc[mb][nb], 0, 0, 0);
+          if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+        }
       }
-#pragma unroll
-      for (int q = 0; q < NPROD; ++q)
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][PA[6 - NPROD + q]][mb],
-                                                                  fb[cur][PB[6 - NPROD + q]][nb], acc[mb][nb], 0, 0, 0);
       if (s + 2 < S) STORE_W(slot2);           // slot (s+2)%3 was last read one barrier ago
       if (s + 3 < S) LOAD_W(s + 3);
       __syncthreads();
-      if (t + 1 == T && c + 1 < nchunk) {
+      if (st + 1 == NSTEP && c + 1 < nchunk) {
         store_halo(hv);         // every wave is past its last read of the old slab (barrier above)
         __syncthreads();
-        LOAD_FRAGS(0, slot1, 0, 0);            // T odd or even: a block always starts on set 0
+        LOAD_FRAGS(0, slot1, 0, 0, 0);         // T is odd: a block always starts on fragment set 0
       }
       ++s;
       slot = slot1;
@@ -252,26 +271,36 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
   }
 }
 
-// OIHW fp32 -> [C_in/16][tap][plane][2 (k half)][C_out][8] bf16 split planes.
+// OIHW fp32 -> [C_in/16][step][tap in step][plane][2 (k half)][C_out][8] bf16 split planes; taps are
+// grouped TPS per barrier step (taps_per_step), the tail of the last step is zero.
 __global__ void pack_conv_weight_bf16s_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int cout,
-                                              int cin, int ks, int ns) {
+                                              int cin, int ks, int ns, int tps) {
   const int T = ks * ks;
-  const size_t total = (size_t)cout * cin * T;      // one thread per fp32 weight -> ns outputs
+  const int nstep = (T + tps - 1) / tps;
+  const int TP = nstep * tps;                          // padded tap count
+  const size_t total = (size_t)cout * cin * TP;        // one thread per (padded) fp32 weight -> ns outputs
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int j = i & 7;
     size_t r = i >> 3;
     const int n = r % cout; r /= cout;
     const int kh = r & 1; r >>= 1;
-    const int tap = r % T;
-    const int chunk = r / T;
+    const int tap = r % TP;
+    const int chunk = r / TP;
     const int ci = chunk * 16 + kh * 8 + j;
-    float v = w[((size_t)n * cin + ci) * T + tap];
+    float v = tap < T ? w[((size_t)n * cin + ci) * T + tap] : 0.f;
     for (int p = 0; p < ns; ++p) {
       const __bf16 bq = (__bf16)v;
       v -= (float)bq;
-      wp[((((size_t)(chunk * T + tap) * ns + p) * 2 + kh) * cout + n) * 8 + j] = bq;
+      wp[((((size_t)(chunk * TP + tap) * ns + p) * 2 + kh) * cout + n) * 8 + j] = bq;
     }
   }
+}
+
+// bf16 elements a packed weight needs (taps padded to a multiple of the step size)
+extern "C" long long tsr_conv_weight_bf16s_elems(int cout, int cin, int ks, int nsplit) {
+  const int tps = taps_per_step(ks, cout, nsplit);
+  const int T = ks * ks;
+  return (long long)nsplit * cout * cin * (((T + tps - 1) / tps) * tps);
 }
 
 extern "C" int tsr_pack_conv_weight_bf16s(const float* w_oihw, void* w_packed, int cout, int cin, int ks,
@@ -279,17 +308,21 @@ extern "C" int tsr_pack_conv_weight_bf16s(const float* w_oihw, void* w_packed, i
   if (!w_oihw || !w_packed || (cin & 15) || (cout != 64 && cout != 128) || (ks != 1 && ks != 3 && ks != 5) ||
       nsplit < 1 || nsplit > 3)
     return TSR_ERR_ARG;
-  const size_t total = (size_t)cout * cin * ks * ks;
+  const int tps = taps_per_step(ks, cout, nsplit);
+  const size_t total = (size_t)cout * cin * (((ks * ks + tps - 1) / tps) * tps);
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
-                     (hipStream_t)stream, w_oihw, (__bf16*)w_packed, cout, cin, ks, nsplit);
+                     (hipStream_t)stream, w_oihw, (__bf16*)w_packed, cout, cin, ks, nsplit, tps);
   return tsr_check_launch();
 }
 
 template <int KS, int COUT, int NS>
 static int launch_bf16s(const ConvArgs& a, hipStream_t st) {
   const int grid = ((a.B + 1) / 2) * a.tiles_x * a.tiles_y;
-  hipLaunchKernelGGL((conv_mfma_bf16s_kernel<KS, COUT, NS>), dim3(grid), dim3(256), 0, st, a);
+  static int setprio = -1;
+  if (setprio < 0) { const char* e = getenv("TSR_BF16S_SETPRIO"); setprio = e ? atoi(e) : 0; }
+  if (setprio) hipLaunchKernelGGL((conv_mfma_bf16s_kernel<KS, COUT, NS, true>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_mfma_bf16s_kernel<KS, COUT, NS, false>), dim3(grid), dim3(256), 0, st, a);
   return tsr_check_launch();
 }
 

@@ -83,7 +83,8 @@ class _PackedConv:
             self.w = torch.empty_like(w)
             call("tsr_pack_conv_weight", ptr(w), ptr(self.w), _I(self.cout), _I(self.cin), _I(self.ks), stream())
         else:
-            self.w = torch.empty(nsplit * w.numel(), dtype=torch.bfloat16, device=w.device)
+            n = _lib.load().tsr_conv_weight_bf16s_elems(self.cout, self.cin, self.ks, nsplit)
+            self.w = torch.empty(n, dtype=torch.bfloat16, device=w.device)
             call("tsr_pack_conv_weight_bf16s", ptr(w), ptr(self.w), _I(self.cout), _I(self.cin), _I(self.ks),
                  _I(nsplit), stream())
         self.scale, self.shift = _fold(conv.bias, bn, self.cout, w.device)

@@ -215,7 +215,8 @@ def test_conv2d_fwd_bf16_split(T, ks, cin, cout, B, H, W, nsplit, tol):
                    + shift.double().view(1, -1, 1, 1) + res.double())
     xin, rbuf = T.to_cb16(x.cuda()), T.to_cb16(res.cuda())
     wd = w.cuda().contiguous()
-    wp = torch.empty(nsplit * w.numel(), dtype=torch.bfloat16, device="cuda")
+    from tactilesr_amd._lib import load
+    wp = torch.empty(load().tsr_conv_weight_bf16s_elems(cout, cin, ks, nsplit), dtype=torch.bfloat16, device="cuda")
     call("tsr_pack_conv_weight_bf16s", ptr(wd), ptr(wp), I(cout), I(cin), I(ks), I(nsplit), stream())
     out = torch.empty(B * cout * H * W, device="cuda")
     sc, sh = scale.cuda(), shift.cuda()

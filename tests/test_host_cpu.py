@@ -26,7 +26,7 @@ def sd_hash(sd):
 
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(REPO, "include", "tactilesr_hip.h")).read()
-    declared = set(re.findall(r"^\s*int\s+(tsr_\w+|tpsf_\w+)\s*\(", hdr, re.M))
+    declared = set(re.findall(r"^\s*(?:int|long long)\s+(tsr_\w+|tpsf_\w+)\s*\(", hdr, re.M))
     assert declared, "no declarations parsed"
     lib = _lib.load()
     for name in declared:
