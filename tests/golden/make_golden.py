@@ -287,8 +287,51 @@ def gen_metrics():
     np.savez_compressed(os.path.join(HERE, "metrics.npz"), **out)
 
 
+
+
+def gen_lr():
+    """LR sequences of the reference's own LRWarmupScheduler (cpu/lr_scheduler.py, loaded by path because
+    cpu/__init__ needs tensorboard) wrapped around StepLR: one value after every iter_update / epoch_update."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_lr", "/root/reference/cpu/lr_scheduler.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    out = {k: lr_sequence(ref.LRWarmupScheduler, dict(c), 6, 500) for k, c in LR_CASES.items()}
+    np.savez_compressed(os.path.join(HERE, "lr_schedule.npz"), **out)
+
+
+LR_CASES = {
+    "auto_shipped": dict(lr=1e-3, step=2, by_epoch=True, warmup_t=2000, warmup_by_epoch=False, warmup_mode='auto',
+                         warmup_init_lr=1e-5, warmup_factor=1e-4),      # config/default.py:56-60 as forwarded
+    "fix": dict(lr=1e-3, step=2, by_epoch=True, warmup_t=700, warmup_by_epoch=False, warmup_mode='fix',
+                warmup_init_lr=1e-5, warmup_factor=1e-4),
+    "factor": dict(lr=1e-3, step=1, by_epoch=True, warmup_t=1300, warmup_by_epoch=False, warmup_mode='factor',
+                   warmup_init_lr=1e-5, warmup_factor=1e-2),
+    "by_epoch": dict(lr=1e-4, step=1, by_epoch=True, warmup_t=3, warmup_by_epoch=True, warmup_mode='auto',
+                     warmup_init_lr=1e-5, warmup_factor=1e-1),
+    "none": dict(lr=1e-4, step=1, by_epoch=True, warmup_t=0, warmup_by_epoch=False, warmup_mode='fix',
+                 warmup_init_lr=0.0, warmup_factor=0.0),
+}
+
+
+def lr_sequence(cls, cfg, epochs, epoch_len):
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=cfg.pop('lr'))
+    sch = torch.optim.lr_scheduler.StepLR(opt, step_size=cfg.pop('step'), gamma=0.8)
+    w = cls(sch, epoch_len=epoch_len, **cfg)
+    lrs = [opt.param_groups[0]['lr']]
+    for _ in range(epochs):
+        for _ in range(epoch_len):
+            opt.step()
+            w.iter_update()
+            lrs.append(opt.param_groups[0]['lr'])
+        w.epoch_update()
+        lrs.append(opt.param_groups[0]['lr'])
+    return np.array(lrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["init", "eval", "train", "tpsf", "metrics"]
+    which = sys.argv[1:] or ["init", "eval", "train", "tpsf", "metrics", "lr"]
     for w in which:
         globals()["gen_" + w]()
         print("wrote", w)

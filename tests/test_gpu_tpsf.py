@@ -59,3 +59,28 @@ def test_tpsf_large_batch_properties():
     assert torch.equal(psf, psf.transpose(2, 3))
     m = depth[5, 0] > depth[5, 0].max() - 1e-3
     assert HR[5, 0][m].unique().numel() == 1
+
+
+def test_dataset_generator_matches_batch1_loop(tmp_path):
+    """The batched generator (data/SRdataset/depth2tactile.py:104-160 rewritten without the batch-1 loop)
+    writes, per sample, exactly what a batch-1 forward produces, in the reference's file format."""
+    import os
+    import tactilesr_amd
+    from tactilesr_amd.data import depth2tactile as D
+    torch.manual_seed(2)
+    net = tactilesr_amd.tPSFNet(1.4, None).cuda()
+    g = torch.Generator().manual_seed(3)
+    LR_raw = torch.rand(9, 3, 4, 4, generator=g) * 800
+    depth = (torch.rand(9, 100, 100, generator=g) > 0.7).float()
+    entries = D.synthesize(net, LR_raw, depth, scale_num=100.0, batch_size=4)
+    path = os.path.join(tmp_path, "SRdataset_test.npy")
+    D.save_dataset(path, entries)
+    ds = np.load(path, allow_pickle=True)
+    assert len(ds) == 9
+    with torch.no_grad():
+        for i in (0, 4, 8):
+            HR, LRd, _, ab = net((LR_raw[i:i + 1] / 100).cuda(), depth[i:i + 1].unsqueeze(1).cuda())
+            it = ds[i].item()
+            assert torch.equal(it["HR"], HR[0].cpu()) and torch.equal(it["LR_degrade"], LRd[0].cpu())
+            assert torch.equal(it["alphaBeta"], ab[0, 0].cpu()) and it["depth"].shape == (1, 100, 100)
+            assert torch.allclose(it["LR"], LR_raw[i] / 100)
