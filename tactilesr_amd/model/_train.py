@@ -100,6 +100,7 @@ class TrainEngine:
 
     def __init__(self, model):
         self.m = model
+        self.debug = None        # tests may set a dict: backward then stores clones of dz tensors in it
 
     # ------------------------------------------------------------------ helpers
     def _bn_finalize(self, c: _Ctx, conv_bias, bn, slab, cnt, entries, C):
@@ -303,6 +304,9 @@ class TrainEngine:
         self._wgrad(c, HC, DZ, m.output_layer[0], grads, "output_layer.0", False)
         g_hcat = buf(128)
         self._dgrad(c, DZ, m.output_layer[0], 0, 128, g_hcat, 128, 0, mask=HC)
+        if self.debug is not None:
+            self.debug["dz_h0"] = dz_h0.clone()
+            self.debug["g_hcat"] = g_hcat.clone()
         del dz_h0
 
         # ---- force branch (ResBlocks, reversed); gradient w.r.t. block output pre-ReLU in `dpre`
@@ -344,6 +348,8 @@ class TrainEngine:
                 r = self._bn_bwd(c, g2, 256, o, Act(s.cat2, 256, 0, 256), o, 128, s.bn_c2[:, o:o + 128], bnm, grads,
                                  nm)
                 grads[f"{name}.{nm}.1.weight"], grads[f"{name}.{nm}.1.bias"] = r[0].clone(), r[1].clone()
+            if self.debug is not None:
+                self.debug[f"msrb{i}.dz2"] = g2.clone()
             DZ32, DZ52 = Act(g2, 256, 0, 128), Act(g2, 256, 128, 128)
             self._wgrad(c, s.A1, DZ32, blk.conv_3_2[0], grads, f"{name}.conv_3_2.0", True)
             self._wgrad(c, s.A1, DZ52, blk.conv_5_2[0], grads, f"{name}.conv_5_2.0", True)
@@ -355,6 +361,8 @@ class TrainEngine:
             grads[f"{name}.conv_3_1.1.weight"], grads[f"{name}.conv_3_1.1.bias"] = r[0, :64].clone(), r[1, :64].clone()
             grads[f"{name}.conv_5_1.1.weight"], grads[f"{name}.conv_5_1.1.bias"] = r[0, 64:].clone(), r[1, 64:].clone()
             del g2
+            if self.debug is not None:
+                self.debug[f"msrb{i}.dz1"] = g1.clone()
             DZ31, DZ51 = Act(g1, 128, 0, 64), Act(g1, 128, 64, 64)
             self._wgrad(c, s.X, DZ31, blk.conv_3_1[0], grads, f"{name}.conv_3_1.0", True)
             self._wgrad(c, s.X, DZ51, blk.conv_5_1[0], grads, f"{name}.conv_5_1.0", True)
