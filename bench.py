@@ -70,14 +70,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    local = local % torch.cuda.device_count()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+        backend = os.environ.get("TSR_BENCH_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; gloo = rehearsal only
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, init_method="env://")
 
     import tactilesr_amd
     torch.manual_seed(42)
@@ -150,7 +154,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "tactileSR_model eval forward 4x4->40x40, batch=4096/GPU, fp32 in/out (BASELINE configs[1])",
+            "config": {"workload": "tactileSR_model eval forward 4x4->40x40, batch=%d/GPU, fp32 in/out (BASELINE configs[1])" % B,
                        "batch_per_gpu": B, "scale_factor": 10, "seqsCnt": 1, "parallelism": f"replicas x{world}",
                        "conv_impl": args.impl},
             "roofline": {"bound": "mfma", "kernel": kname + "> (5x5 128->128 conv+BN+ReLU, 54% of all FLOPs)",
@@ -187,11 +191,12 @@ def main_train(args):
     from tactilesr_amd import ddp, optim
     from tactilesr_amd.train import tactileSR_train as TR
     import tactilesr_amd
-    if world > 1:
-        import torch.distributed as dist
-        ddp.init_distributed("nccl")
+    local = local % torch.cuda.device_count()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        ddp.init_distributed(os.environ.get("TSR_BENCH_DIST_BACKEND", "nccl"))
     torch.manual_seed(42)
     model = tactilesr_amd.TactileSR().to(dev).train()
     opt = optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-2)

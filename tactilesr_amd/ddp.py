@@ -25,6 +25,7 @@ def init_distributed(backend: str = "nccl"):
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if backend == "nccl":
+        local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
         dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local))
     else:

@@ -250,3 +250,25 @@ def test_model_eval_forward_bf16x6_vs_reference_golden(T, golden, tag):
     m.conv_impl = "f32"
     y32 = m(LR)                      # two fp32-grade evaluations: within the sum of their errors to fp64
     assert relerr(y, y32) < 2 * max(TOL, 4 * yard)
+
+
+@pytest.mark.parametrize("impl", ["bf16x6", "f32"])
+def test_full_size_batch4096_tiling_invariance(T, impl):
+    """BASELINE configs[1] size (B=4096): the batch is 32 distinct frames tiled 128x.  Samples are independent in
+    eval mode, so every replica must be bit-identical to the first, and the 32 distinct outputs must match the
+    CPU oracle (which finishes 32 frames in well under a second)."""
+    torch.manual_seed(42)
+    m = T.TactileSR()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.cuda().eval()
+    m.conv_impl = impl
+    g = torch.Generator().manual_seed(11)
+    base = torch.rand(32, 3, 4, 4, generator=g) * 8
+    LR = base.repeat(128, 1, 1, 1).cuda()
+    assert LR.shape[0] == 4096
+    y = m(LR)
+    y = y.view(128, 32, 1, 40, 40)
+    assert torch.equal(y, y[:1].expand_as(y))
+    with torch.no_grad():
+        ref = O.tactilesr_forward(sd, base)
+    assert relerr(y[0], ref) < TOL

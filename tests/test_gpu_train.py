@@ -278,3 +278,29 @@ def test_train_multiframe_and_odd_batch_vs_oracle(T, Tn, nm, B):
         if e_hip > max(2e-5, 2.5 * e_ref) and l2 > 3e-3:
             bad.append((k, e_hip, e_ref, l2))
     assert not bad, bad
+
+
+def test_large_batch_train_step_tiling_invariance(T):
+    """Size-independent property at a large batch (B=1024 = 32 frames tiled 32x): batch statistics, the MSE loss
+    and hence every gradient of a tiled batch equal those of the 32 base frames, which the CPU oracle can run."""
+    torch.manual_seed(5)
+    m = T.TactileSR(patternFeatureExtraLayerCnt=2)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(6)
+    LRb, HRb = torch.rand(32, 3, 4, 4, generator=g) * 8, torch.rand(32, 1, 40, 40, generator=g) * 25
+    m = m.cuda().train()
+    out = m(LRb.repeat(32, 1, 1, 1).cuda())
+    loss = F.mse_loss(out, HRb.repeat(32, 1, 1, 1).cuda())
+    loss.backward()
+    big = {k: p.grad.detach().cpu().double() for k, p in m.named_parameters()}
+    leaves = {k: v.double().requires_grad_(True) for k, v in sd.items() if O.is_trainable(k)}
+    full = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    full.update(leaves)
+    lo = F.mse_loss(O.tactilesr_forward(full, LRb.double(), training=True, new_stats={}), HRb.double())
+    gl = torch.autograd.grad(lo, list(leaves.values()))
+    assert abs(loss.item() - lo.item()) < 1e-5 * lo.item()
+    for k, ref in zip(leaves, gl):
+        if float(ref.abs().max()) < 1e-7:
+            continue
+        l2 = float((big[k] - ref).norm() / ref.norm())
+        assert l2 < 3e-3, (k, l2)          # rel-L2: robust to isolated ReLU-mask flips (see the odd-batch test)
