@@ -114,6 +114,8 @@ typedef struct tsr_conv_desc {
   const float* mask_scale; const float* mask_shift;
   const float* bn_a; const float* bn_b;
   float* slab; float* slab_cnt;
+  int nsplit;   /* 0: fp32 MFMA, w_packed from tsr_pack_conv_weight[_dgrad]; 1..3: split-bf16 MFMA (3 = fp32-equivalent),
+                   w_packed from tsr_pack_conv_weight[_dgrad]_bf16s */
 } tsr_conv_desc;
 
 int tsr_conv2d_ex(const tsr_conv_desc* desc, void* stream);
@@ -124,6 +126,9 @@ int tsr_conv2d_slab_entries(int B, int H, int W);
 int tsr_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed, int cout, int cin, int ks,
                                int ci0, int nprime, void* stream);
 
+int tsr_pack_conv_weight_dgrad_bf16s(const float* w_oihw, void* w_packed, int cout, int cin, int ks,
+                                     int ci0, int nprime, int nsplit, void* stream);
+
 /* Weight (and bias) gradient partials: slab[s][cout][cin][k][k] (s < nsplit, OIHW) with
  * dW = sum_s slab[s] (tsr_reduce_splits), from a = conv input (CB16, optional relu(a*scale+shift)
  * transform) and dz = gradient w.r.t. the conv output (CB16).  cin, cout multiples of 64.
@@ -132,6 +137,11 @@ int tsr_conv2d_wgrad(const float* a, int a_ctot, int a_coff, int cin,
                      const float* a_scale, const float* a_shift,
                      const float* dz, int dz_ctot, int dz_coff, int cout, int ks,
                      float* slab, float* bias_slab, int nsplit, int B, int H, int W, void* stream);
+/* Same on the bf16 matrix cores with 3-way split operands (planes must be 3: fp32-equivalent). */
+int tsr_conv2d_wgrad_bf16s(const float* a, int a_ctot, int a_coff, int cin,
+                           const float* a_scale, const float* a_shift,
+                           const float* dz, int dz_ctot, int dz_coff, int cout, int ks, int planes,
+                           float* slab, float* bias_slab, int nsplit, int B, int H, int W, void* stream);
 int tsr_reduce_splits(const float* slab, float* out, long long n, int nsplit, float alpha, void* stream);
 
 /* nn.BatchNorm2d train mode (model/tactileSR_model.py:38,42,48,169,175,181,187), from the

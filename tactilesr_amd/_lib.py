@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtactilesr_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _P, _I, _F, _L = c_void_p, c_int, c_float, c_longlong
 
@@ -30,7 +30,9 @@ SIGNATURES = {
     "tsr_conv2d_ex": [_P, _P],
     "tsr_conv2d_slab_entries": [_I, _I, _I],
     "tsr_pack_conv_weight_dgrad": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "tsr_pack_conv_weight_dgrad_bf16s": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "tsr_conv2d_wgrad": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P],
+    "tsr_conv2d_wgrad_bf16s": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P],
     "tsr_reduce_splits": [_P, _P, _L, _I, _F, _P],
     "tsr_bn_stats_finalize": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P],
     "tsr_cb16_stats_entries": [_I, _I],

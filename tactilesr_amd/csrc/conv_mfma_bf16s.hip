@@ -20,7 +20,8 @@
 // [plane][2][C_out][8] weight slab goes through a 2-deep LDS ring.
 #include "tsr_common.h"
 #include "conv_args.h"
-#include <stdlib.h>
+#include "conv_epilogue.h"
+#include "tactilesr_hip.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -43,7 +44,7 @@ constexpr int row_slots(int hh, int pixs, int rmod) {
   return rs;
 }
 
-template <int KS, int COUT, int NS, bool SETPRIO>
+template <int KS, int COUT, int NS, bool EXT>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs a) {
   constexpr int IMG = 2;
   constexpr int P = KS / 2;
@@ -133,11 +134,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
       if (st_src[k] >= 0) hv[k] = *(const f32x4*)(inc + st_src[k]);
     }
   };
-  auto store_halo = [&](const f32x4* hv) {
+  auto store_halo = [&](const f32x4* hv, int c) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       if (st_dst[k] >= 0) {
         f32x4 v = hv[k];
+        if (EXT && a.in_scale && st_src[k] >= 0) {   // producer's train-mode BN+ReLU, fused into the load
+          const int cq = c * 16 + ((tid + k * 256) & 3) * 4;
+          const f32x4 sc = *(const f32x4*)(a.in_scale + cq);
+          const f32x4 sh = *(const f32x4*)(a.in_shift + cq);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), 0.f);
+        }
 #pragma unroll
         for (int p = 0; p < NS; ++p) {
           bf16x4 bq;
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
   LOAD_W(0);
   STORE_W(0);
   if (S > 1) { LOAD_W(1); STORE_W(1); }
-  store_halo(hv);
+  store_halo(hv, 0);
   if (S > 2) LOAD_W(2);
   __syncthreads();
 
@@ -208,7 +216,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
           } else if (c + 1 < nchunk) {
             load_halo(c + 1, hv); // next block's slab: global loads fly under this tap's MFMAs
           }
-          if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int q = 0; q < NPROD; ++q)
 #pragma unroll
@@ -217,14 +224,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
               for (int nb = 0; nb < NB; ++nb)
                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][PA[6 - NPROD + q]][mb],
                                                                       fb[cur][PB[6 - NPROD + q]][nb], acc[mb][nb], 0, 0, 0);
-          if (SETPRIO) __builtin_amdgcn_s_setprio(0);
         }
       }
       if (s + 2 < S) STORE_W(slot2);           // slot (s+2)%3 was last read one barrier ago
       if (s + 3 < S) LOAD_W(s + 3);
       __syncthreads();
       if (st + 1 == NSTEP && c + 1 < nchunk) {
-        store_halo(hv);         // every wave is past its last read of the old slab (barrier above)
+        store_halo(hv, c + 1);  // every wave is past its last read of the old slab (barrier above)
         __syncthreads();
         LOAD_FRAGS(0, slot1, 0, 0, 0);         // T is odd: a block always starts on fragment set 0
       }
@@ -236,45 +242,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
 #undef STORE_W
 #undef LOAD_FRAGS
 
-  // ---- epilogue (inference form): y = acc*scale + shift (+ residual) (ReLU) -> channel slice of out
-  const int b = b0 + wm;
-  if (b >= a.B) return;
-  const int out_blocks = a.out_ctot >> 4;
-  const int res_blocks = a.res_ctot >> 4;
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int n = wn * (COUT / 2) + nb * 32 + li;
-    const float sc = a.scale ? a.scale[n] : 1.f;
-    const float sh = a.shift ? a.shift[n] : 0.f;
-    const int oc = a.out_coff + n;
-    float* obase = a.out + (((size_t)b * out_blocks + (oc >> 4)) * HW) * 16 + (oc & 15);
-    const float* rbase = nullptr;
-    if (a.res) {
-      const int rc = a.res_coff + n;
-      rbase = a.res + (((size_t)b * res_blocks + (rc >> 4)) * HW) * 16 + (rc & 15);
-    }
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int gy = y0 + 4 * mb + (m >> 3), gx = x0 + (m & 7);
-        if (gy < a.H && gx < a.W) {
-          const size_t po = (size_t)(gy * a.W + gx) * 16;
-          float v = acc[mb][nb][r] * sc + sh;
-          if (rbase) v += rbase[po];
-          if (a.relu) v = fmaxf(v, 0.f);
-          obase[po] = v;
-        }
-      }
-    }
-  }
+  conv_epilogue<COUT, EXT>(a, acc, bid, b0, y0, x0, wm, wn, h, li, HW);
 }
 
 // OIHW fp32 -> [C_in/16][step][tap in step][plane][2 (k half)][C_out][8] bf16 split planes; taps are
 // grouped TPS per barrier step (taps_per_step), the tail of the last step is zero.
+// dgrad mode (ci0 >= 0): the packed conv is W'[n][k=co][kh][kw] = W[co][ci0+n][K-1-kh][K-1-kw] with
+// "cout" := nprime and "cin" := cout_f (see tsr_pack_conv_weight_dgrad).
 __global__ void pack_conv_weight_bf16s_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int cout,
-                                              int cin, int ks, int ns, int tps) {
+                                              int cin, int ks, int ns, int tps, int ci0, int cin_f) {
   const int T = ks * ks;
   const int nstep = (T + tps - 1) / tps;
   const int TP = nstep * tps;                          // padded tap count
@@ -287,7 +263,9 @@ __global__ void pack_conv_weight_bf16s_kernel(const float* __restrict__ w, __bf1
     const int tap = r % TP;
     const int chunk = r / TP;
     const int ci = chunk * 16 + kh * 8 + j;
-    float v = tap < T ? w[((size_t)n * cin + ci) * T + tap] : 0.f;
+    float v = 0.f;
+    if (tap < T) v = ci0 < 0 ? w[((size_t)n * cin + ci) * T + tap]
+                             : w[((size_t)ci * cin_f + ci0 + n) * T + (T - 1 - tap)];
     for (int p = 0; p < ns; ++p) {
       const __bf16 bq = (__bf16)v;
       v -= (float)bq;
@@ -312,31 +290,49 @@ extern "C" int tsr_pack_conv_weight_bf16s(const float* w_oihw, void* w_packed, i
   const size_t total = (size_t)cout * cin * (((ks * ks + tps - 1) / tps) * tps);
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
-                     (hipStream_t)stream, w_oihw, (__bf16*)w_packed, cout, cin, ks, nsplit, tps);
+                     (hipStream_t)stream, w_oihw, (__bf16*)w_packed, cout, cin, ks, nsplit, tps, -1, 0);
   return tsr_check_launch();
 }
 
-template <int KS, int COUT, int NS>
+extern "C" int tsr_pack_conv_weight_dgrad_bf16s(const float* w_oihw, void* w_packed, int cout, int cin, int ks,
+                                                int ci0, int nprime, int nsplit, void* stream) {
+  if (!w_oihw || !w_packed || (cout & 15) || (nprime != 64 && nprime != 128) || ci0 < 0 || ci0 + nprime > cin ||
+      (ks != 1 && ks != 3 && ks != 5) || nsplit < 1 || nsplit > 3)
+    return TSR_ERR_ARG;
+  const int tps = taps_per_step(ks, nprime, nsplit);
+  const size_t total = (size_t)nprime * cout * (((ks * ks + tps - 1) / tps) * tps);
+  const int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
+                     (hipStream_t)stream, w_oihw, (__bf16*)w_packed, nprime, cout, ks, nsplit, tps, ci0, cin);
+  return tsr_check_launch();
+}
+
+template <int KS, int COUT, int NS, bool EXT>
 static int launch_bf16s(const ConvArgs& a, hipStream_t st) {
   const int grid = ((a.B + 1) / 2) * a.tiles_x * a.tiles_y;
-  static int setprio = -1;
-  if (setprio < 0) { const char* e = getenv("TSR_BF16S_SETPRIO"); setprio = e ? atoi(e) : 0; }
-  if (setprio) hipLaunchKernelGGL((conv_mfma_bf16s_kernel<KS, COUT, NS, true>), dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_mfma_bf16s_kernel<KS, COUT, NS, false>), dim3(grid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv_mfma_bf16s_kernel<KS, COUT, NS, EXT>), dim3(grid), dim3(256), 0, st, a);
   return tsr_check_launch();
 }
 
-template <int NS>
+template <int NS, bool EXT>
 static int dispatch_bf16s(const ConvArgs& a, int cout, int ks, hipStream_t st) {
   if (cout == 64) {
-    if (ks == 1) return launch_bf16s<1, 64, NS>(a, st);
-    if (ks == 3) return launch_bf16s<3, 64, NS>(a, st);
-    if (ks == 5) return launch_bf16s<5, 64, NS>(a, st);
+    if (ks == 1) return launch_bf16s<1, 64, NS, EXT>(a, st);
+    if (ks == 3) return launch_bf16s<3, 64, NS, EXT>(a, st);
+    if (ks == 5) return launch_bf16s<5, 64, NS, EXT>(a, st);
   } else if (cout == 128) {
-    if (ks == 1) return launch_bf16s<1, 128, NS>(a, st);
-    if (ks == 3) return launch_bf16s<3, 128, NS>(a, st);
-    if (ks == 5) return launch_bf16s<5, 128, NS>(a, st);
+    if (ks == 1) return launch_bf16s<1, 128, NS, EXT>(a, st);
+    if (ks == 3) return launch_bf16s<3, 128, NS, EXT>(a, st);
+    if (ks == 5) return launch_bf16s<5, 128, NS, EXT>(a, st);
   }
+  return TSR_ERR_ARG;
+}
+
+// tsr_conv2d_ex with nsplit > 0 lands here (argument checks were done by the caller)
+int tsr_conv2d_ex_bf16s(const ConvArgs& a, int cout, int ks, int nsplit, hipStream_t st) {
+  if (nsplit == 3) return dispatch_bf16s<3, true>(a, cout, ks, st);
+  if (nsplit == 2) return dispatch_bf16s<2, true>(a, cout, ks, st);
+  if (nsplit == 1) return dispatch_bf16s<1, true>(a, cout, ks, st);
   return TSR_ERR_ARG;
 }
 
@@ -359,7 +355,7 @@ extern "C" int tsr_conv2d_fwd_bf16s(const float* in, int in_ctot, int in_coff, i
   a.B = B; a.H = H; a.W = W;
   a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8;
   hipStream_t st = (hipStream_t)stream;
-  if (nsplit == 3) return dispatch_bf16s<3>(a, cout, ks, st);
-  if (nsplit == 2) return dispatch_bf16s<2>(a, cout, ks, st);
-  return dispatch_bf16s<1>(a, cout, ks, st);
+  if (nsplit == 3) return dispatch_bf16s<3, false>(a, cout, ks, st);
+  if (nsplit == 2) return dispatch_bf16s<2, false>(a, cout, ks, st);
+  return dispatch_bf16s<1, false>(a, cout, ks, st);
 }

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "conv_args.h"
+#include "conv_epilogue.h"
 
 // EXT = training-path extensions compiled in (input/residual transforms, epi_mode 1/2);
 // PF  = prefetch the next channel block's halo slab into registers during the current block.
@@ -181,133 +182,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_f32_kernel(const ConvArgs a)
     }
   }
 
-  // ---- epilogue
-  const int b = b0 + wm;
-  const bool img_ok = b < a.B;
-  const int out_blocks = a.out_ctot >> 4;
-  const int res_blocks = a.res_ctot >> 4;
-  const int mask_blocks = a.mask_ctot >> 4;
-  const int bsafe = img_ok ? b : 0;
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int n = wn * (COUT / 2) + nb * 32 + li;
-    const int oc = a.out_coff + n;
-    float* obase = a.out + (((size_t)bsafe * out_blocks + (oc >> 4)) * HW) * 16 + (oc & 15);
-    const float* rbase = nullptr;
-    if (a.res) {
-      const int rc = a.res_coff + n;
-      rbase = a.res + (((size_t)bsafe * res_blocks + (rc >> 4)) * HW) * 16 + (rc & 15);
-    }
-    if (!EXT || a.epi_mode == 0) {
-      // y = acc*scale + shift (+ residual) (ReLU) -> channel slice of out
-      if (!img_ok) continue;
-      const float sc = a.scale ? a.scale[n] : 1.f;
-      const float sh = a.shift ? a.shift[n] : 0.f;
-      const float rsc = (EXT && a.res_scale) ? a.res_scale[n] : 1.f;
-      const float rsh = (EXT && a.res_scale) ? a.res_shift[n] : 0.f;
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int gy = y0 + 4 * mb + (m >> 3), gx = x0 + (m & 7);
-          if (gy < a.H && gx < a.W) {
-            const size_t po = (size_t)(gy * a.W + gx) * 16;
-            float v = acc[mb][nb][r] * sc + sh;
-            if (rbase) {
-              float rv = rbase[po];
-              if (EXT && a.res_scale) rv = fmaxf(fmaf(rv, rsc, rsh), 0.f);
-              v += rv;
-            }
-            if (a.relu) v = fmaxf(v, 0.f);
-            obase[po] = v;
-          }
-        }
-      }
-    } else if (EXT && a.epi_mode == 1) {
-      // raw accumulator out + Welford partial (mean, M2) of this wave's valid pixels
-      float cnt = 0.f, sum = 0.f;
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int gy = y0 + 4 * mb + (m >> 3), gx = x0 + (m & 7);
-          if (img_ok && gy < a.H && gx < a.W) {
-            const float v = acc[mb][nb][r];
-            obase[(size_t)(gy * a.W + gx) * 16] = v;
-            cnt += 1.f;
-            sum += v;
-          }
-        }
-      }
-      float mean = cnt > 0.f ? sum / cnt : 0.f;
-      float m2 = 0.f;
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int gy = y0 + 4 * mb + (m >> 3), gx = x0 + (m & 7);
-          if (img_ok && gy < a.H && gx < a.W) {
-            const float d = acc[mb][nb][r] - mean;
-            m2 = fmaf(d, d, m2);
-          }
-        }
-      }
-      // Chan merge with the partner half-wave (same channel, other 4 pixel columns)
-      const float cnt2 = __shfl_xor(cnt, 32), mean2 = __shfl_xor(mean, 32), m22 = __shfl_xor(m2, 32);
-      const float nt = cnt + cnt2;
-      const float dlt = mean2 - mean;
-      const float meanm = nt > 0.f ? mean + dlt * (cnt2 / nt) : 0.f;
-      const float m2m = nt > 0.f ? m2 + m22 + dlt * dlt * (cnt * cnt2 / nt) : 0.f;
-      if (h == 0) {
-        const size_t e = (size_t)bid * 2 + wm;
-        float* sl = a.slab + (e * COUT + n) * 2;
-        sl[0] = meanm;
-        sl[1] = m2m;
-        if (nb == 0 && li == 0 && wn == 0) a.slab_cnt[e] = nt;
-      }
-    } else if (EXT) {
-      // ReLU backward by the stored activation (+ optional BN-backward partial sums)
-      const int mc = a.mask_coff + n;
-      const float* mbase = a.mask + (((size_t)bsafe * mask_blocks + (mc >> 4)) * HW) * 16 + (mc & 15);
-      const float msc = a.mask_scale ? a.mask_scale[n] : 1.f;
-      const float msh = a.mask_scale ? a.mask_shift[n] : 0.f;
-      const float ba = a.bn_a ? a.bn_a[n] : 0.f;
-      const float bb = a.bn_a ? a.bn_b[n] : 0.f;
-      const float sc = a.scale ? a.scale[n] : 1.f;
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int gy = y0 + 4 * mb + (m >> 3), gx = x0 + (m & 7);
-          if (img_ok && gy < a.H && gx < a.W) {
-            const size_t po = (size_t)(gy * a.W + gx) * 16;
-            float v = acc[mb][nb][r] * sc;
-            if (rbase) v += rbase[po];
-            const float mv = mbase[po];
-            if (!(fmaf(mv, msc, msh) > 0.f)) v = 0.f;
-            obase[po] = v;
-            s1 += v;
-            s2 = fmaf(v, fmaf(mv, ba, bb), s2);
-          }
-        }
-      }
-      if (a.bn_a) {
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (h == 0) {
-          const size_t e = (size_t)bid * 2 + wm;
-          float* sl = a.slab + (e * COUT + n) * 2;
-          sl[0] = s1;
-          sl[1] = s2;
-        }
-      }
-    }
-  }
+  conv_epilogue<COUT, EXT>(a, acc, bid, b0, y0, x0, wm, wn, h, li, HW);
 }
 
 // OIHW -> [C_in/16][tap][4 (channel quad)][C_out][4]: the order the kernel streams.
@@ -433,6 +308,8 @@ extern "C" int tsr_conv2d_slab_entries(int B, int H, int W) {
   return ((B + 1) / 2) * ((W + 7) / 8) * ((H + 7) / 8) * 2;
 }
 
+int tsr_conv2d_ex_bf16s(const ConvArgs& a, int cout, int ks, int nsplit, hipStream_t st);   // conv_mfma_bf16s.hip
+
 extern "C" int tsr_conv2d_ex(const tsr_conv_desc* d, void* stream) {
   if (!d || !d->in || !d->w_packed || !d->out || d->B <= 0 || d->H <= 0 || d->W <= 0) return TSR_ERR_ARG;
   if (check_slices(d->cin, d->in_ctot, d->in_coff, d->cout, d->out_ctot, d->out_coff)) return TSR_ERR_ARG;
@@ -459,5 +336,7 @@ extern "C" int tsr_conv2d_ex(const tsr_conv_desc* d, void* stream) {
   a.mask_scale = d->mask_scale; a.mask_shift = d->mask_shift;
   a.bn_a = d->bn_a; a.bn_b = d->bn_b;
   a.slab = d->slab; a.slab_cnt = d->slab_cnt;
+  if (d->nsplit < 0 || d->nsplit > 3) return TSR_ERR_ARG;
+  if (d->nsplit > 0) return tsr_conv2d_ex_bf16s(a, d->cout, d->ks, d->nsplit, (hipStream_t)stream);
   return dispatch_conv<true>(a, d->cout, d->ks, (hipStream_t)stream);
 }

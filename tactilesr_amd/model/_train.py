@@ -39,6 +39,7 @@ class ConvDesc(ctypes.Structure):
         ("mask_scale", c_void_p), ("mask_shift", c_void_p),
         ("bn_a", c_void_p), ("bn_b", c_void_p),
         ("slab", c_void_p), ("slab_cnt", c_void_p),
+        ("nsplit", c_int),
     ]
 
 
@@ -56,8 +57,9 @@ class Act:
 
 
 def conv_ex(*, B, H, W, src: Act, w, cout, ks, out, out_ctot, out_coff, scale=None, shift=None, relu=0,
-            res: Act = None, epi_mode=0, mask: Act = None, bn=False, slab=None, slab_cnt=None):
+            res: Act = None, epi_mode=0, mask: Act = None, bn=False, slab=None, slab_cnt=None, nsplit=0):
     d = ConvDesc()
+    d.nsplit = nsplit
     d.in_, d.in_ctot, d.in_coff, d.cin = _p(src.buf), src.ctot, src.coff, src.c
     d.w_packed, d.cout, d.ks = _p(w), cout, ks
     d.scale, d.shift = _p(scale), _p(shift)
@@ -79,13 +81,24 @@ def conv_ex(*, B, H, W, src: Act, w, cout, ks, out, out_ctot, out_coff, scale=No
         raise _lib.TactileSRHipError(f"tsr_conv2d_ex failed: status {st}")
 
 
-def _pack(w, cout, cin, ks):
+def _pack(w, cout, cin, ks, nsplit=0):
+    if nsplit:
+        n = _lib.load().tsr_conv_weight_bf16s_elems(cout, cin, ks, nsplit)
+        wp = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+        call("tsr_pack_conv_weight_bf16s", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), _I(nsplit), stream())
+        return wp
     wp = torch.empty(cout * cin * ks * ks, dtype=torch.float32, device=w.device)
     call("tsr_pack_conv_weight", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), stream())
     return wp
 
 
-def _pack_dgrad(w, cout, cin, ks, ci0, nprime):
+def _pack_dgrad(w, cout, cin, ks, ci0, nprime, nsplit=0):
+    if nsplit:
+        n = _lib.load().tsr_conv_weight_bf16s_elems(nprime, cout, ks, nsplit)
+        wp = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+        call("tsr_pack_conv_weight_dgrad_bf16s", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), _I(ci0), _I(nprime),
+             _I(nsplit), stream())
+        return wp
     wp = torch.empty(nprime * cout * ks * ks, dtype=torch.float32, device=w.device)
     call("tsr_pack_conv_weight_dgrad", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), _I(ci0), _I(nprime), stream())
     return wp
@@ -101,6 +114,9 @@ class TrainEngine:
     def __init__(self, model):
         self.m = model
         self.debug = None        # tests may set a dict: backward then stores clones of dz tensors in it
+        import os
+        # conv arithmetic of the train path: 0 = fp32 MFMA, 3 = split-bf16 (six products, fp32-equivalent)
+        self.nsplit = {"f32": 0, "bf16x6": 3}[os.environ.get("TSR_TRAIN_IMPL", "bf16x6")]
 
     # ------------------------------------------------------------------ helpers
     def _bn_finalize(self, c: _Ctx, conv_bias, bn, slab, cnt, entries, C):
@@ -117,9 +133,9 @@ class TrainEngine:
         """conv (bias-free raw output) + batch statistics; returns the 4xC BN vectors."""
         w = conv.weight.detach()
         cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
-        wp = _pack(w.contiguous(), cout, cin, ks)
+        wp = _pack(w.contiguous(), cout, cin, ks, self.nsplit)
         conv_ex(B=c.B, H=c.H, W=c.W, src=src, w=wp, cout=cout, ks=ks, out=out, out_ctot=out_ctot,
-                out_coff=out_coff, epi_mode=1, slab=c.slab, slab_cnt=c.slab_cnt)
+                out_coff=out_coff, epi_mode=1, slab=c.slab, slab_cnt=c.slab_cnt, nsplit=self.nsplit)
         return self._bn_finalize(c, conv.bias, bn, c.slab, c.slab_cnt, c.entries, cout)
 
     # ------------------------------------------------------------------ forward
@@ -180,13 +196,13 @@ class TrainEngine:
             A2 = Act(s.cat2, 256, 0, 256, s.bn_c2[0], s.bn_c2[1], s.bn_c2[2], s.bn_c2[3])
             s.A1, s.A2 = A1, A2
             wconf = blk.confusion.weight.detach().contiguous()
-            wp = _pack(wconf, 64, 256, 1)
+            wp = _pack(wconf, 64, 256, 1, self.nsplit)
             if i == n_msrb - 1:
                 out, octot, ocoff = c.hcat, 128, 64
             else:
                 out, octot, ocoff = buf(64), 64, 0
             conv_ex(B=B, H=H, W=W, src=A2, w=wp, cout=64, ks=1, out=out, out_ctot=octot, out_coff=ocoff,
-                    shift=blk.confusion.bias.detach(), relu=1, res=X)
+                    shift=blk.confusion.bias.detach(), relu=1, res=X, nsplit=self.nsplit)
             X = Act(out, octot, ocoff, 64)
             s.Y = X
             c.blocks.append(s)
@@ -206,24 +222,24 @@ class TrainEngine:
             s = _Ctx()
             s.X = F0
             s.f1 = buf(64)
-            w1 = _pack(rb.conv1.weight.detach().contiguous(), 64, 64, 3)
+            w1 = _pack(rb.conv1.weight.detach().contiguous(), 64, 64, 3, self.nsplit)
             conv_ex(B=B, H=H, W=W, src=F0, w=w1, cout=64, ks=3, out=s.f1, out_ctot=64, out_coff=0,
-                    shift=rb.conv1.bias.detach(), relu=1)
-            w2 = _pack(rb.conv2.weight.detach().contiguous(), 64, 64, 3)
+                    shift=rb.conv1.bias.detach(), relu=1, nsplit=self.nsplit)
+            w2 = _pack(rb.conv2.weight.detach().contiguous(), 64, 64, 3, self.nsplit)
             if i == n_res - 1:
                 out, octot, ocoff = c.hcat, 128, 0
             else:
                 out, octot, ocoff = buf(64), 64, 0
             conv_ex(B=B, H=H, W=W, src=Act(s.f1, 64, 0, 64), w=w2, cout=64, ks=3, out=out, out_ctot=octot,
-                    out_coff=ocoff, shift=rb.conv2.bias.detach(), relu=1, res=F0)
+                    out_coff=ocoff, shift=rb.conv2.bias.detach(), relu=1, res=F0, nsplit=self.nsplit)
             F0 = Act(out, octot, ocoff, 64)
             s.Y = F0
             c.res.append(s)
         # ---- head
         c.h0 = buf(128)
-        wh = _pack(m.output_layer[0].weight.detach().contiguous(), 128, 128, 3)
+        wh = _pack(m.output_layer[0].weight.detach().contiguous(), 128, 128, 3, self.nsplit)
         conv_ex(B=B, H=H, W=W, src=Act(c.hcat, 128, 0, 128), w=wh, cout=128, ks=3, out=c.h0, out_ctot=128,
-                out_coff=0, relu=1)
+                out_coff=0, relu=1, nsplit=self.nsplit)
         out = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
         call("tsr_head_fwd", ptr(c.h0), _I(128), _I(128), ptr(m.output_layer[2].weight.detach()), ptr(out), _I(1),
              _I(B), _I(H), _I(W), stream())
@@ -231,12 +247,11 @@ class TrainEngine:
         return out, c
 
     # ------------------------------------------------------------------ backward pieces
-    @staticmethod
-    def _nsplit(B, tiles, ks, cout, cin):
+    def _nsplit(self, B, tiles, ks, cout, cin):
         """Batch splits of the wgrad launch: slices*nsplit ~ 2 x (3 workgroups x 256 CUs) resident slots;
         work items are (image, 8x8 patch) pairs, so splits may outnumber images."""
         slices = ks * (cout // 64) * (cin // 64)
-        return max(1, min(B * tiles, 1536 // slices))
+        return max(1, min(B * tiles, (1024 if self.nsplit == 3 else 1536) // slices))   # 2 (bf16s) / 3 (f32) WGs per CU
 
     def _wgrad(self, c, a: Act, dz: Act, conv, grads, name, with_bias):
         w = conv.weight
@@ -245,9 +260,14 @@ class TrainEngine:
         n = cout * cin * ks * ks
         slab = torch.empty(ns * n, dtype=torch.float32, device=w.device)
         bslab = torch.empty(ns * cout, dtype=torch.float32, device=w.device) if with_bias else None
-        call("tsr_conv2d_wgrad", ptr(a.buf), _I(a.ctot), _I(a.coff), _I(cin), ptr(a.scale), ptr(a.shift),
-             ptr(dz.buf), _I(dz.ctot), _I(dz.coff), _I(cout), _I(ks), ptr(slab), ptr(bslab), _I(ns),
-             _I(c.B), _I(c.H), _I(c.W), stream())
+        if self.nsplit == 3:
+            call("tsr_conv2d_wgrad_bf16s", ptr(a.buf), _I(a.ctot), _I(a.coff), _I(cin), ptr(a.scale), ptr(a.shift),
+                 ptr(dz.buf), _I(dz.ctot), _I(dz.coff), _I(cout), _I(ks), _I(3), ptr(slab), ptr(bslab), _I(ns),
+                 _I(c.B), _I(c.H), _I(c.W), stream())
+        else:
+            call("tsr_conv2d_wgrad", ptr(a.buf), _I(a.ctot), _I(a.coff), _I(cin), ptr(a.scale), ptr(a.shift),
+                 ptr(dz.buf), _I(dz.ctot), _I(dz.coff), _I(cout), _I(ks), ptr(slab), ptr(bslab), _I(ns),
+                 _I(c.B), _I(c.H), _I(c.W), stream())
         gw = torch.empty_like(w)
         call("tsr_reduce_splits", ptr(slab), ptr(gw), _L(n), _I(ns), _F(1.0), stream())
         grads[name + ".weight"] = gw
@@ -261,10 +281,10 @@ class TrainEngine:
         """d(input)[ci0:ci0+nprime] of conv given dz; optional + res, ReLU mask, BN-backward sums."""
         w = conv.weight.detach().contiguous()
         cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
-        wp = _pack_dgrad(w, cout, cin, ks, ci0, nprime)
+        wp = _pack_dgrad(w, cout, cin, ks, ci0, nprime, self.nsplit)
         conv_ex(B=c.B, H=c.H, W=c.W, src=dz, w=wp, cout=nprime, ks=ks, out=out, out_ctot=out_ctot,
                 out_coff=out_coff, res=res, epi_mode=2 if mask is not None else 0, mask=mask, bn=bn,
-                slab=c.slab if bn else None, slab_cnt=None)
+                slab=c.slab if bn else None, slab_cnt=None, nsplit=self.nsplit)
 
     def _bn_bwd(self, c, g_buf, g_ctot, g_coff, z: Act, zoff, C, bn_vec, bn_mod, grads, name):
         """Finish BatchNorm backward for C channels whose masked gradient g sits in g_buf (slab sums
