@@ -22,6 +22,7 @@
 #include "conv_args.h"
 #include "conv_epilogue.h"
 #include "tactilesr_hip.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -44,7 +45,7 @@ constexpr int row_slots(int hh, int pixs, int rmod) {
   return rs;
 }
 
-template <int KS, int COUT, int NS, bool EXT>
+template <int KS, int COUT, int NS, bool EXT, bool STAGGER>
 __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs a) {
   constexpr int IMG = 2;
   constexpr int P = KS / 2;
@@ -77,6 +78,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int h = lane >> 5, li = lane & 31;
+
+  // The two workgroups that share a CU run the same program and fall into lockstep (both in their MFMA
+  // block, then both in their LDS/barrier phase: the matrix pipe idles ~25 % of the time).  A static,
+  // asymmetric priority by hardware wave slot lets one of the two co-resident waves of each SIMD run ahead
+  // and the other fill its gaps (HW_REG_HW_ID bits [3:0] = wave slot within the SIMD).
+  if (STAGGER) {
+    const unsigned slot_id = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+    if (slot_id & 1) __builtin_amdgcn_s_setprio(2);
+  }
 
   int bid;
   {
@@ -224,11 +234,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
               for (int nb = 0; nb < NB; ++nb)
                 acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][PA[6 - NPROD + q]][mb],
                                                                       fb[cur][PB[6 - NPROD + q]][nb], acc[mb][nb], 0, 0, 0);
+          if (t + 1 < T) {
+            // interleave the next tap's fragment reads with this tap's MFMAs (hipcc otherwise sinks all ds_reads
+            // below the MFMA block, exposing their latency in front of the barrier's lgkmcnt(0) every step)
+            constexpr int NRD = NS * (2 + NB), NMF = NPROD * 2 * NB, PER = NMF / NRD > 0 ? NMF / NRD : 1;
+#pragma unroll
+            for (int i = 0; i < NRD; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+            }
+          }
         }
       }
       if (s + 2 < S) STORE_W(slot2);           // slot (s+2)%3 was last read one barrier ago
       if (s + 3 < S) LOAD_W(s + 3);
+#ifndef TSR_EXPERIMENT_NOBAR
       __syncthreads();
+#endif
       if (st + 1 == NSTEP && c + 1 < nchunk) {
         store_halo(hv, c + 1);  // every wave is past its last read of the old slab (barrier above)
         __syncthreads();
@@ -310,7 +332,10 @@ extern "C" int tsr_pack_conv_weight_dgrad_bf16s(const float* w_oihw, void* w_pac
 template <int KS, int COUT, int NS, bool EXT>
 static int launch_bf16s(const ConvArgs& a, hipStream_t st) {
   const int grid = ((a.B + 1) / 2) * a.tiles_x * a.tiles_y;
-  hipLaunchKernelGGL((conv_mfma_bf16s_kernel<KS, COUT, NS, EXT>), dim3(grid), dim3(256), 0, st, a);
+  static int stagger = -1;
+  if (stagger < 0) { const char* e = getenv("TSR_BF16S_STAGGER"); stagger = e ? atoi(e) : 0; }
+  if (stagger) hipLaunchKernelGGL((conv_mfma_bf16s_kernel<KS, COUT, NS, EXT, true>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_mfma_bf16s_kernel<KS, COUT, NS, EXT, false>), dim3(grid), dim3(256), 0, st, a);
   return tsr_check_launch();
 }
 
