@@ -70,3 +70,27 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No fallback: without the HIP library every product entry point raises (it never routes to the oracle)."""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(tmp_path, "nope", "libtactilesr_hip.so"))
+    with pytest.raises(_lib.TactileSRHipError, match="no CPU fallback"):
+        _lib.load()
+    with pytest.raises(_lib.TactileSRHipError):
+        _lib.call("tsr_abi_version")
+    monkeypatch.undo()
+    assert _lib.load().tsr_abi_version() == _lib.ABI_VERSION
+
+
+def test_tpsfnet_interface_and_cpu_refusal():
+    net = tactilesr_amd.tPSFNet(gama=1.4, perception_scale=None, device="cpu")
+    assert (net.gama, net.perception_scale) == (1.4, None)
+    assert list(net.state_dict()) == [f"MLP_layer.{i}.{p}" for i in (1, 3, 5, 7) for p in ("weight", "bias")]
+    assert net.PSF_sdf.shape == (1, 1, 99, 99) and net.LR_masking_sdf.shape == (4, 4, 100, 100)
+    assert abs(float(net.PSF_sdf.max()) - 10) < 1e-5 and abs(float(net.LR_masking_sdf.max()) - 10) < 1e-5
+    with pytest.raises(AssertionError, match="Batch size of LR tactile and depth"):
+        net(torch.zeros(2, 3, 4, 4), torch.zeros(3, 1, 100, 100))
+    with pytest.raises(_lib.TactileSRHipError, match="no CPU fallback"):
+        net(torch.zeros(2, 3, 4, 4), torch.zeros(2, 1, 100, 100))
