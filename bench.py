@@ -56,9 +56,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=4096, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--impl", choices=["bf16x6", "f32", "bf16x3", "bf16"], default="bf16x6",
-                    help="conv arithmetic of the timed path: bf16x6 = fp32 operands split into 3 bf16 planes, "
-                         "6 bf16-MFMA products, fp32 accumulate (fp32-equivalent, default); f32 = fp32 MFMA; "
+    ap.add_argument("--impl", choices=["fp16x3", "bf16x6", "f32", "bf16x3", "bf16"], default="fp16x3",
+                    help="conv arithmetic of the timed path (all accumulate in fp32): fp16x3 = fp32 operands scaled by "
+                         "powers of two and split into 2 fp16 planes, 3 f16-MFMA products (fp32-grade, default); "
+                         "bf16x6 = 3 bf16 planes, 6 products (fp32-equivalent); f32 = fp32 MFMA; "
                          "bf16x3 / bf16 = reduced precision (not the headline)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = BASELINE configs[1] (headline); train = data-parallel train step "
@@ -138,16 +139,18 @@ def main():
         value = total / dt
         ev = prof.get((5, 128), [])
         c5_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
-        nprod = {"bf16x6": 6, "bf16x3": 3, "bf16": 1, "f32": 1}[args.impl]
+        nprod = {"fp16x3": 3, "bf16x6": 6, "bf16x3": 3, "bf16": 1, "f32": 1}[args.impl]
         peak = PEAK_F32_MFMA if args.impl == "f32" else PEAK_BF16_MFMA
         alg = B * C5_FLOP_PER_SAMPLE / (c5_ms * 1e-3) if ev else None       # algorithmic FLOP/s of the launch
         achieved = alg * nprod / 1e12 if ev else None                        # MFMA FLOP/s actually executed
         kname = ("conv_mfma_f32_kernel<5, 128" if args.impl == "f32" else
-                 "conv_mfma_bf16s_kernel<5, 128, %d" % {"bf16x6": 3, "bf16x3": 2, "bf16": 1}[args.impl])
+                 "conv_mfma_split16_kernel<5, 128, %d, false, %s" % ({"fp16x3": 2, "bf16x6": 3, "bf16x3": 2, "bf16": 1}[args.impl],
+                                                                     "true" if args.impl == "fp16x3" else "false"))
         per_kernel = {f"conv{k[0]}x{k[0]}_c{k[1]}": round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 3)
                       for k, v in sorted(prof.items())}
         traffic, traffic_src = pmc_traffic(kname) if B == 4096 else (None, None)
-        dtype = {"bf16x6": "f32 as 3 bf16 planes x 6 MFMA products, fp32 accumulate (fp32-equivalent)",
+        dtype = {"fp16x3": "f32 as 2 power-of-two-scaled fp16 planes x 3 MFMA products, fp32 accumulate (fp32-grade)",
+                 "bf16x6": "f32 as 3 bf16 planes x 6 MFMA products, fp32 accumulate (fp32-equivalent)",
                  "f32": "f32", "bf16x3": "bf16x3 (reduced: ~16 significand bits)", "bf16": "bf16"}[args.impl]
         res = {
             "metric": "SR samples/sec (4x4->40x40)", "value": round(value, 2), "unit": "samples/s",

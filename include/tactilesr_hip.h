@@ -70,13 +70,31 @@ int tsr_conv2d_fwd_bf16s(const float* in, int in_ctot, int in_coff, int cin,
                          float* out, int out_ctot, int out_coff, int relu,
                          int B, int H, int W, void* stream);
 
+/* fp16 two-plane variant ("fp16x3"): operands are scaled by powers of two into fp16's range -- weights at pack
+ * time (wscale chosen by the caller: max|w|*wscale in [2^13,2^14); pass w_inv_scale = 1/wscale), activations in
+ * the kernel from the device scalar in_amax = max|x| that the producer wrote through its out_amax -- then split
+ * x*sx = h1+h2, w*sw = g1+g2 (22+ significand bits) and h1g1 + h1g2 + h2g1 are accumulated in fp32; the scales
+ * are undone exactly in the epilogue.  Half the MFMA work of bf16x6; network-level error equal to the reference's
+ * own fp32 CPU run against fp64 (tests).  Same remaining arguments as tsr_conv2d_fwd. */
+int tsr_pack_conv_weight_f16s(const float* w_oihw, void* w_packed, int cout, int cin, int ks, float wscale,
+                              void* stream);
+int tsr_conv2d_fwd_f16s(const float* in, int in_ctot, int in_coff, int cin,
+                        const void* w_packed, int cout, int ks, float w_inv_scale,
+                        const float* in_amax, float* out_amax,
+                        const float* scale, const float* shift,
+                        const float* res, int res_ctot, int res_coff,
+                        float* out, int out_ctot, int out_coff, int relu,
+                        int B, int H, int W, void* stream);
+
 /* nn.Upsample(scale_factor=sf, bilinear, align_corners=False) + Conv2d(3->64, 3x3, pad 1, no bias)
  * + scale/shift + optional ReLU: the pattern stem's first conv (model/tactileSR_model.py:34-39)
  * and the force stem (:59-63).  lr is the NCHW taxel tensor (B, lr_ctot, hin, win); channels
  * [lr_coff, lr_coff+3) are read (the x[:, 3t:3t+3] slices of :71-78).  Output CB16, H = hin*sf. */
 int tsr_stem_fwd(const float* lr, int lr_ctot, int lr_coff, int axis_cnt, int hin, int win, int sf,
                  const float* w_oihw, const float* scale, const float* shift,
-                 float* out, int out_ctot, int out_coff, int relu, int B, void* stream);
+                 float* out, int out_ctot, int out_coff, int relu, int B, float* out_amax, void* stream);
+/* out_amax (optional device scalar): receives max|output| by atomic max -- the fp16-split convolution that
+ * consumes the tensor derives its power-of-two input scale from it. */
 
 /* Conv2d(cin->1, 3x3, pad 1, no bias) + ReLU, CB16 in, NCHW (B,1,H,W) out: output_layer[2:]
  * (model/tactileSR_model.py:55-56).  The trailing same-size F.interpolate (:83) is an identity. */

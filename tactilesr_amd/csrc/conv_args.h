@@ -24,4 +24,8 @@ struct ConvArgs {
   const float* mask_scale; const float* mask_shift;
   const float* bn_a; const float* bn_b;
   float* slab; float* slab_cnt;
+  // ---- fp16-split path (dynamic power-of-two operand scaling; all optional) ----
+  const float* in_amax;   // device scalar: max |input activation| (written by the producer) -> input scale 2^k
+  float w_inv_scale;      // 1 / (power-of-two weight scale applied at pack time); 0 = unused
+  float* out_amax;        // device scalar: atomic max of |output| after the epilogue (for the consumer)
 };

@@ -7,10 +7,15 @@
 #include "tsr_common.h"
 #include "conv_args.h"
 
-template <int COUT, bool EXT>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2][COUT / 64], int bid, int b0, int y0,
-                                              int x0, int wm, int wn, int h, int li, int HW) {
-  constexpr int NB = COUT / 64;
+// accmul: exact power-of-two factor undoing the operand scaling of the fp16-split path (1 otherwise).
+// WN = waves across C_out (2: each wave owns C_out/2 of one of 2 images; 1: each wave owns all C_out of one of 4).
+template <int COUT, bool EXT, int WN = 2>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2][COUT / (32 * WN)], int bid, int b0,
+                                              int y0, int x0, int wm, int wn, int h, int li, int HW,
+                                              float accmul = 1.f) {
+  constexpr int NB = COUT / (32 * WN);
+  constexpr int IMG = 4 / WN;
+  float amax = 0.f;
   const int b = b0 + wm;
   const bool img_ok = b < a.B;
   const int out_blocks = a.out_ctot >> 4;
@@ -19,7 +24,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
   const int bsafe = img_ok ? b : 0;
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const int n = wn * (COUT / 2) + nb * 32 + li;
+    const int n = wn * (COUT / WN) + nb * 32 + li;
     const int oc = a.out_coff + n;
     float* obase = a.out + (((size_t)bsafe * out_blocks + (oc >> 4)) * HW) * 16 + (oc & 15);
     const float* rbase = nullptr;
@@ -42,7 +47,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
           const int gy = y0 + 4 * mb + (m >> 3), gx = x0 + (m & 7);
           if (gy < a.H && gx < a.W) {
             const size_t po = (size_t)(gy * a.W + gx) * 16;
-            float v = acc[mb][nb][r] * sc + sh;
+            float v = (acc[mb][nb][r] * accmul) * sc + sh;
             if (rbase) {
               float rv = rbase[po];
               if (EXT && a.res_scale) rv = fmaxf(fmaf(rv, rsc, rsh), 0.f);
@@ -50,6 +55,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
             }
             if (a.relu) v = fmaxf(v, 0.f);
             obase[po] = v;
+            amax = fmaxf(amax, fabsf(v));
           }
         }
       }
@@ -91,7 +97,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
       const float meanm = nt > 0.f ? mean + dlt * (cnt2 / nt) : 0.f;
       const float m2m = nt > 0.f ? m2 + m22 + dlt * dlt * (cnt * cnt2 / nt) : 0.f;
       if (h == 0) {
-        const size_t e = (size_t)bid * 2 + wm;
+        const size_t e = (size_t)bid * IMG + wm;
         float* sl = a.slab + (e * COUT + n) * 2;
         sl[0] = meanm;
         sl[1] = m2m;
@@ -129,12 +135,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
         if (h == 0) {
-          const size_t e = (size_t)bid * 2 + wm;
+          const size_t e = (size_t)bid * IMG + wm;
           float* sl = a.slab + (e * COUT + n) * 2;
           sl[0] = s1;
           sl[1] = s2;
         }
       }
     }
+  }
+  if (a.out_amax) {     // one atomic per wave: |v| >= 0, so the uint order of the bit patterns is the float order
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if ((h | li) == 0) atomicMax((unsigned int*)a.out_amax, __float_as_uint(amax));
   }
 }

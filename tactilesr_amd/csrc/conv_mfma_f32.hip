@@ -308,7 +308,7 @@ extern "C" int tsr_conv2d_slab_entries(int B, int H, int W) {
   return ((B + 1) / 2) * ((W + 7) / 8) * ((H + 7) / 8) * 2;
 }
 
-int tsr_conv2d_ex_bf16s(const ConvArgs& a, int cout, int ks, int nsplit, hipStream_t st);   // conv_mfma_bf16s.hip
+int tsr_conv2d_ex_bf16s(const ConvArgs& a, int cout, int ks, int nsplit, hipStream_t st);   // conv_mfma_split16.hip
 
 extern "C" int tsr_conv2d_ex(const tsr_conv_desc* d, void* stream) {
   if (!d || !d->in || !d->w_packed || !d->out || d->B <= 0 || d->H <= 0 || d->W <= 0) return TSR_ERR_ARG;

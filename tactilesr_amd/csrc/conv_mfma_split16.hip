@@ -1,23 +1,25 @@
-// Split-bf16 implicit-GEMM convolution on the CDNA4 bf16 matrix cores (v_mfma_f32_32x32x16_bf16),
-// a drop-in alternative to conv_mfma_f32_kernel for the inference epilogue.
+// Split-operand implicit-GEMM convolution on the CDNA4 16-bit matrix cores (v_mfma_f32_32x32x16_{bf16,f16}),
+// a drop-in alternative to conv_mfma_f32_kernel (same tiling, same epilogues).
 //
-// gfx950 runs bf16 MFMA at 16x the fp32-MFMA rate, so fp32 operands are split on the fly into NS
-// bf16 planes  x = x1 + x2 + x3  (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 24
-// significand bits for NS = 3, exact for every fp32 value whose low planes stay normal) and each K = 16
-// step issues the bf16 products that matter, all accumulated in fp32 inside the MFMA:
-//   NS = 3 ("bf16x6"): x1w1 + x1w2 + x2w1 + x1w3 + x3w1 + x2w2  -> error <= the fp32 MFMA path's
-//                      (measured 1.4e-7 vs 2.9e-7 at K = 3200), at 16/6 = 2.67x its MFMA rate;
-//   NS = 2 ("bf16x3"): x1w1 + x1w2 + x2w1                         -> ~4e-6 per layer (16 significand bits);
-//   NS = 1 ("bf16"):   x1w1                                       -> plain bf16 inputs, fp32 accumulate.
-// bf16 has fp32's exponent range, so no scaling is needed.  Activations stay fp32 CB16 in HBM (the
-// path is MFMA-bound, not HBM-bound); the split happens while the halo slab is staged into LDS,
-// weights are split once by tsr_pack_conv_weight_bf16s.
+// gfx950 runs 16-bit MFMA at 16x the fp32-MFMA rate, so fp32 operands are split on the fly into NS 16-bit planes
+// and each K = 16 step issues only the cross products that matter, all accumulated in fp32 inside the MFMA:
+//   fp16, NS = 2 ("fp16x3", default eval path): operands are first scaled by exact powers of two into fp16's
+//        range (weights at pack time; activations from the max|x| scalar their producer published), then
+//        x*sx = h1+h2, w*sw = g1+g2 (2 x 11 significand bits; round-to-nearest residuals make that 23 bits) and
+//        h1g1 + h1g2 + h2g1; the scales are undone exactly in the epilogue.  3/16 of the fp32-MFMA cost; measured
+//        network-level error vs fp64 <= the fp32-MFMA path's on every fixture.
+//   bf16, NS = 3 ("bf16x6"): x = x1+x2+x3 (24 bits, fp32's exponent range, no scaling), six products
+//        x1w1 + x1w2 + x2w1 + x1w3 + x3w1 + x2w2: error <= the fp32 MFMA path's (1.4e-7 vs 2.9e-7 at K = 3200).
+//        Used for training (gradients span too wide a range for fp16 planes without per-tensor bookkeeping).
+//   bf16, NS = 2 ("bf16x3", ~4e-6 per layer) and NS = 1 (plain bf16): reduced-precision modes, never the parity path.
+// Activations stay fp32 CB16 in HBM (the path is MFMA-bound, not HBM-bound); the split happens while the halo
+// slab is staged into LDS, weights are split once by tsr_pack_conv_weight_{bf16s,f16s}.
 //
-// Tiling is the fp32 kernel's: 8x8 patch x 2 images (M = 128) x all C_out per 256-thread workgroup,
-// waves 2 (image) x 2 (C_out half), per C_in block of 16 (= one MFMA K step) the halo slab sits in
-// LDS as [pixel][plane][16 bf16] with a 112/64/48-B pixel stride and a row stride chosen so that the
-// ds_read_b128 A fragments of all 64 lanes are bank-conflict free; per (block, tap) the
-// [plane][2][C_out][8] weight slab goes through a 2-deep LDS ring.
+// Tiling is the fp32 kernel's: 8x8 patch x 2 images (M = 128) x all C_out per 256-thread workgroup, waves
+// 2 (image) x 2 (C_out half), per C_in block of 16 (= one MFMA K step) the halo slab sits in LDS as
+// [pixel][plane][16 x 16-bit] with a 112/64/48-B pixel stride and a row stride chosen so that the ds_read_b128
+// A fragments of all 64 lanes are bank-conflict free; fragments are ping-pong prefetched one tap ahead and
+// interleaved with the MFMAs; per step the [plane][2][C_out][8] weight slab goes through a 3-slot LDS ring.
 #include "tsr_common.h"
 #include "conv_args.h"
 #include "conv_epilogue.h"
@@ -26,6 +28,20 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// 16-bit plane element: bf16 (fp32 exponent range, 8-bit significand: 3 planes = fp32) or fp16 (11-bit
+// significand: 2 planes = 22+ bits, the operands are pre-scaled by a power of two into fp16's range).
+template <bool F16> struct Plane;
+template <> struct Plane<false> {
+  typedef __bf16 T; typedef bf16x8 V8; typedef bf16x4 V4;
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Plane<true> {
+  typedef _Float16 T; typedef f16x8 V8; typedef f16x4 V4;
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 
 template <int NS> struct SplitGeom;
 template <> struct SplitGeom<1> { static constexpr int PIXS = 3, RMOD = 8; };
@@ -45,13 +61,18 @@ constexpr int row_slots(int hh, int pixs, int rmod) {
   return rs;
 }
 
-template <int KS, int COUT, int NS, bool EXT, bool STAGGER>
-__global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs a) {
-  constexpr int IMG = 2;
+// WN = waves across C_out: 2 -> 2 images per workgroup, wave = (image, C_out half); 1 -> 4 images per workgroup, wave
+// = image x all C_out (used for C_out = 64, where a half would leave a single 32-wide block per wave).
+template <int KS, int COUT, int NS, bool EXT, bool F16, int WN>
+__global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArgs a) {
+  typedef typename Plane<F16>::T PT;
+  typedef typename Plane<F16>::V8 PV8;
+  typedef typename Plane<F16>::V4 PV4;
+  constexpr int IMG = 4 / WN;
   constexpr int P = KS / 2;
   constexpr int HH = 8 + KS - 1;
   constexpr int T = KS * KS;
-  constexpr int NB = COUT / 64;
+  constexpr int NB = COUT / (32 * WN);
   constexpr int PIXB = SplitGeom<NS>::PIXS * 16;                               // bytes per halo pixel
   constexpr int ROWB = row_slots(HH, SplitGeom<NS>::PIXS, SplitGeom<NS>::RMOD) * 16;
   constexpr int IMGB = HH * ROWB;
@@ -76,16 +97,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
   const int h = lane >> 5, li = lane & 31;
 
-  // The two workgroups that share a CU run the same program and fall into lockstep (both in their MFMA
-  // block, then both in their LDS/barrier phase: the matrix pipe idles ~25 % of the time).  A static,
-  // asymmetric priority by hardware wave slot lets one of the two co-resident waves of each SIMD run ahead
-  // and the other fill its gaps (HW_REG_HW_ID bits [3:0] = wave slot within the SIMD).
-  if (STAGGER) {
-    const unsigned slot_id = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
-    if (slot_id & 1) __builtin_amdgcn_s_setprio(2);
+  // fp16 planes: power-of-two input scale from the producer's max|x| (m*sx in [2^13, 2^14)), undone exactly in
+  // the epilogue together with the pack-time weight scale
+  float sx = 1.f, accmul = 1.f;
+  if (F16) {
+    const float m = a.in_amax ? *a.in_amax : 0.f;
+    if (m > 0.f) {
+      int e = (int)((__float_as_uint(m) >> 23) & 0xFF) - 127;
+      int be = 13 - e + 127;
+      be = be < 1 ? 1 : (be > 254 ? 254 : be);
+      sx = __uint_as_float((unsigned)be << 23);
+    }
+    accmul = a.w_inv_scale / sx;
   }
 
   int bid;
@@ -121,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
   const float* in_base = a.in + ((size_t)b0 * in_blocks + (a.in_coff >> 4)) * HW * 16;
 
   const int laneA = wm * IMGB + (li >> 3) * ROWB + (li & 7) * PIXB + h * 16;
-  const int laneB = (h * COUT + wn * (COUT / 2) + li) * 16;
+  const int laneB = (h * COUT + wn * (COUT / WN) + li) * 16;
 
   f32x16 acc[2][NB];
 #pragma unroll
@@ -156,15 +182,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), 0.f);
         }
+        if (F16) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] *= sx;
+        }
 #pragma unroll
         for (int p = 0; p < NS; ++p) {
-          bf16x4 bq;
+          PV4 bq;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            bq[j] = (__bf16)v[j];
+            bq[j] = (PT)v[j];
             v[j] -= (float)bq[j];
           }
-          *(bf16x4*)(halo + st_dst[k] + p * 32) = bq;
+          *(PV4*)(halo + st_dst[k] + p * 32) = bq;
         }
       }
     }
@@ -188,9 +218,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
     const char* wb_ = wbuf + (slot) * WSLAB_B + (tapoff) * WTAP_B;                       \
     _Pragma("unroll") for (int p = 0; p < NS; ++p) {                                     \
       _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                   \
-        fa[set][p][mb] = *(const bf16x8*)(halo + laneA + (4 * mb + (kh_)) * ROWB + (kw_) * PIXB + p * 32); \
+        fa[set][p][mb] = *(const PV8*)(halo + laneA + (4 * mb + (kh_)) * ROWB + (kw_) * PIXB + p * 32); \
       _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                  \
-        fb[set][p][nb] = *(const bf16x8*)(wb_ + laneB + p * (2 * COUT * 16) + nb * (32 * 16)); \
+        fb[set][p][nb] = *(const PV8*)(wb_ + laneB + p * (2 * COUT * 16) + nb * (32 * 16)); \
     }                                                                                    \
   }
 
@@ -204,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
   if (S > 2) LOAD_W(2);
   __syncthreads();
 
-  bf16x8 fa[2][NS][2], fb[2][NS][NB];     // ping-pong fragment sets, statically indexed
+  PV8 fa[2][NS][2], fb[2][NS][NB];        // ping-pong fragment sets, statically indexed
   LOAD_FRAGS(0, 0, 0, 0, 0);
 
   int s = 0;
@@ -232,8 +262,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
               for (int nb = 0; nb < NB; ++nb)
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][PA[6 - NPROD + q]][mb],
-                                                                      fb[cur][PB[6 - NPROD + q]][nb], acc[mb][nb], 0, 0, 0);
+                acc[mb][nb] = Plane<F16>::mfma(fa[cur][PA[6 - NPROD + q]][mb], fb[cur][PB[6 - NPROD + q]][nb],
+                                               acc[mb][nb]);
           if (t + 1 < T) {
             // interleave the next tap's fragment reads with this tap's MFMAs (hipcc otherwise sinks all ds_reads
             // below the MFMA block, exposing their latency in front of the barrier's lgkmcnt(0) every step)
@@ -264,15 +294,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_bf16s_kernel(const ConvArgs 
 #undef STORE_W
 #undef LOAD_FRAGS
 
-  conv_epilogue<COUT, EXT>(a, acc, bid, b0, y0, x0, wm, wn, h, li, HW);
+  conv_epilogue<COUT, EXT, WN>(a, acc, bid, b0, y0, x0, wm, wn, h, li, HW, accmul);
 }
 
 // OIHW fp32 -> [C_in/16][step][tap in step][plane][2 (k half)][C_out][8] bf16 split planes; taps are
 // grouped TPS per barrier step (taps_per_step), the tail of the last step is zero.
 // dgrad mode (ci0 >= 0): the packed conv is W'[n][k=co][kh][kw] = W[co][ci0+n][K-1-kh][K-1-kw] with
 // "cout" := nprime and "cin" := cout_f (see tsr_pack_conv_weight_dgrad).
-__global__ void pack_conv_weight_bf16s_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int cout,
-                                              int cin, int ks, int ns, int tps, int ci0, int cin_f) {
+template <bool F16>
+__global__ void pack_conv_weight_bf16s_kernel(const float* __restrict__ w, typename Plane<F16>::T* __restrict__ wp,
+                                              int cout, int cin, int ks, int ns, int tps, int ci0, int cin_f,
+                                              float wscale) {
+  typedef typename Plane<F16>::T PT;
   const int T = ks * ks;
   const int nstep = (T + tps - 1) / tps;
   const int TP = nstep * tps;                          // padded tap count
@@ -288,8 +321,9 @@ __global__ void pack_conv_weight_bf16s_kernel(const float* __restrict__ w, __bf1
     float v = 0.f;
     if (tap < T) v = ci0 < 0 ? w[((size_t)n * cin + ci) * T + tap]
                              : w[((size_t)ci * cin_f + ci0 + n) * T + (T - 1 - tap)];
+    v *= wscale;
     for (int p = 0; p < ns; ++p) {
-      const __bf16 bq = (__bf16)v;
+      const PT bq = (PT)v;
       v -= (float)bq;
       wp[((((size_t)(chunk * TP + tap) * ns + p) * 2 + kh) * cout + n) * 8 + j] = bq;
     }
@@ -311,8 +345,23 @@ extern "C" int tsr_pack_conv_weight_bf16s(const float* w_oihw, void* w_packed, i
   const int tps = taps_per_step(ks, cout, nsplit);
   const size_t total = (size_t)cout * cin * (((ks * ks + tps - 1) / tps) * tps);
   const int grid = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
-                     (hipStream_t)stream, w_oihw, (__bf16*)w_packed, cout, cin, ks, nsplit, tps, -1, 0);
+  hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel<false>, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
+                     (hipStream_t)stream, w_oihw, (__bf16*)w_packed, cout, cin, ks, nsplit, tps, -1, 0, 1.0f);
+  return tsr_check_launch();
+}
+
+// fp16 two-plane packing: planes of w*wscale (wscale a power of two chosen by the caller so that
+// max|w|*wscale lies in [2^13, 2^14)); tsr_conv2d_fwd_f16s gets 1/wscale back.
+extern "C" int tsr_pack_conv_weight_f16s(const float* w_oihw, void* w_packed, int cout, int cin, int ks,
+                                         float wscale, void* stream) {
+  if (!w_oihw || !w_packed || (cin & 15) || (cout != 64 && cout != 128) || (ks != 1 && ks != 3 && ks != 5) ||
+      !(wscale > 0.f))
+    return TSR_ERR_ARG;
+  const int tps = taps_per_step(ks, cout, 2);
+  const size_t total = (size_t)cout * cin * (((ks * ks + tps - 1) / tps) * tps);
+  const int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel<true>, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
+                     (hipStream_t)stream, w_oihw, (_Float16*)w_packed, cout, cin, ks, 2, tps, -1, 0, wscale);
   return tsr_check_launch();
 }
 
@@ -324,31 +373,33 @@ extern "C" int tsr_pack_conv_weight_dgrad_bf16s(const float* w_oihw, void* w_pac
   const int tps = taps_per_step(ks, nprime, nsplit);
   const size_t total = (size_t)nprime * cout * (((ks * ks + tps - 1) / tps) * tps);
   const int grid = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
-                     (hipStream_t)stream, w_oihw, (__bf16*)w_packed, nprime, cout, ks, nsplit, tps, ci0, cin);
+  hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel<false>, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
+                     (hipStream_t)stream, w_oihw, (__bf16*)w_packed, nprime, cout, ks, nsplit, tps, ci0, cin, 1.0f);
   return tsr_check_launch();
 }
 
-template <int KS, int COUT, int NS, bool EXT>
+template <int KS, int COUT, int NS, bool EXT, bool F16>
 static int launch_bf16s(const ConvArgs& a, hipStream_t st) {
-  const int grid = ((a.B + 1) / 2) * a.tiles_x * a.tiles_y;
-  static int stagger = -1;
-  if (stagger < 0) { const char* e = getenv("TSR_BF16S_STAGGER"); stagger = e ? atoi(e) : 0; }
-  if (stagger) hipLaunchKernelGGL((conv_mfma_bf16s_kernel<KS, COUT, NS, EXT, true>), dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_mfma_bf16s_kernel<KS, COUT, NS, EXT, false>), dim3(grid), dim3(256), 0, st, a);
+  // inference, C_out = 64: 4 images per workgroup, every wave owns all 64 channels of one image (the training
+  // form keeps image pairs: its statistics slabs are laid out per pair, tsr_conv2d_slab_entries)
+  // (measured: helps the fp16 3x3 / 5x5 kernels; the 1x1 and the 3-plane bf16 forms are faster as pairs)
+  constexpr int WN = (!EXT && COUT == 64 && F16 && KS > 1) ? 1 : 2;
+  constexpr int IMG = 4 / WN;
+  const int grid = ((a.B + IMG - 1) / IMG) * a.tiles_x * a.tiles_y;
+  hipLaunchKernelGGL((conv_mfma_split16_kernel<KS, COUT, NS, EXT, F16, WN>), dim3(grid), dim3(256), 0, st, a);
   return tsr_check_launch();
 }
 
-template <int NS, bool EXT>
+template <int NS, bool EXT, bool F16 = false>
 static int dispatch_bf16s(const ConvArgs& a, int cout, int ks, hipStream_t st) {
   if (cout == 64) {
-    if (ks == 1) return launch_bf16s<1, 64, NS, EXT>(a, st);
-    if (ks == 3) return launch_bf16s<3, 64, NS, EXT>(a, st);
-    if (ks == 5) return launch_bf16s<5, 64, NS, EXT>(a, st);
+    if (ks == 1) return launch_bf16s<1, 64, NS, EXT, F16>(a, st);
+    if (ks == 3) return launch_bf16s<3, 64, NS, EXT, F16>(a, st);
+    if (ks == 5) return launch_bf16s<5, 64, NS, EXT, F16>(a, st);
   } else if (cout == 128) {
-    if (ks == 1) return launch_bf16s<1, 128, NS, EXT>(a, st);
-    if (ks == 3) return launch_bf16s<3, 128, NS, EXT>(a, st);
-    if (ks == 5) return launch_bf16s<5, 128, NS, EXT>(a, st);
+    if (ks == 1) return launch_bf16s<1, 128, NS, EXT, F16>(a, st);
+    if (ks == 3) return launch_bf16s<3, 128, NS, EXT, F16>(a, st);
+    if (ks == 5) return launch_bf16s<5, 128, NS, EXT, F16>(a, st);
   }
   return TSR_ERR_ARG;
 }
@@ -383,4 +434,30 @@ extern "C" int tsr_conv2d_fwd_bf16s(const float* in, int in_ctot, int in_coff, i
   if (nsplit == 3) return dispatch_bf16s<3, false>(a, cout, ks, st);
   if (nsplit == 2) return dispatch_bf16s<2, false>(a, cout, ks, st);
   return dispatch_bf16s<1, false>(a, cout, ks, st);
+}
+
+// fp16 two-plane variant ("fp16x3": x*sx = h1+h2, w*sw = g1+g2, products h1g1 + h1g2 + h2g1, fp32 accumulate).
+// in_amax: device scalar holding max|x| of the input tensor (written by its producer through out_amax);
+// out_amax: device scalar that receives (atomic max) max|y| of this launch's output, for the consumer.
+extern "C" int tsr_conv2d_fwd_f16s(const float* in, int in_ctot, int in_coff, int cin,
+                                   const void* w_packed, int cout, int ks, float w_inv_scale,
+                                   const float* in_amax, float* out_amax,
+                                   const float* scale, const float* shift,
+                                   const float* res, int res_ctot, int res_coff,
+                                   float* out, int out_ctot, int out_coff, int relu,
+                                   int B, int H, int W, void* stream) {
+  if (!in || !w_packed || !out || !in_amax || B <= 0 || H <= 0 || W <= 0 || !(w_inv_scale > 0.f)) return TSR_ERR_ARG;
+  if ((cin & 15) || (in_ctot & 15) || (in_coff & 15) || (out_ctot & 15) || (out_coff & 15) || cin <= 0 ||
+      in_coff + cin > in_ctot || out_coff + cout > out_ctot)
+    return TSR_ERR_ARG;
+  if (res && ((res_ctot & 15) || (res_coff & 15) || res_coff + cout > res_ctot)) return TSR_ERR_ARG;
+  ConvArgs a = {};
+  a.in = in; a.in_ctot = in_ctot; a.in_coff = in_coff; a.cin = cin;
+  a.wp = (const float*)w_packed; a.scale = scale; a.shift = shift;
+  a.res = res; a.res_ctot = res_ctot; a.res_coff = res_coff;
+  a.out = out; a.out_ctot = out_ctot; a.out_coff = out_coff; a.relu = relu;
+  a.B = B; a.H = H; a.W = W;
+  a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8;
+  a.in_amax = in_amax; a.w_inv_scale = w_inv_scale; a.out_amax = out_amax;
+  return dispatch_bf16s<2, false, true>(a, cout, ks, (hipStream_t)stream);
 }

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ lr,
                                                    const float* __restrict__ scale,
                                                    const float* __restrict__ shift,
                                                    float* __restrict__ out, int out_ctot, int out_coff,
-                                                   int relu, int B, int RB) {
+                                                   int relu, int B, int RB, float* __restrict__ out_amax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = hin * sf, W = win * sf;
   const int WP = W + 2;
@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ lr,
   const int HW = H * W;
   const int npix = rows * W;
   const int out_blocks = out_ctot >> 4;
+  float amax = 0.f;
   for (int it = tid; it < npix * 4; it += 256) {
     const int blk = it / npix, p = it - blk * npix;
     const int y = p / W, x = p - y * W;
@@ -107,15 +108,21 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ lr,
         const int n = blk * 16 + 4 * q + j;
         float t = acc[4 * q + j] * (scale ? scale[n] : 1.f) + (shift ? shift[n] : 0.f);
         v[j] = relu ? fmaxf(t, 0.f) : t;
+        amax = fmaxf(amax, fabsf(v[j]));
       }
       ((f32x4*)o)[q] = v;
     }
+  }
+  if (out_amax) {      // max |output| for the fp16-split consumer's power-of-two scale
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if ((tid & 63) == 0) atomicMax((unsigned int*)out_amax, __float_as_uint(amax));
   }
 }
 
 extern "C" int tsr_stem_fwd(const float* lr, int lr_ctot, int lr_coff, int axis_cnt, int hin, int win, int sf,
                             const float* w_oihw, const float* scale, const float* shift,
-                            float* out, int out_ctot, int out_coff, int relu, int B, void* stream) {
+                            float* out, int out_ctot, int out_coff, int relu, int B, float* out_amax, void* stream) {
   if (!lr || !w_oihw || !out || B <= 0 || axis_cnt != 3 || hin <= 0 || win <= 0 || sf <= 0) return TSR_ERR_ARG;
   if ((out_ctot & 15) || (out_coff & 15) || out_coff + 64 > out_ctot || lr_coff + axis_cnt > lr_ctot)
     return TSR_ERR_ARG;
@@ -125,7 +132,7 @@ extern "C" int tsr_stem_fwd(const float* lr, int lr_ctot, int lr_coff, int axis_
   if (smem > 64 * 1024) return TSR_ERR_ARG;
   dim3 grid((H + RB - 1) / RB, B);
   hipLaunchKernelGGL((stem_kernel<3>), grid, dim3(256), smem, (hipStream_t)stream, lr, lr_ctot, lr_coff, hin,
-                     win, sf, w_oihw, scale, shift, out, out_ctot, out_coff, relu, B, RB);
+                     win, sf, w_oihw, scale, shift, out, out_ctot, out_coff, relu, B, RB, out_amax);
   return tsr_check_launch();
 }
 

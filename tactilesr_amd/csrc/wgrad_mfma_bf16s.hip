@@ -1,4 +1,4 @@
-// Weight gradient on the bf16 matrix cores with split-fp32 operands (see conv_mfma_bf16s.hip for the
+// Weight gradient on the bf16 matrix cores with split-fp32 operands (see conv_mfma_split16.hip for the
 // arithmetic: x = x1+x2+x3 in bf16, six cross products per K step, fp32 accumulate -> fp32-equivalent).
 // Same decomposition as wgrad_mfma_f32_kernel: a workgroup owns 64 co x 64 ci x one kernel row and sweeps
 // (image, 8x8 patch) work items; M = co, N = ci, K = pixels.  v_mfma_f32_32x32x16_bf16 wants 8 consecutive K

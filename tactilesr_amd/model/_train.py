@@ -166,7 +166,7 @@ class TrainEngine:
         for t, seq in enumerate(m.inputLayer_pattern_list):
             z1 = buf(64)
             call("tsr_stem_fwd", ptr(x), _I(ctot_in), _I(A * t), _I(A), _I(hin), _I(win), _I(sf),
-                 ptr(seq[1].weight.detach()), ptr(None), ptr(None), ptr(z1), _I(64), _I(0), _I(0), _I(B), stream())
+                 ptr(seq[1].weight.detach()), ptr(None), ptr(None), ptr(z1), _I(64), _I(0), _I(0), _I(B), ptr(None), stream())
             call("tsr_cb16_stats", ptr(z1), _I(64), _I(0), _I(B), _I(HW), ptr(c.slab), ptr(c.slab_cnt), stream())
             v1 = self._bn_finalize(c, None, seq[2], c.slab, c.slab_cnt, st_entries, 64)
             c.z1.append(z1)
@@ -212,7 +212,7 @@ class TrainEngine:
         c.f0 = buf(64)
         call("tsr_stem_fwd", ptr(x), _I(ctot_in), _I(0), _I(A), _I(hin), _I(win), _I(sf),
              ptr(m.input_layer_force[1].weight.detach()), ptr(None), ptr(None), ptr(c.f0), _I(64), _I(0), _I(1),
-             _I(B), stream())
+             _I(B), ptr(None), stream())
         F0 = Act(c.f0, 64, 0, 64)
         c.res = []
         n_res = len(m.forceFeatureExtra_layer)

@@ -68,18 +68,30 @@ class ResBlock(nn.Module):
         raise _lib.TactileSRHipError("ResBlock is executed by TactileSR's fused HIP engine, not standalone")
 
 
-CONV_IMPLS = {"f32": 0, "bf16x6": 3, "bf16x3": 2, "bf16": 1}   # name -> bf16 split planes (0 = fp32 MFMA)
+CONV_IMPLS = {"f32": 0, "bf16x6": 3, "bf16x3": 2, "bf16": 1, "fp16x3": -2}   # name -> split planes (0 = fp32 MFMA,
+#                                                                              negative = fp16 planes with scaling)
 
 
 class _PackedConv:
     """Device-side constants of one conv launch: packed weight, folded scale/shift."""
-    __slots__ = ("w", "scale", "shift", "cin", "cout", "ks", "nsplit")
+    __slots__ = ("w", "scale", "shift", "cin", "cout", "ks", "nsplit", "w_inv_scale")
 
     def __init__(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], nsplit: int = 0):
         w = conv.weight.detach().float().contiguous()
         self.cout, self.cin, self.ks = w.shape[0], w.shape[1], w.shape[2]
         self.nsplit = nsplit
-        if nsplit == 0:
+        self.w_inv_scale = 1.0
+        if nsplit == -2:
+            # fp16 planes: power-of-two weight scale so that max|w|*wscale lies in [2^13, 2^14)
+            import math
+            m = float(w.abs().max())
+            wscale = 2.0 ** (13 - math.floor(math.log2(m))) if m > 0 else 1.0
+            self.w_inv_scale = 1.0 / wscale
+            n = _lib.load().tsr_conv_weight_bf16s_elems(self.cout, self.cin, self.ks, 2)
+            self.w = torch.empty(n, dtype=torch.float16, device=w.device)
+            call("tsr_pack_conv_weight_f16s", ptr(w), ptr(self.w), _I(self.cout), _I(self.cin), _I(self.ks),
+                 _lib.c_float(wscale), stream())
+        elif nsplit == 0:
             self.w = torch.empty_like(w)
             call("tsr_pack_conv_weight", ptr(w), ptr(self.w), _I(self.cout), _I(self.cin), _I(self.ks), stream())
         else:
@@ -141,10 +153,13 @@ class TactileSR(nn.Module):
         self._plan_key = None
         self._profile = None
         self._train_engine = None
-        # eval-mode conv arithmetic: "f32" = fp32 MFMA (exact fp32 fma chain); "bf16x6" = 3-way bf16 split, six
-        # bf16 MFMA products per K step (fp32-equivalent, faster); "bf16x3" / "bf16" = reduced precision
+        # eval-mode conv arithmetic (all accumulate in fp32):
+        #   "fp16x3" (default) 2 power-of-two-scaled fp16 planes, 3 f16-MFMA products: fp32-grade at 3/16 the fp32-MFMA cost
+        #   "bf16x6"           3 bf16 planes, 6 bf16-MFMA products: fp32-equivalent, no scaling needed
+        #   "f32"              fp32 MFMA (exact fp32 fma chain)
+        #   "bf16x3" / "bf16"  reduced precision (never the parity path)
         import os
-        self.conv_impl = os.environ.get("TSR_CONV_IMPL", "f32")
+        self.conv_impl = os.environ.get("TSR_CONV_IMPL", "fp16x3")
         assert self.conv_impl in CONV_IMPLS, self.conv_impl
         self.max_images_per_pass = 4096   # workspace bound: ~6.6 MB of CB16 activations per image
 
@@ -189,12 +204,17 @@ class TactileSR(nn.Module):
         return self._plan
 
     def _conv(self, pc: _PackedConv, src, s_ctot, s_coff, dst, d_ctot, d_coff, relu, B, H, W, res=None, r_ctot=0,
-              r_coff=0):
+              r_coff=0, amax_in=None, amax_out=None):
         prof = self._profile
         if prof is not None:     # bench.py: HIP-event bracket on the launch stream, per kernel instantiation
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if pc.nsplit == 0:
+        if pc.nsplit == -2:
+            call("tsr_conv2d_fwd_f16s", ptr(src), _I(s_ctot), _I(s_coff), _I(pc.cin), ptr(pc.w), _I(pc.cout),
+                 _I(pc.ks), _lib.c_float(pc.w_inv_scale), ptr(amax_in), ptr(amax_out), ptr(pc.scale), ptr(pc.shift),
+                 ptr(res), _I(r_ctot), _I(r_coff), ptr(dst), _I(d_ctot), _I(d_coff), _I(1 if relu else 0),
+                 _I(B), _I(H), _I(W), stream())
+        elif pc.nsplit == 0:
             call("tsr_conv2d_fwd", ptr(src), _I(s_ctot), _I(s_coff), _I(pc.cin), ptr(pc.w), _I(pc.cout), _I(pc.ks),
                  ptr(pc.scale), ptr(pc.shift), ptr(res), _I(r_ctot), _I(r_coff),
                  ptr(dst), _I(d_ctot), _I(d_coff), _I(1 if relu else 0), _I(B), _I(H), _I(W), stream())
@@ -219,18 +239,36 @@ class TactileSR(nn.Module):
             return torch.empty(B * c * HW, dtype=torch.float32, device=dev)
 
         ctot = x.shape[1]
+        # fp16-split path: one device scalar per logical activation tensor holds max|x| (atomic max by the
+        # producer's epilogue); the consumer derives its power-of-two input scale from it
+        f16 = CONV_IMPLS[self.conv_impl] == -2
+        amax = torch.zeros(16 + 8 * len(plan["msrb"]) + 4 * len(plan["res"]) + T, dtype=torch.float32,
+                           device=dev) if f16 else None
+        nslot = [0]
+
+        def slot():
+            if amax is None:
+                return None
+            i = nslot[0]
+            nslot[0] += 1
+            return amax[i:i + 1]
+
         stemA, catT = buf(64), buf(64 * T)
+        s_catT = slot()
         for t, (w1, s1, sh1, pc2) in enumerate(plan["stems"]):
+            s_stem = slot()
             call("tsr_stem_fwd", ptr(x), _I(ctot), _I(A * t), _I(A), _I(hin), _I(win), _I(sf), ptr(w1), ptr(s1),
-                 ptr(sh1), ptr(stemA), _I(64), _I(0), _I(1), _I(B), stream())
-            self._conv(pc2, stemA, 64, 0, catT, 64 * T, 64 * t, True, B, H, W)
+                 ptr(sh1), ptr(stemA), _I(64), _I(0), _I(1), _I(B), ptr(s_stem), stream())
+            self._conv(pc2, stemA, 64, 0, catT, 64 * T, 64 * t, True, B, H, W, amax_in=s_stem, amax_out=s_catT)
         xa, xb = buf(64), buf(64)
-        self._conv(plan["fuse"], catT, 64 * T, 0, xa, 64, 0, True, B, H, W)
+        s_x = slot()
+        self._conv(plan["fuse"], catT, 64 * T, 0, xa, 64, 0, True, B, H, W, amax_in=s_catT, amax_out=s_x)
         if stages is not None:
             stages["stems"] = (catT, 64 * T)
             stages["fuse"] = (xa.clone(), 64)
         del stemA
         hcat = buf(128)
+        s_hcat = slot()
         cat1, cat2 = buf(128), buf(256)
         n_msrb = len(plan["msrb"])
         cur = xa
@@ -239,23 +277,28 @@ class TactileSR(nn.Module):
             call("tsr_nchw_to_cb16", ptr(xb), ptr(hcat), _I(B), _I(64), _I(HW), _I(128), _I(64), stream())
         for i, (c31, c51, c32, c52, conf) in enumerate(plan["msrb"]):
             last = i == n_msrb - 1
-            self._conv(c31, cur, 64, 0, cat1, 128, 0, True, B, H, W)
-            self._conv(c51, cur, 64, 0, cat1, 128, 64, True, B, H, W)
-            self._conv(c32, cat1, 128, 0, cat2, 256, 0, True, B, H, W)
-            self._conv(c52, cat1, 128, 0, cat2, 256, 128, True, B, H, W)
+            s_c1, s_c2 = slot(), slot()
+            self._conv(c31, cur, 64, 0, cat1, 128, 0, True, B, H, W, amax_in=s_x, amax_out=s_c1)
+            self._conv(c51, cur, 64, 0, cat1, 128, 64, True, B, H, W, amax_in=s_x, amax_out=s_c1)
+            self._conv(c32, cat1, 128, 0, cat2, 256, 0, True, B, H, W, amax_in=s_c1, amax_out=s_c2)
+            self._conv(c52, cat1, 128, 0, cat2, 256, 128, True, B, H, W, amax_in=s_c1, amax_out=s_c2)
             nxt = xb if cur is xa else xa
             if last:   # pattern feature lands in channels [64,128) of the head input (cat: force first)
-                self._conv(conf, cat2, 256, 0, hcat, 128, 64, True, B, H, W, res=cur, r_ctot=64, r_coff=0)
+                self._conv(conf, cat2, 256, 0, hcat, 128, 64, True, B, H, W, res=cur, r_ctot=64, r_coff=0,
+                           amax_in=s_c2, amax_out=s_hcat)
             else:
-                self._conv(conf, cat2, 256, 0, nxt, 64, 0, True, B, H, W, res=cur, r_ctot=64, r_coff=0)
+                s_x = slot()
+                self._conv(conf, cat2, 256, 0, nxt, 64, 0, True, B, H, W, res=cur, r_ctot=64, r_coff=0,
+                           amax_in=s_c2, amax_out=s_x)
                 cur = nxt
             if stages is not None:
                 stages[f"msrb{i}"] = (hcat.clone(), 128, 64) if last else (cur.clone(), 64, 0)
         del cat1, cat2
         # force branch
         f0, f1 = buf(64), buf(64)
+        s_f = slot()
         call("tsr_stem_fwd", ptr(x), _I(ctot), _I(0), _I(A), _I(hin), _I(win), _I(sf), ptr(plan["force_w"]),
-             ptr(None), ptr(None), ptr(f0), _I(64), _I(0), _I(1), _I(B), stream())
+             ptr(None), ptr(None), ptr(f0), _I(64), _I(0), _I(1), _I(B), ptr(s_f), stream())
         if stages is not None:
             stages["force_in"] = (f0.clone(), 64, 0)
         n_res = len(plan["res"])
@@ -266,15 +309,19 @@ class TactileSR(nn.Module):
         curf = f0
         for i, (c1, c2) in enumerate(plan["res"]):
             last = i == n_res - 1
-            self._conv(c1, curf, 64, 0, f1, 64, 0, True, B, H, W)
+            s_f1 = slot()
+            self._conv(c1, curf, 64, 0, f1, 64, 0, True, B, H, W, amax_in=s_f, amax_out=s_f1)
             if last:
-                self._conv(c2, f1, 64, 0, hcat, 128, 0, True, B, H, W, res=curf, r_ctot=64, r_coff=0)
+                self._conv(c2, f1, 64, 0, hcat, 128, 0, True, B, H, W, res=curf, r_ctot=64, r_coff=0,
+                           amax_in=s_f1, amax_out=s_hcat)
             else:
                 nxt = f2 if curf is f0 else f0
-                self._conv(c2, f1, 64, 0, nxt, 64, 0, True, B, H, W, res=curf, r_ctot=64, r_coff=0)
+                s_f = slot()
+                self._conv(c2, f1, 64, 0, nxt, 64, 0, True, B, H, W, res=curf, r_ctot=64, r_coff=0,
+                           amax_in=s_f1, amax_out=s_f)
                 curf = nxt
         h0 = buf(128)
-        self._conv(plan["head0"], hcat, 128, 0, h0, 128, 0, True, B, H, W)
+        self._conv(plan["head0"], hcat, 128, 0, h0, 128, 0, True, B, H, W, amax_in=s_hcat, amax_out=None)
         if stages is not None:
             stages["force"] = (hcat, 128, 0)
             stages["head0"] = (h0, 128, 0)

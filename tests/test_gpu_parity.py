@@ -96,7 +96,7 @@ def test_stem_fwd(T, sf, B, coff, ctot):
     out = torch.zeros(B * 64 * H * W, device="cuda")
     lr_d, w_d, sc_d, sh_d = lr.cuda(), w.cuda(), scale.cuda(), shift.cuda()   # keep alive across the launch
     call("tsr_stem_fwd", ptr(lr_d), I(ctot), I(coff), I(3), I(4), I(4), I(sf), ptr(w_d),
-         ptr(sc_d), ptr(sh_d), ptr(out), I(64), I(0), I(1), I(B), stream())
+         ptr(sc_d), ptr(sh_d), ptr(out), I(64), I(0), I(1), I(B), ptr(None), stream())
     assert relerr(T.from_cb16(out, B, 64, H, W), ref) < TOL
 
 
@@ -122,15 +122,18 @@ def probe(t):
     return t[:, ::cs, ::3, ::3].contiguous()
 
 
+@pytest.mark.parametrize("impl", ["fp16x3", "f32"])
 @pytest.mark.parametrize("tag", ["t1", "t1_l2", "t7", "sf25t8"])
-def test_model_eval_forward_vs_reference_golden(T, golden, tag):
-    """HIP eval forward vs outputs of the reference itself (tests/golden/eval.npz)."""
+def test_model_eval_forward_vs_reference_golden(T, golden, tag, impl):
+    """HIP eval forward vs outputs of the reference itself (tests/golden/eval.npz), per-stage and final, for the
+    default conv arithmetic (fp16x3) and the strict fp32-MFMA path."""
     g = golden("eval")
     cfg = GOLD_CFG[tag]
     sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), int(g[f"{tag}/seed"]))
     m = T.TactileSR(**cfg)
     m.load_state_dict(sd, strict=True)
     m = m.cuda().eval()
+    m.conv_impl = impl
     LR = torch.from_numpy(g[f"{tag}/LR"]).cuda()
     y, stages = m.forward_with_stages(LR)
     for name, t in stages.items():
@@ -149,7 +152,7 @@ def test_model_eval_forward_vs_reference_golden(T, golden, tag):
     else:
         e32 = relerr(y, torch.from_numpy(g[f"{tag}/out"]))
         e64 = relerr(y, torch.from_numpy(g[f"{tag}/out64"]))
-    print(f"[parity] {tag}: hip-vs-ref32 {e32:.2e}  hip-vs-f64 {e64:.2e}  ref32-vs-f64 {yard:.2e}")
+    print(f"[parity {impl}] {tag}: hip-vs-ref32 {e32:.2e}  hip-vs-f64 {e64:.2e}  ref32-vs-f64 {yard:.2e}")
     assert e32 < tol and e64 < tol
     y2 = m(LR)
     assert torch.equal(y, y2)
@@ -230,29 +233,31 @@ def test_conv2d_fwd_bf16_split(T, ks, cin, cout, B, H, W, nsplit, tol):
     assert err < tol
 
 
-@pytest.mark.parametrize("tag", ["t1", "t7"])
-def test_model_eval_forward_bf16x6_vs_reference_golden(T, golden, tag):
-    """Whole eval forward with the split-bf16 (six-product) convolutions: same 1e-5 bar as the fp32 MFMA path."""
+@pytest.mark.parametrize("impl", ["bf16x6", "fp16x3"])
+@pytest.mark.parametrize("tag", ["t1", "t7", "t1_l2"])
+def test_model_eval_forward_bf16x6_vs_reference_golden(T, golden, tag, impl):
+    """Whole eval forward with the split-operand convolutions (bf16x6: 3 bf16 planes / 6 products; fp16x3: 2 scaled
+    fp16 planes / 3 products): same 1e-5 bar as the fp32 MFMA path."""
     g = golden("eval")
     cfg = GOLD_CFG[tag]
     sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), int(g[f"{tag}/seed"]))
     m = T.TactileSR(**cfg)
     m.load_state_dict(sd, strict=True)
     m = m.cuda().eval()
-    m.conv_impl = "bf16x6"
+    m.conv_impl = impl
     LR = torch.from_numpy(g[f"{tag}/LR"]).cuda()
     y = m(LR)
     yard = float(g[f"{tag}/ref32_vs_f64"])
     e32 = relerr(y, torch.from_numpy(g[f"{tag}/out"]))
     e64 = relerr(y, torch.from_numpy(g[f"{tag}/out64"]))
-    print(f"[parity bf16x6] {tag}: vs-ref32 {e32:.2e}  vs-f64 {e64:.2e}  ref32-vs-f64 {yard:.2e}")
+    print(f"[parity {impl}] {tag}: vs-ref32 {e32:.2e}  vs-f64 {e64:.2e}  ref32-vs-f64 {yard:.2e}")
     assert e32 < max(TOL, 4 * yard) and e64 < max(TOL, 4 * yard)
     m.conv_impl = "f32"
     y32 = m(LR)                      # two fp32-grade evaluations: within the sum of their errors to fp64
     assert relerr(y, y32) < 2 * max(TOL, 4 * yard)
 
 
-@pytest.mark.parametrize("impl", ["bf16x6", "f32"])
+@pytest.mark.parametrize("impl", ["bf16x6", "f32", "fp16x3"])
 def test_full_size_batch4096_tiling_invariance(T, impl):
     """BASELINE configs[1] size (B=4096): the batch is 32 distinct frames tiled 128x.  Samples are independent in
     eval mode, so every replica must be bit-identical to the first, and the 32 distinct outputs must match the
@@ -272,3 +277,53 @@ def test_full_size_batch4096_tiling_invariance(T, impl):
     with torch.no_grad():
         ref = O.tactilesr_forward(sd, base)
     assert relerr(y[0], ref) < TOL
+
+
+@pytest.mark.parametrize("ks,cin,cout,B,H,W", BF16S_CASES)
+@pytest.mark.parametrize("outlier", [False, True])
+def test_conv2d_fwd_fp16_split(T, ks, cin, cout, B, H, W, outlier):
+    """fp16 two-plane split conv (3 products) with power-of-two operand scaling: fp32-grade single-layer accuracy,
+    also with a 1e4 outlier and 1e-6 values in the same tensor (dynamic range handling), and the out_amax scalar it
+    publishes for its consumer."""
+    import math
+    from tactilesr_amd._lib import call, ptr, stream, load, c_int as I, c_float as Fl
+    g = torch.Generator().manual_seed(ks * 100 + cin + B + 5)
+    x = torch.randn(B, cin, H, W, generator=g) * 3
+    if outlier:
+        x[0, 0, 0, 0] = 1e4
+        x[0, 1, 1, 1] = 1e-6
+    w = torch.randn(cout, cin, ks, ks, generator=g) * (2.0 / (cout * ks * ks)) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    res = torch.randn(B, cout, H, W, generator=g)
+    ref64 = F.relu(F.conv2d(x.double(), w.double(), padding=ks // 2) * scale.double().view(1, -1, 1, 1)
+                   + shift.double().view(1, -1, 1, 1) + res.double())
+    ref32 = F.relu(F.conv2d(x, w, padding=ks // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+    xin, rbuf = T.to_cb16(x.cuda()), T.to_cb16(res.cuda())
+    wd = w.cuda().contiguous()
+    wscale = 2.0 ** (13 - math.floor(math.log2(float(w.abs().max()))))
+    wp = torch.empty(load().tsr_conv_weight_bf16s_elems(cout, cin, ks, 2), dtype=torch.float16, device="cuda")
+    call("tsr_pack_conv_weight_f16s", ptr(wd), ptr(wp), I(cout), I(cin), I(ks), Fl(wscale), stream())
+    amax_in = x.abs().max().reshape(1).cuda()
+    amax_out = torch.zeros(1, device="cuda")
+    out = torch.empty(B * cout * H * W, device="cuda")
+    sc, sh = scale.cuda(), shift.cuda()
+    call("tsr_conv2d_fwd_f16s", ptr(xin), I(cin), I(0), I(cin), ptr(wp), I(cout), I(ks), Fl(1.0 / wscale), ptr(amax_in),
+         ptr(amax_out), ptr(sc), ptr(sh), ptr(rbuf), I(cout), I(0), ptr(out), I(cout), I(0), I(1), I(B), I(H), I(W),
+         stream())
+    got = T.from_cb16(out, B, cout, H, W)
+    err = relerr(got, ref64)
+    print(f"[fp16x3] k{ks} {cin}->{cout} outlier={outlier}: err vs f64 {err:.2e}  (torch fp32 CPU vs f64 {relerr(ref32, ref64):.2e})")
+    assert err < TOL
+    assert abs(float(amax_out) - float(got.abs().max())) == 0.0
+
+
+def test_stem_publishes_amax(T):
+    from tactilesr_amd._lib import call, ptr, stream, c_int as I
+    g = torch.Generator().manual_seed(3)
+    lr = (torch.rand(3, 3, 4, 4, generator=g) * 8).cuda()
+    w = (torch.randn(64, 3, 3, 3, generator=g) * 0.2).cuda()
+    out = torch.zeros(3 * 64 * 1600, device="cuda")
+    amax = torch.zeros(1, device="cuda")
+    call("tsr_stem_fwd", ptr(lr), I(3), I(0), I(3), I(4), I(4), I(10), ptr(w), ptr(None), ptr(None), ptr(out), I(64),
+         I(0), I(1), I(3), ptr(amax), stream())
+    assert float(amax) == float(out.max()) > 0
