@@ -230,14 +230,15 @@ def main_train(args):
         dt = float(t.item())
     if rank == 0:
         value = B * world * args.steps / dt
-        impl = os.environ.get("TSR_TRAIN_IMPL", "bf16x6")
-        nprod, peak = (6, PEAK_BF16_MFMA) if impl == "bf16x6" else (1, PEAK_F32_MFMA)
+        impl = os.environ.get("TSR_TRAIN_IMPL", "fp16x3")
+        nprod, peak = {"bf16x6": (6, PEAK_BF16_MFMA), "fp16x3": (3, PEAK_BF16_MFMA)}.get(impl, (1, PEAK_F32_MFMA))
         train_flop = 3 * FWD_FLOP_PER_SAMPLE - 2 * 5_529_600 * 2
         print(json.dumps({
             "metric": "SR train samples/sec (4x4->40x40)", "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 as 3 bf16 planes x 6 MFMA products, fp32 accumulate (fp32-equivalent)" if nprod == 6 else "f32"),
+            "dtype": {6: "f32 as 3 bf16 planes x 6 MFMA products, fp32 accumulate (fp32-equivalent)",
+                      3: "f32 as 2 scaled fp16 planes x 3 MFMA products, fp32 accumulate (fp32-grade)"}.get(nprod, "f32"),
             "data": "synthetic",
             "config": {"workload": "TactileSR train step (fwd+bwd+Adam L2), fp32 params/activations, batch/GPU=%d (BASELINE configs[3] shape)" % B,
                        "batch_per_gpu": B, "parallelism": f"dp{world}", "grad_allreduce_MB": 18.33, "conv_impl": impl},

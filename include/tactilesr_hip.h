@@ -133,7 +133,11 @@ typedef struct tsr_conv_desc {
   const float* bn_a; const float* bn_b;
   float* slab; float* slab_cnt;
   int nsplit;   /* 0: fp32 MFMA, w_packed from tsr_pack_conv_weight[_dgrad]; 1..3: split-bf16 MFMA (3 = fp32-equivalent),
-                   w_packed from tsr_pack_conv_weight[_dgrad]_bf16s */
+                   w_packed from tsr_pack_conv_weight[_dgrad]_bf16s; -2: fp16 two-plane split ("fp16x3"), w_packed from
+                   tsr_pack_conv_weight[_dgrad]_f16s, needs in_amax and w_inv_scale below */
+  const float* in_amax;   /* device scalar max|in| (of the raw tensor; a fused input transform is bounded in-kernel) */
+  float w_inv_scale;      /* 1 / wscale used at pack time */
+  float* out_amax;        /* device scalar receiving max|out| (atomic max), any mode; NULL = off */
 } tsr_conv_desc;
 
 int tsr_conv2d_ex(const tsr_conv_desc* desc, void* stream);
@@ -147,6 +151,9 @@ int tsr_pack_conv_weight_dgrad(const float* w_oihw, float* w_packed, int cout, i
 int tsr_pack_conv_weight_dgrad_bf16s(const float* w_oihw, void* w_packed, int cout, int cin, int ks,
                                      int ci0, int nprime, int nsplit, void* stream);
 
+int tsr_pack_conv_weight_dgrad_f16s(const float* w_oihw, void* w_packed, int cout, int cin, int ks,
+                                    int ci0, int nprime, float wscale, void* stream);
+
 /* Weight (and bias) gradient partials: slab[s][cout][cin][k][k] (s < nsplit, OIHW) with
  * dW = sum_s slab[s] (tsr_reduce_splits), from a = conv input (CB16, optional relu(a*scale+shift)
  * transform) and dz = gradient w.r.t. the conv output (CB16).  cin, cout multiples of 64.
@@ -155,10 +162,13 @@ int tsr_conv2d_wgrad(const float* a, int a_ctot, int a_coff, int cin,
                      const float* a_scale, const float* a_shift,
                      const float* dz, int dz_ctot, int dz_coff, int cout, int ks,
                      float* slab, float* bias_slab, int nsplit, int B, int H, int W, void* stream);
-/* Same on the bf16 matrix cores with 3-way split operands (planes must be 3: fp32-equivalent). */
+/* Same on the 16-bit matrix cores with split operands: planes = 3 -> three bf16 planes, six products
+ * (fp32-equivalent; a_amax/dz_amax unused); planes = -2 -> two power-of-two-scaled fp16 planes, three products,
+ * scales derived from the device scalars a_amax = max|a| (raw tensor) and dz_amax = max|dz|. */
 int tsr_conv2d_wgrad_bf16s(const float* a, int a_ctot, int a_coff, int cin,
                            const float* a_scale, const float* a_shift,
                            const float* dz, int dz_ctot, int dz_coff, int cout, int ks, int planes,
+                           const float* a_amax, const float* dz_amax,
                            float* slab, float* bias_slab, int nsplit, int B, int H, int W, void* stream);
 int tsr_reduce_splits(const float* slab, float* out, long long n, int nsplit, float alpha, void* stream);
 
@@ -182,7 +192,8 @@ int tsr_bn_bwd_finalize(const float* slab, int entries, int C, double N, const f
                         const float* xhat_a, const float* xhat_b, float* dgamma, float* dbeta,
                         float* c1, float* c2, float* c3, double* work, void* stream);
 int tsr_bn_bwd_apply(float* g, int g_ctot, int g_coff, const float* z, int z_ctot, int z_coff,
-                     const float* c1, const float* c2, const float* c3, int C, int B, int HW, void* stream);
+                     const float* c1, const float* c2, const float* c3, int C, int B, int HW,
+                     float* out_amax /* optional: max|g| after the update */, void* stream);
 
 /* Backward of tsr_stem_fwd's conv weight: slab[s][64][3][3][3] partials (taxels carry no gradient). */
 int tsr_stem_wgrad(const float* lr, int lr_ctot, int lr_coff, int hin, int win, int sf,
@@ -191,7 +202,7 @@ int tsr_stem_wgrad(const float* lr, int lr_ctot, int lr_coff, int hin, int win, 
  * wslab[s][cin][3][3]. */
 int tsr_head_bwd(const float* dout, const float* out, const float* h0, int h_ctot, int cin,
                  const float* w_oihw, float* dz_h0, int dz_ctot, float* wslab, int nsplit,
-                 int B, int H, int W, void* stream);
+                 int B, int H, int W, float* dz_amax /* optional: max|dz_h0| */, void* stream);
 
 /* HR.float()/HR_scale_num + F.interpolate(size=(H,W), bilinear) (train/tactileSR_train.py:44-45). */
 int tsr_target_prep(const float* hr_raw, float* out, float inv_scale, int B, int hin, int win, int H, int W,

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TSR_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libtactilesr_hip.so")   # override: kernel A/B experiments
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _P, _I, _F, _L = c_void_p, c_int, c_float, c_longlong
 
@@ -33,16 +33,17 @@ SIGNATURES = {
     "tsr_conv2d_slab_entries": [_I, _I, _I],
     "tsr_pack_conv_weight_dgrad": [_P, _P, _I, _I, _I, _I, _I, _P],
     "tsr_pack_conv_weight_dgrad_bf16s": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "tsr_pack_conv_weight_dgrad_f16s": [_P, _P, _I, _I, _I, _I, _I, _F, _P],
     "tsr_conv2d_wgrad": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P],
-    "tsr_conv2d_wgrad_bf16s": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P],
+    "tsr_conv2d_wgrad_bf16s": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "tsr_reduce_splits": [_P, _P, _L, _I, _F, _P],
     "tsr_bn_stats_finalize": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P],
     "tsr_cb16_stats_entries": [_I, _I],
     "tsr_cb16_stats": [_P, _I, _I, _I, _I, _P, _P, _P],
     "tsr_bn_bwd_finalize": [_P, _I, _I, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "tsr_bn_bwd_apply": [_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P],
+    "tsr_bn_bwd_apply": [_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P],
     "tsr_stem_wgrad": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P],
-    "tsr_head_bwd": [_P, _P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P],
+    "tsr_head_bwd": [_P, _P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P],
     "tsr_target_prep": [_P, _P, _F, _I, _I, _I, _I, _I, _P],
     "tsr_mse_fwd_bwd": [_P, _P, _P, _P, _L, _F, _P, _P],
     "tsr_adam_l2_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],

@@ -68,11 +68,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
         for (int r = 0; r < 16; ++r) {
           const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
           const int gy = y0 + 4 * mb + (m >> 3), gx = x0 + (m & 7);
+          acc[mb][nb][r] *= accmul;
           if (img_ok && gy < a.H && gx < a.W) {
             const float v = acc[mb][nb][r];
             obase[(size_t)(gy * a.W + gx) * 16] = v;
             cnt += 1.f;
             sum += v;
+            amax = fmaxf(amax, fabsf(v));
           }
         }
       }
@@ -121,11 +123,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
           const int gy = y0 + 4 * mb + (m >> 3), gx = x0 + (m & 7);
           if (img_ok && gy < a.H && gx < a.W) {
             const size_t po = (size_t)(gy * a.W + gx) * 16;
-            float v = acc[mb][nb][r] * sc;
+            float v = (acc[mb][nb][r] * accmul) * sc;
             if (rbase) v += rbase[po];
             const float mv = mbase[po];
             if (!(fmaf(mv, msc, msh) > 0.f)) v = 0.f;
             obase[po] = v;
+            amax = fmaxf(amax, fabsf(v));
             s1 += v;
             s2 = fmaf(v, fmaf(mv, ba, bb), s2);
           }

@@ -104,7 +104,26 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
   // the epilogue together with the pack-time weight scale
   float sx = 1.f, accmul = 1.f;
   if (F16) {
-    const float m = a.in_amax ? *a.in_amax : 0.f;
+    float m = a.in_amax ? *a.in_amax : 0.f;
+    if (EXT && a.in_scale) {
+      // the input is virtual, relu(x*s_c + t_c): bound its magnitude by max|x| * max|s_c| + max|t_c|
+      __shared__ float bnd[8];
+      float ms = 0.f, mt = 0.f;
+      for (int c = threadIdx.x; c < a.cin; c += 256) {
+        ms = fmaxf(ms, fabsf(a.in_scale[c]));
+        mt = fmaxf(mt, fabsf(a.in_shift[c]));
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        ms = fmaxf(ms, __shfl_xor(ms, o));
+        mt = fmaxf(mt, __shfl_xor(mt, o));
+      }
+      if ((threadIdx.x & 63) == 0) { bnd[(threadIdx.x >> 6) * 2] = ms; bnd[(threadIdx.x >> 6) * 2 + 1] = mt; }
+      __syncthreads();
+      ms = fmaxf(fmaxf(bnd[0], bnd[2]), fmaxf(bnd[4], bnd[6]));
+      mt = fmaxf(fmaxf(bnd[1], bnd[3]), fmaxf(bnd[5], bnd[7]));
+      m = m * ms + mt;
+    }
     if (m > 0.f) {
       int e = (int)((__float_as_uint(m) >> 23) & 0xFF) - 127;
       int be = 13 - e + 127;
@@ -404,8 +423,22 @@ static int dispatch_bf16s(const ConvArgs& a, int cout, int ks, hipStream_t st) {
   return TSR_ERR_ARG;
 }
 
-// tsr_conv2d_ex with nsplit > 0 lands here (argument checks were done by the caller)
+extern "C" int tsr_pack_conv_weight_dgrad_f16s(const float* w_oihw, void* w_packed, int cout, int cin, int ks,
+                                               int ci0, int nprime, float wscale, void* stream) {
+  if (!w_oihw || !w_packed || (cout & 15) || (nprime != 64 && nprime != 128) || ci0 < 0 || ci0 + nprime > cin ||
+      (ks != 1 && ks != 3 && ks != 5) || !(wscale > 0.f))
+    return TSR_ERR_ARG;
+  const int tps = taps_per_step(ks, nprime, 2);
+  const size_t total = (size_t)nprime * cout * (((ks * ks + tps - 1) / tps) * tps);
+  const int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel<true>, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
+                     (hipStream_t)stream, w_oihw, (_Float16*)w_packed, nprime, cout, ks, 2, tps, ci0, cin, wscale);
+  return tsr_check_launch();
+}
+
+// tsr_conv2d_ex with nsplit != 0 lands here (argument checks were done by the caller)
 int tsr_conv2d_ex_bf16s(const ConvArgs& a, int cout, int ks, int nsplit, hipStream_t st) {
+  if (nsplit == -2) return dispatch_bf16s<2, true, true>(a, cout, ks, st);      // fp16x3
   if (nsplit == 3) return dispatch_bf16s<3, true>(a, cout, ks, st);
   if (nsplit == 2) return dispatch_bf16s<2, true>(a, cout, ks, st);
   if (nsplit == 1) return dispatch_bf16s<1, true>(a, cout, ks, st);

@@ -126,7 +126,9 @@ extern "C" int tsr_bn_bwd_finalize(const float* slab, int entries, int C, double
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g, int g_ctot, int g_coff,
                                                            const float* __restrict__ z, int z_ctot, int z_coff,
                                                            const float* __restrict__ c1, const float* __restrict__ c2,
-                                                           const float* __restrict__ c3, int C, int HW, size_t total4) {
+                                                           const float* __restrict__ c3, int C, int HW, size_t total4,
+                                                           float* __restrict__ out_amax) {
+  float amax = 0.f;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
     const int q = i & 3;
     size_t r = i >> 2;
@@ -139,21 +141,29 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g
     const f32x4 k1 = *(const f32x4*)(c1 + c), k2 = *(const f32x4*)(c2 + c), k3 = *(const f32x4*)(c3 + c);
     f32x4 gv = *gp;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) gv[j] = fmaf(k1[j], gv[j], fmaf(k2[j], zv[j], k3[j]));
+    for (int j = 0; j < 4; ++j) {
+      gv[j] = fmaf(k1[j], gv[j], fmaf(k2[j], zv[j], k3[j]));
+      amax = fmaxf(amax, fabsf(gv[j]));
+    }
     *gp = gv;
+  }
+  if (out_amax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)out_amax, __float_as_uint(amax));
   }
 }
 
 extern "C" int tsr_bn_bwd_apply(float* g, int g_ctot, int g_coff, const float* z, int z_ctot, int z_coff,
                                 const float* c1, const float* c2, const float* c3, int C, int B, int HW,
-                                void* stream) {
+                                float* out_amax, void* stream) {
   if (!g || !z || !c1 || !c2 || !c3 || (C & 15) || (g_ctot & 15) || (g_coff & 15) || (z_ctot & 15) || (z_coff & 15) ||
       g_coff + C > g_ctot || z_coff + C > z_ctot)
     return TSR_ERR_ARG;
   const size_t total4 = (size_t)B * C * HW / 4;
   const size_t grid = (total4 + 255) / 256;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid > 16384 ? 16384 : (int)grid), dim3(256), 0, (hipStream_t)stream,
-                     g, g_ctot, g_coff, z, z_ctot, z_coff, c1, c2, c3, C, HW, total4);
+                     g, g_ctot, g_coff, z, z_ctot, z_coff, c1, c2, c3, C, HW, total4, out_amax);
   return tsr_check_launch();
 }
 
@@ -256,7 +266,7 @@ extern "C" int tsr_stem_wgrad(const float* lr, int lr_ctot, int lr_coff, int hin
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                        const float* __restrict__ h0, int h_ctot, int cin,
                                                        const float* __restrict__ w, float* __restrict__ dz,
-                                                       int dz_ctot, int B, int H, int W) {
+                                                       int dz_ctot, int B, int H, int W, float* __restrict__ out_amax) {
   extern __shared__ __attribute__((aligned(16))) float wl[];   // [9][cin]
   const int tid = threadIdx.x;
   for (int i = tid; i < 9 * cin; i += 256) {
@@ -266,7 +276,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   __syncthreads();
   const int HW = H * W, b = blockIdx.y, nblk = cin >> 4;
   const int item = blockIdx.x * 256 + tid;        // (pixel, channel block)
-  if (item >= HW * nblk) return;
+  float amax = 0.f;
+  if (item < HW * nblk) {
   const int blk = item / HW, q = item - blk * HW;
   const int y = q / W, x = q - y * W;
   float dp[9];
@@ -295,8 +306,15 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 #pragma unroll
       for (int t = 0; t < 9; ++t) s = fmaf(dp[t], wl[t * cin + c], s);
       r[j] = hv[j] > 0.f ? s : 0.f;
+      amax = fmaxf(amax, fabsf(r[j]));
     }
     dp4[qd] = r;
+  }
+  }
+  if (out_amax) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if ((tid & 63) == 0) atomicMax((unsigned int*)out_amax, __float_as_uint(amax));
   }
 }
 
@@ -352,14 +370,14 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
 
 extern "C" int tsr_head_bwd(const float* dout, const float* out, const float* h0, int h_ctot, int cin,
                             const float* w_oihw, float* dz_h0, int dz_ctot, float* wslab, int nsplit,
-                            int B, int H, int W, void* stream) {
+                            int B, int H, int W, float* dz_amax, void* stream) {
   if (!dout || !out || !h0 || !w_oihw || !dz_h0 || !wslab || nsplit <= 0 || (cin & 15) || cin > 256 || cin > h_ctot ||
       cin > dz_ctot || (h_ctot & 15) || (dz_ctot & 15))
     return TSR_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int items = H * W * (cin >> 4);
   hipLaunchKernelGGL(head_bwd_kernel, dim3((items + 255) / 256, B), dim3(256), (size_t)9 * cin * 4, st, dout, out,
-                     h0, h_ctot, cin, w_oihw, dz_h0, dz_ctot, B, H, W);
+                     h0, h_ctot, cin, w_oihw, dz_h0, dz_ctot, B, H, W, dz_amax);
   size_t fl = (size_t)(H + 2) * (W + 2);
   const size_t redf = (size_t)(256 / cin) * cin * 9;
   if (fl < redf) fl = redf;

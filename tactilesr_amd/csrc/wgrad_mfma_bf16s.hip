@@ -10,6 +10,26 @@
 #include "tsr_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <bool F16> struct WPlane;
+template <> struct WPlane<false> {
+  typedef __bf16 T; typedef bf16x8 V8;
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct WPlane<true> {
+  typedef _Float16 T; typedef f16x8 V8;
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+// power-of-two scale that brings m into [2^13, 2^14) (1 for m == 0)
+__device__ __forceinline__ float pow2_scale_to_2p13(float m) {
+  if (!(m > 0.f)) return 1.f;
+  int e = (int)((__float_as_uint(m) >> 23) & 0xFF) - 127;
+  int be = 13 - e + 127;
+  be = be < 1 ? 1 : (be > 254 ? 254 : be);
+  return __uint_as_float((unsigned)be << 23);
+}
 
 struct WgradBArgs {
   const float* a;  int a_ctot; int a_coff; int cin;
@@ -18,27 +38,31 @@ struct WgradBArgs {
   float* slab; float* bslab;
   int B, H, W, nsplit;
   int tiles_x, tiles_y;
+  const float* a_amax; const float* dz_amax;   // fp16 form: device scalars max|a| (raw), max|dz|
 };
 
-template <int NS>
-__device__ __forceinline__ void split_store8(const float (&v)[8], char* dst, int plane_stride) {
+template <int NS, bool F16>
+__device__ __forceinline__ void split_store8(const float (&v)[8], char* dst, int plane_stride, float sc) {
+  typedef typename WPlane<F16>::T PT;
+  typedef typename WPlane<F16>::V8 PV8;
   float r[8];
 #pragma unroll
-  for (int y = 0; y < 8; ++y) r[y] = v[y];
+  for (int y = 0; y < 8; ++y) r[y] = F16 ? v[y] * sc : v[y];
 #pragma unroll
   for (int p = 0; p < NS; ++p) {
-    bf16x8 q;
+    PV8 q;
 #pragma unroll
     for (int y = 0; y < 8; ++y) {
-      q[y] = (__bf16)r[y];
+      q[y] = (PT)r[y];
       r[y] -= (float)q[y];
     }
-    *(bf16x8*)(dst + p * plane_stride) = q;
+    *(PV8*)(dst + p * plane_stride) = q;
   }
 }
 
-template <int KS, int NS>
+template <int KS, int NS, bool F16>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_bf16s_kernel(const WgradBArgs g) {
+  typedef typename WPlane<F16>::V8 PV8;
   constexpr int P = KS / 2;
   constexpr int XH = 8 + KS - 1;
   constexpr int DZ_PLANE = 8 * 64 * 16;        // bytes per bf16 plane of the dz tile
@@ -102,6 +126,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_bf16s_kernel(const WgradBAr
       sc1 = g.a_scale[cib * 64 + r1_blk * 16 + r1_q * 4 + r1_j];
       sh1 = g.a_shift[cib * 64 + r1_blk * 16 + r1_q * 4 + r1_j];
     }
+  }
+
+  // fp16 planes: power-of-two scales of both operands (input: bound of the fused transform), undone at the end
+  float s_a = 1.f, s_d = 1.f;
+  if (F16) {
+    float ma = g.a_amax ? *g.a_amax : 0.f;
+    if (g.a_scale) {
+      __shared__ float bnd[8];
+      float ms = 0.f, mt = 0.f;
+      for (int c = tid; c < 64; c += 256) {
+        ms = fmaxf(ms, fabsf(g.a_scale[cib * 64 + c]));
+        mt = fmaxf(mt, fabsf(g.a_shift[cib * 64 + c]));
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        ms = fmaxf(ms, __shfl_xor(ms, o));
+        mt = fmaxf(mt, __shfl_xor(mt, o));
+      }
+      if (tid == 0) { bnd[0] = ms; bnd[1] = mt; }
+      __syncthreads();
+      ma = ma * bnd[0] + bnd[1];
+    }
+    s_a = pow2_scale_to_2p13(ma);
+    s_d = pow2_scale_to_2p13(g.dz_amax ? *g.dz_amax : 0.f);
   }
 
   const int tpi = g.tiles_x * g.tiles_y;
@@ -173,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_bf16s_kernel(const WgradBAr
 #pragma unroll
           for (int y = 0; y < 8; ++y) bsum[j] += col[y];
         }
-        split_store8<NS>(col, dst + j * 16, pstride);
+        split_store8<NS, F16>(col, dst + j * 16, pstride, r0_dz ? s_d : s_a);
       }
     }
     if (NA1 > 0 && r1_on) {
@@ -183,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_bf16s_kernel(const WgradBAr
         col[y] = v1[y];
         if (g.a_scale && ((ok1 >> y) & 1)) col[y] = fmaxf(fmaf(col[y], sc1, sh1), 0.f);
       }
-      split_store8<NS>(col, at + (r1_x * 64 + r1_blk * 16 + r1_q * 4 + r1_j) * 16, A_PLANE);
+      split_store8<NS, F16>(col, at + (r1_x * 64 + r1_blk * 16 + r1_q * 4 + r1_j) * 16, A_PLANE, s_a);
     }
   };
 
@@ -195,17 +243,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_bf16s_kernel(const WgradBAr
     if (item + 1 < it1) load_item(item + 1);     // next patch's global loads fly under this patch's MFMAs
 #pragma unroll
     for (int xp = 0; xp < 4; ++xp) {
-      bf16x8 af[NS];
+      PV8 af[NS];
 #pragma unroll
-      for (int p = 0; p < NS; ++p) af[p] = *(const bf16x8*)(dzt + p * DZ_PLANE + (2 * xp) * (64 * 16) + laneA);
+      for (int p = 0; p < NS; ++p) af[p] = *(const PV8*)(dzt + p * DZ_PLANE + (2 * xp) * (64 * 16) + laneA);
 #pragma unroll
       for (int kw = 0; kw < KS; ++kw) {
-        bf16x8 bf[NS];
+        PV8 bf[NS];
 #pragma unroll
-        for (int p = 0; p < NS; ++p) bf[p] = *(const bf16x8*)(at + p * A_PLANE + (2 * xp + kw) * (64 * 16) + laneB);
+        for (int p = 0; p < NS; ++p) bf[p] = *(const PV8*)(at + p * A_PLANE + (2 * xp + kw) * (64 * 16) + laneB);
 #pragma unroll
         for (int t = 0; t < NPROD; ++t)
-          acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[6 - NPROD + t]], bf[PB[6 - NPROD + t]], acc[kw], 0, 0, 0);
+          acc[kw] = WPlane<F16>::mfma(af[PA[6 - NPROD + t]], bf[PB[6 - NPROD + t]], acc[kw]);
       }
     }
   }
@@ -218,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_bf16s_kernel(const WgradBAr
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = cob * 64 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      sl[((size_t)co * g.cin + ci) * T + kh * KS + kw] = acc[kw][r];
+      sl[((size_t)co * g.cin + ci) * T + kh * KS + kw] = F16 ? acc[kw][r] * (1.f / (s_a * s_d)) : acc[kw][r];
     }
   }
   if (do_bias) {      // thread tid < 128 holds sums of its (column x, 4 channels); reduce the 8 columns
@@ -240,9 +288,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_bf16s_kernel(const WgradBAr
 
 extern "C" int tsr_conv2d_wgrad_bf16s(const float* a, int a_ctot, int a_coff, int cin,
                                       const float* a_scale, const float* a_shift,
-                                      const float* dz, int dz_ctot, int dz_coff, int cout, int ks, int nsplit_planes,
+                                      const float* dz, int dz_ctot, int dz_coff, int cout, int ks, int planes,
+                                      const float* a_amax, const float* dz_amax,
                                       float* slab, float* bias_slab, int nsplit, int B, int H, int W, void* stream) {
-  if (!a || !dz || !slab || B <= 0 || H <= 0 || W <= 0 || nsplit <= 0 || nsplit_planes != 3) return TSR_ERR_ARG;
+  // planes = 3: bf16 (fp32-equivalent, a_amax/dz_amax unused); planes = -2: fp16 two-plane split with the
+  // power-of-two scales derived from the device scalars a_amax = max|a| (raw) and dz_amax = max|dz|
+  if (!a || !dz || !slab || B <= 0 || H <= 0 || W <= 0 || nsplit <= 0 || (planes != 3 && planes != -2))
+    return TSR_ERR_ARG;
+  if (planes == -2 && (!a_amax || !dz_amax)) return TSR_ERR_ARG;
   if ((cin & 63) || (cout & 63) || (a_ctot & 15) || (a_coff & 15) || (dz_ctot & 15) || (dz_coff & 15) ||
       a_coff + cin > a_ctot || dz_coff + cout > dz_ctot || (ks != 1 && ks != 3 && ks != 5))
     return TSR_ERR_ARG;
@@ -252,10 +305,17 @@ extern "C" int tsr_conv2d_wgrad_bf16s(const float* a, int a_ctot, int a_coff, in
   g.dz = dz; g.dz_ctot = dz_ctot; g.dz_coff = dz_coff; g.cout = cout;
   g.slab = slab; g.bslab = bias_slab; g.B = B; g.H = H; g.W = W; g.nsplit = nsplit;
   g.tiles_x = (W + 7) / 8; g.tiles_y = (H + 7) / 8;
+  g.a_amax = a_amax; g.dz_amax = dz_amax;
   const int grid = nsplit * ks * (cout >> 6) * (cin >> 6);
   hipStream_t st = (hipStream_t)stream;
-  if (ks == 1) hipLaunchKernelGGL((wgrad_mfma_bf16s_kernel<1, 3>), dim3(grid), dim3(256), 0, st, g);
-  else if (ks == 3) hipLaunchKernelGGL((wgrad_mfma_bf16s_kernel<3, 3>), dim3(grid), dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((wgrad_mfma_bf16s_kernel<5, 3>), dim3(grid), dim3(256), 0, st, g);
+  if (planes == 3) {
+    if (ks == 1) hipLaunchKernelGGL((wgrad_mfma_bf16s_kernel<1, 3, false>), dim3(grid), dim3(256), 0, st, g);
+    else if (ks == 3) hipLaunchKernelGGL((wgrad_mfma_bf16s_kernel<3, 3, false>), dim3(grid), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((wgrad_mfma_bf16s_kernel<5, 3, false>), dim3(grid), dim3(256), 0, st, g);
+  } else {
+    if (ks == 1) hipLaunchKernelGGL((wgrad_mfma_bf16s_kernel<1, 2, true>), dim3(grid), dim3(256), 0, st, g);
+    else if (ks == 3) hipLaunchKernelGGL((wgrad_mfma_bf16s_kernel<3, 2, true>), dim3(grid), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((wgrad_mfma_bf16s_kernel<5, 2, true>), dim3(grid), dim3(256), 0, st, g);
+  }
   return tsr_check_launch();
 }

@@ -40,6 +40,7 @@ class ConvDesc(ctypes.Structure):
         ("bn_a", c_void_p), ("bn_b", c_void_p),
         ("slab", c_void_p), ("slab_cnt", c_void_p),
         ("nsplit", c_int),
+        ("in_amax", c_void_p), ("w_inv_scale", c_float), ("out_amax", c_void_p),
     ]
 
 
@@ -49,17 +50,20 @@ def _p(t):
 
 class Act:
     """A CB16 activation slice, optionally 'virtual': value = relu(buf*scale+shift)."""
-    __slots__ = ("buf", "ctot", "coff", "c", "scale", "shift", "xa", "xb")
+    __slots__ = ("buf", "ctot", "coff", "c", "scale", "shift", "xa", "xb", "amax")
 
-    def __init__(self, buf, ctot, coff, c, scale=None, shift=None, xa=None, xb=None):
+    def __init__(self, buf, ctot, coff, c, scale=None, shift=None, xa=None, xb=None, amax=None):
         self.buf, self.ctot, self.coff, self.c = buf, ctot, coff, c
         self.scale, self.shift, self.xa, self.xb = scale, shift, xa, xb
+        self.amax = amax     # fp16x3 only: 1-element device tensor holding max|buf| (of the raw stored values)
 
 
 def conv_ex(*, B, H, W, src: Act, w, cout, ks, out, out_ctot, out_coff, scale=None, shift=None, relu=0,
-            res: Act = None, epi_mode=0, mask: Act = None, bn=False, slab=None, slab_cnt=None, nsplit=0):
+            res: Act = None, epi_mode=0, mask: Act = None, bn=False, slab=None, slab_cnt=None, nsplit=0,
+            w_inv_scale=1.0, out_amax=None):
     d = ConvDesc()
     d.nsplit = nsplit
+    d.in_amax, d.w_inv_scale, d.out_amax = _p(src.amax), w_inv_scale, _p(out_amax)
     d.in_, d.in_ctot, d.in_coff, d.cin = _p(src.buf), src.ctot, src.coff, src.c
     d.w_packed, d.cout, d.ks = _p(w), cout, ks
     d.scale, d.shift = _p(scale), _p(shift)
@@ -81,7 +85,12 @@ def conv_ex(*, B, H, W, src: Act, w, cout, ks, out, out_ctot, out_coff, scale=No
         raise _lib.TactileSRHipError(f"tsr_conv2d_ex failed: status {st}")
 
 
-def _pack(w, cout, cin, ks, nsplit=0):
+def _pack(w, cout, cin, ks, nsplit=0, wscale=1.0):
+    if nsplit == -2:
+        n = _lib.load().tsr_conv_weight_bf16s_elems(cout, cin, ks, 2)
+        wp = torch.empty(n, dtype=torch.float16, device=w.device)
+        call("tsr_pack_conv_weight_f16s", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), _F(wscale), stream())
+        return wp
     if nsplit:
         n = _lib.load().tsr_conv_weight_bf16s_elems(cout, cin, ks, nsplit)
         wp = torch.empty(n, dtype=torch.bfloat16, device=w.device)
@@ -92,7 +101,13 @@ def _pack(w, cout, cin, ks, nsplit=0):
     return wp
 
 
-def _pack_dgrad(w, cout, cin, ks, ci0, nprime, nsplit=0):
+def _pack_dgrad(w, cout, cin, ks, ci0, nprime, nsplit=0, wscale=1.0):
+    if nsplit == -2:
+        n = _lib.load().tsr_conv_weight_bf16s_elems(nprime, cout, ks, 2)
+        wp = torch.empty(n, dtype=torch.float16, device=w.device)
+        call("tsr_pack_conv_weight_dgrad_f16s", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), _I(ci0), _I(nprime),
+             _F(wscale), stream())
+        return wp
     if nsplit:
         n = _lib.load().tsr_conv_weight_bf16s_elems(nprime, cout, ks, nsplit)
         wp = torch.empty(n, dtype=torch.bfloat16, device=w.device)
@@ -115,8 +130,44 @@ class TrainEngine:
         self.m = model
         self.debug = None        # tests may set a dict: backward then stores clones of dz tensors in it
         import os
-        # conv arithmetic of the train path: 0 = fp32 MFMA, 3 = split-bf16 (six products, fp32-equivalent)
-        self.nsplit = {"f32": 0, "bf16x6": 3}[os.environ.get("TSR_TRAIN_IMPL", "bf16x6")]
+        # conv arithmetic of the train path: 0 = fp32 MFMA, 3 = split-bf16 (six products, fp32-equivalent),
+        # -2 = two scaled fp16 planes (three products; operand scales from device-side max|.| scalars)
+        self.nsplit = {"f32": 0, "bf16x6": 3, "fp16x3": -2}[os.environ.get("TSR_TRAIN_IMPL", "fp16x3")]
+        self.f16 = self.nsplit == -2
+
+    def _mfma_convs(self):
+        m = self.m
+        cv = [m.inputContact_layer[0], m.output_layer[0]]
+        cv += [seq[4] for seq in m.inputLayer_pattern_list]
+        for blk in m.patternFeatureExtra_layer:
+            cv += [blk.conv_3_1[0], blk.conv_5_1[0], blk.conv_3_2[0], blk.conv_5_2[0], blk.confusion]
+        for rb in m.forceFeatureExtra_layer:
+            cv += [rb.conv1, rb.conv2]
+        return cv
+
+    def _weight_scales(self, c):
+        """fp16x3: power-of-two scale per conv weight (max|w|*wscale in [2^13, 2^14)); one host sync per step."""
+        c.wscale = {}
+        if not self.f16:
+            return
+        import math
+        cv = self._mfma_convs()
+        mx = torch.stack(torch._foreach_norm([k.weight.detach() for k in cv], float("inf"))).cpu().tolist()
+        for k, v in zip(cv, mx):
+            c.wscale[id(k)] = 2.0 ** (13 - math.floor(math.log2(v))) if v > 0 and math.isfinite(v) else 1.0
+
+    def _amax_pool(self, c, dev):
+        n = 64 + 8 * (len(self.m.patternFeatureExtra_layer) + len(self.m.forceFeatureExtra_layer) + self.m.seqsCnt)
+        pool = torch.zeros(n, dtype=torch.float32, device=dev) if self.f16 else None
+        state = [0]
+
+        def new():
+            if pool is None:
+                return None
+            i = state[0]
+            state[0] += 1
+            return pool[i:i + 1]
+        return new
 
     # ------------------------------------------------------------------ helpers
     def _bn_finalize(self, c: _Ctx, conv_bias, bn, slab, cnt, entries, C):
@@ -129,13 +180,19 @@ class TrainEngine:
         bn.num_batches_tracked.add_(1)
         return vec   # rows: scale, shift, xhat_a, xhat_b
 
-    def _conv_bn(self, c: _Ctx, src: Act, conv, bn, out, out_ctot, out_coff):
+    def _packw(self, c, conv):
+        w = conv.weight.detach().contiguous()
+        ws = c.wscale.get(id(conv), 1.0)
+        return _pack(w, w.shape[0], w.shape[1], w.shape[2], self.nsplit, ws), 1.0 / ws
+
+    def _conv_bn(self, c: _Ctx, src: Act, conv, bn, out, out_ctot, out_coff, out_amax=None):
         """conv (bias-free raw output) + batch statistics; returns the 4xC BN vectors."""
-        w = conv.weight.detach()
+        w = conv.weight
         cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
-        wp = _pack(w.contiguous(), cout, cin, ks, self.nsplit)
+        wp, wis = self._packw(c, conv)
         conv_ex(B=c.B, H=c.H, W=c.W, src=src, w=wp, cout=cout, ks=ks, out=out, out_ctot=out_ctot,
-                out_coff=out_coff, epi_mode=1, slab=c.slab, slab_cnt=c.slab_cnt, nsplit=self.nsplit)
+                out_coff=out_coff, epi_mode=1, slab=c.slab, slab_cnt=c.slab_cnt, nsplit=self.nsplit,
+                w_inv_scale=wis, out_amax=out_amax)
         return self._bn_finalize(c, conv.bias, bn, c.slab, c.slab_cnt, c.entries, cout)
 
     # ------------------------------------------------------------------ forward
@@ -158,28 +215,37 @@ class TrainEngine:
         def buf(ch):
             return torch.empty(B * ch * HW, dtype=torch.float32, device=dev)
 
+        self._weight_scales(c)
+        new_amax = self._amax_pool(c, dev)
         ctot_in = x.shape[1]
         # ---- pattern stems
-        c.z1, c.bn1 = [], []
+        c.z1, c.bn1, c.am_z1 = [], [], []
         c.catT = buf(64 * T)
+        c.am_catT = new_amax()
         c.bn2 = torch.empty(4, 64 * T, dtype=torch.float32, device=dev)
         for t, seq in enumerate(m.inputLayer_pattern_list):
             z1 = buf(64)
+            am = new_amax()
             call("tsr_stem_fwd", ptr(x), _I(ctot_in), _I(A * t), _I(A), _I(hin), _I(win), _I(sf),
-                 ptr(seq[1].weight.detach()), ptr(None), ptr(None), ptr(z1), _I(64), _I(0), _I(0), _I(B), ptr(None), stream())
+                 ptr(seq[1].weight.detach()), ptr(None), ptr(None), ptr(z1), _I(64), _I(0), _I(0), _I(B), ptr(am),
+                 stream())
             call("tsr_cb16_stats", ptr(z1), _I(64), _I(0), _I(B), _I(HW), ptr(c.slab), ptr(c.slab_cnt), stream())
             v1 = self._bn_finalize(c, None, seq[2], c.slab, c.slab_cnt, st_entries, 64)
             c.z1.append(z1)
             c.bn1.append(v1)
-            v2 = self._conv_bn(c, Act(z1, 64, 0, 64, v1[0], v1[1]), seq[4], seq[5], c.catT, 64 * T, 64 * t)
+            c.am_z1.append(am)
+            v2 = self._conv_bn(c, Act(z1, 64, 0, 64, v1[0], v1[1], amax=am), seq[4], seq[5], c.catT, 64 * T, 64 * t,
+                               out_amax=c.am_catT)
             c.bn2[:, 64 * t:64 * (t + 1)] = v2
         # ---- fuse conv
         c.zf = buf(64)
-        c.bnf = self._conv_bn(c, Act(c.catT, 64 * T, 0, 64 * T, c.bn2[0], c.bn2[1]), m.inputContact_layer[0],
-                              m.inputContact_layer[1], c.zf, 64, 0)
-        X = Act(c.zf, 64, 0, 64, c.bnf[0], c.bnf[1], c.bnf[2], c.bnf[3])
+        am_zf = new_amax()
+        c.bnf = self._conv_bn(c, Act(c.catT, 64 * T, 0, 64 * T, c.bn2[0], c.bn2[1], amax=c.am_catT),
+                              m.inputContact_layer[0], m.inputContact_layer[1], c.zf, 64, 0, out_amax=am_zf)
+        X = Act(c.zf, 64, 0, 64, c.bnf[0], c.bnf[1], c.bnf[2], c.bnf[3], amax=am_zf)
         # ---- MSRB chain
         c.hcat = buf(128)
+        c.am_hcat = new_amax()
         c.blocks = []
         n_msrb = len(m.patternFeatureExtra_layer)
         for i, blk in enumerate(m.patternFeatureExtra_layer):
@@ -188,32 +254,34 @@ class TrainEngine:
             s.cat1, s.cat2 = buf(128), buf(256)
             s.bn_c1 = torch.empty(4, 128, dtype=torch.float32, device=dev)
             s.bn_c2 = torch.empty(4, 256, dtype=torch.float32, device=dev)
-            s.bn_c1[:, 0:64] = self._conv_bn(c, X, blk.conv_3_1[0], blk.conv_3_1[1], s.cat1, 128, 0)
-            s.bn_c1[:, 64:128] = self._conv_bn(c, X, blk.conv_5_1[0], blk.conv_5_1[1], s.cat1, 128, 64)
-            A1 = Act(s.cat1, 128, 0, 128, s.bn_c1[0], s.bn_c1[1], s.bn_c1[2], s.bn_c1[3])
-            s.bn_c2[:, 0:128] = self._conv_bn(c, A1, blk.conv_3_2[0], blk.conv_3_2[1], s.cat2, 256, 0)
-            s.bn_c2[:, 128:256] = self._conv_bn(c, A1, blk.conv_5_2[0], blk.conv_5_2[1], s.cat2, 256, 128)
-            A2 = Act(s.cat2, 256, 0, 256, s.bn_c2[0], s.bn_c2[1], s.bn_c2[2], s.bn_c2[3])
+            am_c1, am_c2 = new_amax(), new_amax()
+            s.bn_c1[:, 0:64] = self._conv_bn(c, X, blk.conv_3_1[0], blk.conv_3_1[1], s.cat1, 128, 0, am_c1)
+            s.bn_c1[:, 64:128] = self._conv_bn(c, X, blk.conv_5_1[0], blk.conv_5_1[1], s.cat1, 128, 64, am_c1)
+            A1 = Act(s.cat1, 128, 0, 128, s.bn_c1[0], s.bn_c1[1], s.bn_c1[2], s.bn_c1[3], amax=am_c1)
+            s.bn_c2[:, 0:128] = self._conv_bn(c, A1, blk.conv_3_2[0], blk.conv_3_2[1], s.cat2, 256, 0, am_c2)
+            s.bn_c2[:, 128:256] = self._conv_bn(c, A1, blk.conv_5_2[0], blk.conv_5_2[1], s.cat2, 256, 128, am_c2)
+            A2 = Act(s.cat2, 256, 0, 256, s.bn_c2[0], s.bn_c2[1], s.bn_c2[2], s.bn_c2[3], amax=am_c2)
             s.A1, s.A2 = A1, A2
-            wconf = blk.confusion.weight.detach().contiguous()
-            wp = _pack(wconf, 64, 256, 1, self.nsplit)
+            wp, wis = self._packw(c, blk.confusion)
             if i == n_msrb - 1:
-                out, octot, ocoff = c.hcat, 128, 64
+                out, octot, ocoff, am_o = c.hcat, 128, 64, c.am_hcat
             else:
-                out, octot, ocoff = buf(64), 64, 0
+                out, octot, ocoff, am_o = buf(64), 64, 0, new_amax()
             conv_ex(B=B, H=H, W=W, src=A2, w=wp, cout=64, ks=1, out=out, out_ctot=octot, out_coff=ocoff,
-                    shift=blk.confusion.bias.detach(), relu=1, res=X, nsplit=self.nsplit)
-            X = Act(out, octot, ocoff, 64)
+                    shift=blk.confusion.bias.detach(), relu=1, res=X, nsplit=self.nsplit, w_inv_scale=wis,
+                    out_amax=am_o)
+            X = Act(out, octot, ocoff, 64, amax=am_o)
             s.Y = X
             c.blocks.append(s)
         if n_msrb == 0:
             raise _lib.TactileSRHipError("train path needs patternFeatureExtraLayerCnt >= 1")
         # ---- force branch
         c.f0 = buf(64)
+        am_f0 = new_amax()
         call("tsr_stem_fwd", ptr(x), _I(ctot_in), _I(0), _I(A), _I(hin), _I(win), _I(sf),
              ptr(m.input_layer_force[1].weight.detach()), ptr(None), ptr(None), ptr(c.f0), _I(64), _I(0), _I(1),
-             _I(B), ptr(None), stream())
-        F0 = Act(c.f0, 64, 0, 64)
+             _I(B), ptr(am_f0), stream())
+        F0 = Act(c.f0, 64, 0, 64, amax=am_f0)
         c.res = []
         n_res = len(m.forceFeatureExtra_layer)
         if n_res == 0:
@@ -222,24 +290,26 @@ class TrainEngine:
             s = _Ctx()
             s.X = F0
             s.f1 = buf(64)
-            w1 = _pack(rb.conv1.weight.detach().contiguous(), 64, 64, 3, self.nsplit)
+            s.F1 = Act(s.f1, 64, 0, 64, amax=new_amax())
+            w1, wis1 = self._packw(c, rb.conv1)
             conv_ex(B=B, H=H, W=W, src=F0, w=w1, cout=64, ks=3, out=s.f1, out_ctot=64, out_coff=0,
-                    shift=rb.conv1.bias.detach(), relu=1, nsplit=self.nsplit)
-            w2 = _pack(rb.conv2.weight.detach().contiguous(), 64, 64, 3, self.nsplit)
+                    shift=rb.conv1.bias.detach(), relu=1, nsplit=self.nsplit, w_inv_scale=wis1, out_amax=s.F1.amax)
+            w2, wis2 = self._packw(c, rb.conv2)
             if i == n_res - 1:
-                out, octot, ocoff = c.hcat, 128, 0
+                out, octot, ocoff, am_o = c.hcat, 128, 0, c.am_hcat
             else:
-                out, octot, ocoff = buf(64), 64, 0
-            conv_ex(B=B, H=H, W=W, src=Act(s.f1, 64, 0, 64), w=w2, cout=64, ks=3, out=out, out_ctot=octot,
-                    out_coff=ocoff, shift=rb.conv2.bias.detach(), relu=1, res=F0, nsplit=self.nsplit)
-            F0 = Act(out, octot, ocoff, 64)
+                out, octot, ocoff, am_o = buf(64), 64, 0, new_amax()
+            conv_ex(B=B, H=H, W=W, src=s.F1, w=w2, cout=64, ks=3, out=out, out_ctot=octot,
+                    out_coff=ocoff, shift=rb.conv2.bias.detach(), relu=1, res=F0, nsplit=self.nsplit,
+                    w_inv_scale=wis2, out_amax=am_o)
+            F0 = Act(out, octot, ocoff, 64, amax=am_o)
             s.Y = F0
             c.res.append(s)
         # ---- head
         c.h0 = buf(128)
-        wh = _pack(m.output_layer[0].weight.detach().contiguous(), 128, 128, 3, self.nsplit)
-        conv_ex(B=B, H=H, W=W, src=Act(c.hcat, 128, 0, 128), w=wh, cout=128, ks=3, out=c.h0, out_ctot=128,
-                out_coff=0, relu=1, nsplit=self.nsplit)
+        wh, wish = self._packw(c, m.output_layer[0])
+        conv_ex(B=B, H=H, W=W, src=Act(c.hcat, 128, 0, 128, amax=c.am_hcat), w=wh, cout=128, ks=3, out=c.h0,
+                out_ctot=128, out_coff=0, relu=1, nsplit=self.nsplit, w_inv_scale=wish)
         out = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
         call("tsr_head_fwd", ptr(c.h0), _I(128), _I(128), ptr(m.output_layer[2].weight.detach()), ptr(out), _I(1),
              _I(B), _I(H), _I(W), stream())
@@ -251,7 +321,7 @@ class TrainEngine:
         """Batch splits of the wgrad launch: slices*nsplit ~ 2 x (3 workgroups x 256 CUs) resident slots;
         work items are (image, 8x8 patch) pairs, so splits may outnumber images."""
         slices = ks * (cout // 64) * (cin // 64)
-        return max(1, min(B * tiles, (1024 if self.nsplit == 3 else 1536) // slices))   # 2 (bf16s) / 3 (f32) WGs per CU
+        return max(1, min(B * tiles, (1024 if self.nsplit else 1536) // slices))   # 2 (16-bit) / 3 (f32) WGs per CU
 
     def _wgrad(self, c, a: Act, dz: Act, conv, grads, name, with_bias):
         w = conv.weight
@@ -260,10 +330,10 @@ class TrainEngine:
         n = cout * cin * ks * ks
         slab = torch.empty(ns * n, dtype=torch.float32, device=w.device)
         bslab = torch.empty(ns * cout, dtype=torch.float32, device=w.device) if with_bias else None
-        if self.nsplit == 3:
+        if self.nsplit:
             call("tsr_conv2d_wgrad_bf16s", ptr(a.buf), _I(a.ctot), _I(a.coff), _I(cin), ptr(a.scale), ptr(a.shift),
-                 ptr(dz.buf), _I(dz.ctot), _I(dz.coff), _I(cout), _I(ks), _I(3), ptr(slab), ptr(bslab), _I(ns),
-                 _I(c.B), _I(c.H), _I(c.W), stream())
+                 ptr(dz.buf), _I(dz.ctot), _I(dz.coff), _I(cout), _I(ks), _I(self.nsplit), ptr(a.amax), ptr(dz.amax),
+                 ptr(slab), ptr(bslab), _I(ns), _I(c.B), _I(c.H), _I(c.W), stream())
         else:
             call("tsr_conv2d_wgrad", ptr(a.buf), _I(a.ctot), _I(a.coff), _I(cin), ptr(a.scale), ptr(a.shift),
                  ptr(dz.buf), _I(dz.ctot), _I(dz.coff), _I(cout), _I(ks), ptr(slab), ptr(bslab), _I(ns),
@@ -277,16 +347,18 @@ class TrainEngine:
             grads[name + ".bias"] = gb
 
     def _dgrad(self, c, dz: Act, conv, ci0, nprime, out, out_ctot, out_coff, res: Act = None, mask: Act = None,
-               bn=False):
+               bn=False, out_amax=None):
         """d(input)[ci0:ci0+nprime] of conv given dz; optional + res, ReLU mask, BN-backward sums."""
         w = conv.weight.detach().contiguous()
         cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
-        wp = _pack_dgrad(w, cout, cin, ks, ci0, nprime, self.nsplit)
+        ws = c.wscale.get(id(conv), 1.0)
+        wp = _pack_dgrad(w, cout, cin, ks, ci0, nprime, self.nsplit, ws)
         conv_ex(B=c.B, H=c.H, W=c.W, src=dz, w=wp, cout=nprime, ks=ks, out=out, out_ctot=out_ctot,
                 out_coff=out_coff, res=res, epi_mode=2 if mask is not None else 0, mask=mask, bn=bn,
-                slab=c.slab if bn else None, slab_cnt=None, nsplit=self.nsplit)
+                slab=c.slab if bn else None, slab_cnt=None, nsplit=self.nsplit, w_inv_scale=1.0 / ws,
+                out_amax=out_amax)
 
-    def _bn_bwd(self, c, g_buf, g_ctot, g_coff, z: Act, zoff, C, bn_vec, bn_mod, grads, name):
+    def _bn_bwd(self, c, g_buf, g_ctot, g_coff, z: Act, zoff, C, bn_vec, bn_mod, grads, name, out_amax=None):
         """Finish BatchNorm backward for C channels whose masked gradient g sits in g_buf (slab sums
         were just produced by the dgrad epilogue over the same C channels)."""
         dev = g_buf.device
@@ -295,7 +367,7 @@ class TrainEngine:
              ptr(bn_vec[0]), ptr(bn_vec[2]), ptr(bn_vec[3]), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]),
              ptr(out[4]), ptr(c.work), stream())
         call("tsr_bn_bwd_apply", ptr(g_buf), _I(g_ctot), _I(g_coff), ptr(z.buf), _I(z.ctot), _I(z.coff + zoff),
-             ptr(out[2]), ptr(out[3]), ptr(out[4]), _I(C), _I(c.B), _I(c.HW), stream())
+             ptr(out[2]), ptr(out[3]), ptr(out[4]), _I(C), _I(c.B), _I(c.HW), ptr(out_amax), stream())
         return out   # rows 0,1 = dgamma, dbeta
 
     # ------------------------------------------------------------------ backward
@@ -308,41 +380,45 @@ class TrainEngine:
         def buf(ch):
             return torch.empty(B * ch * HW, dtype=torch.float32, device=dev)
 
+        new_amax = self._amax_pool(c, dev)      # a gradient tensor consumed by an MFMA launch carries max|.|
         dout = dout.contiguous().float()
         # ---- head: out = relu(conv(h0)), h0 = relu(conv(hcat))
         ns = max(1, min(B, 256))
         dz_h0 = buf(128)
+        am_dzh0 = new_amax()
         wslab = torch.empty(ns * 128 * 9, dtype=torch.float32, device=dev)
         call("tsr_head_bwd", ptr(dout), ptr(c.out), ptr(c.h0), _I(128), _I(128),
              ptr(m.output_layer[2].weight.detach()), ptr(dz_h0), _I(128), ptr(wslab), _I(ns), _I(B), _I(H), _I(W),
-             stream())
+             ptr(am_dzh0), stream())
         gw = torch.empty_like(m.output_layer[2].weight)
         call("tsr_reduce_splits", ptr(wslab), ptr(gw), _L(128 * 9), _I(ns), _F(1.0), stream())
         grads["output_layer.2.weight"] = gw
-        DZ = Act(dz_h0, 128, 0, 128)
-        HC = Act(c.hcat, 128, 0, 128)
+        DZ = Act(dz_h0, 128, 0, 128, amax=am_dzh0)
+        HC = Act(c.hcat, 128, 0, 128, amax=c.am_hcat)
         self._wgrad(c, HC, DZ, m.output_layer[0], grads, "output_layer.0", False)
         g_hcat = buf(128)
-        self._dgrad(c, DZ, m.output_layer[0], 0, 128, g_hcat, 128, 0, mask=HC)
+        am_ghcat = new_amax()
+        self._dgrad(c, DZ, m.output_layer[0], 0, 128, g_hcat, 128, 0, mask=HC, out_amax=am_ghcat)
         if self.debug is not None:
             self.debug["dz_h0"] = dz_h0.clone()
             self.debug["g_hcat"] = g_hcat.clone()
         del dz_h0
 
         # ---- force branch (ResBlocks, reversed); gradient w.r.t. block output pre-ReLU in `dpre`
-        dpre = Act(g_hcat, 128, 0, 64)
+        dpre = Act(g_hcat, 128, 0, 64, amax=am_ghcat)
         for i in reversed(range(len(c.res))):
             s, rb = c.res[i], m.forceFeatureExtra_layer[i]
             name = f"forceFeatureExtra_layer.{i}"
-            F1 = Act(s.f1, 64, 0, 64)
+            F1 = s.F1
             self._wgrad(c, F1, dpre, rb.conv2, grads, name + ".conv2", True)
             d1 = buf(64)
-            self._dgrad(c, dpre, rb.conv2, 0, 64, d1, 64, 0, mask=F1)
-            D1 = Act(d1, 64, 0, 64)
+            D1 = Act(d1, 64, 0, 64, amax=new_amax())
+            self._dgrad(c, dpre, rb.conv2, 0, 64, d1, 64, 0, mask=F1, out_amax=D1.amax)
             self._wgrad(c, s.X, D1, rb.conv1, grads, name + ".conv1", True)
             d0 = buf(64)
-            self._dgrad(c, D1, rb.conv1, 0, 64, d0, 64, 0, res=dpre, mask=s.X)
-            dpre = Act(d0, 64, 0, 64)
+            am = new_amax()
+            self._dgrad(c, D1, rb.conv1, 0, 64, d0, 64, 0, res=dpre, mask=s.X, out_amax=am)
+            dpre = Act(d0, 64, 0, 64, amax=am)
         ns = max(1, min(B, 256))
         sslab = torch.empty(ns * 64 * 27, dtype=torch.float32, device=dev)
         call("tsr_stem_wgrad", ptr(c.x), _I(c.x.shape[1]), _I(0), _I(c.hin), _I(c.win), _I(m.scale_factor),
@@ -352,13 +428,14 @@ class TrainEngine:
         grads["input_layer_force.1.weight"] = gw
 
         # ---- pattern branch: MSRB blocks reversed
-        dpre = Act(g_hcat, 128, 64, 64)
+        dpre = Act(g_hcat, 128, 64, 64, amax=am_ghcat)
         for i in reversed(range(len(c.blocks))):
             s, blk = c.blocks[i], m.patternFeatureExtra_layer[i]
             name = f"patternFeatureExtra_layer.{i}"
             # confusion 1x1: a = relu(bn(cat2)), dz = dpre
             self._wgrad(c, s.A2, dpre, blk.confusion, grads, name + ".confusion", True)
             g2 = buf(256)
+            am_g2 = [new_amax(), new_amax()]
             for half, (cv, bnm, nm) in enumerate(((blk.conv_3_2[0], blk.conv_3_2[1], "conv_3_2"),
                                                   (blk.conv_5_2[0], blk.conv_5_2[1], "conv_5_2"))):
                 o = 128 * half
@@ -366,37 +443,40 @@ class TrainEngine:
                          s.bn_c2[3, o:o + 128])
                 self._dgrad(c, dpre, blk.confusion, o, 128, g2, 256, o, mask=mk, bn=True)
                 r = self._bn_bwd(c, g2, 256, o, Act(s.cat2, 256, 0, 256), o, 128, s.bn_c2[:, o:o + 128], bnm, grads,
-                                 nm)
+                                 nm, out_amax=am_g2[half])
                 grads[f"{name}.{nm}.1.weight"], grads[f"{name}.{nm}.1.bias"] = r[0].clone(), r[1].clone()
             if self.debug is not None:
                 self.debug[f"msrb{i}.dz2"] = g2.clone()
-            DZ32, DZ52 = Act(g2, 256, 0, 128), Act(g2, 256, 128, 128)
+            DZ32, DZ52 = Act(g2, 256, 0, 128, amax=am_g2[0]), Act(g2, 256, 128, 128, amax=am_g2[1])
             self._wgrad(c, s.A1, DZ32, blk.conv_3_2[0], grads, f"{name}.conv_3_2.0", True)
             self._wgrad(c, s.A1, DZ52, blk.conv_5_2[0], grads, f"{name}.conv_5_2.0", True)
             g1 = buf(128)
             self._dgrad(c, DZ32, blk.conv_3_2[0], 0, 128, g1, 128, 0)
             mk = Act(s.cat1, 128, 0, 128, s.bn_c1[0], s.bn_c1[1], s.bn_c1[2], s.bn_c1[3])
             self._dgrad(c, DZ52, blk.conv_5_2[0], 0, 128, g1, 128, 0, res=Act(g1, 128, 0, 128), mask=mk, bn=True)
-            r = self._bn_bwd(c, g1, 128, 0, Act(s.cat1, 128, 0, 128), 0, 128, s.bn_c1, None, grads, "")
+            am_g1 = new_amax()
+            r = self._bn_bwd(c, g1, 128, 0, Act(s.cat1, 128, 0, 128), 0, 128, s.bn_c1, None, grads, "", out_amax=am_g1)
             grads[f"{name}.conv_3_1.1.weight"], grads[f"{name}.conv_3_1.1.bias"] = r[0, :64].clone(), r[1, :64].clone()
             grads[f"{name}.conv_5_1.1.weight"], grads[f"{name}.conv_5_1.1.bias"] = r[0, 64:].clone(), r[1, 64:].clone()
             del g2
             if self.debug is not None:
                 self.debug[f"msrb{i}.dz1"] = g1.clone()
-            DZ31, DZ51 = Act(g1, 128, 0, 64), Act(g1, 128, 64, 64)
+            DZ31, DZ51 = Act(g1, 128, 0, 64, amax=am_g1), Act(g1, 128, 64, 64, amax=am_g1)
             self._wgrad(c, s.X, DZ31, blk.conv_3_1[0], grads, f"{name}.conv_3_1.0", True)
             self._wgrad(c, s.X, DZ51, blk.conv_5_1[0], grads, f"{name}.conv_5_1.0", True)
             dx = buf(64)
             self._dgrad(c, DZ31, blk.conv_3_1[0], 0, 64, dx, 64, 0, res=dpre)
             virtual = s.X.scale is not None
-            self._dgrad(c, DZ51, blk.conv_5_1[0], 0, 64, dx, 64, 0, res=Act(dx, 64, 0, 64), mask=s.X, bn=virtual)
-            dpre = Act(dx, 64, 0, 64)
+            am = new_amax()
+            self._dgrad(c, DZ51, blk.conv_5_1[0], 0, 64, dx, 64, 0, res=Act(dx, 64, 0, 64), mask=s.X, bn=virtual,
+                        out_amax=None if virtual else am)
+            dpre = Act(dx, 64, 0, 64, amax=am)
             del g1
         # X of block 0 is the fuse conv's relu(bn(zf)): finish its BN backward -> dzf
-        r = self._bn_bwd(c, dpre.buf, 64, 0, Act(c.zf, 64, 0, 64), 0, 64, c.bnf, None, grads, "")
+        r = self._bn_bwd(c, dpre.buf, 64, 0, Act(c.zf, 64, 0, 64), 0, 64, c.bnf, None, grads, "", out_amax=dpre.amax)
         grads["inputContact_layer.1.weight"], grads["inputContact_layer.1.bias"] = r[0].clone(), r[1].clone()
         T = m.seqsCnt
-        AT = Act(c.catT, 64 * T, 0, 64 * T, c.bn2[0], c.bn2[1], c.bn2[2], c.bn2[3])
+        AT = Act(c.catT, 64 * T, 0, 64 * T, c.bn2[0], c.bn2[1], c.bn2[2], c.bn2[3], amax=c.am_catT)
         self._wgrad(c, AT, dpre, m.inputContact_layer[0], grads, "inputContact_layer.0", False)
         gT = buf(64 * T)
         for t, seq in enumerate(m.inputLayer_pattern_list):
@@ -405,12 +485,13 @@ class TrainEngine:
             mk = Act(c.catT, 64 * T, o, 64, c.bn2[0, o:o + 64], c.bn2[1, o:o + 64], c.bn2[2, o:o + 64],
                      c.bn2[3, o:o + 64])
             self._dgrad(c, dpre, m.inputContact_layer[0], o, 64, gT, 64 * T, o, mask=mk, bn=True)
+            am_gT = new_amax()
             r = self._bn_bwd(c, gT, 64 * T, o, Act(c.catT, 64 * T, 0, 64 * T), o, 64, c.bn2[:, o:o + 64], None, grads,
-                             "")
+                             "", out_amax=am_gT)
             grads[name + ".5.weight"], grads[name + ".5.bias"] = r[0].clone(), r[1].clone()
-            DZ2 = Act(gT, 64 * T, o, 64)
+            DZ2 = Act(gT, 64 * T, o, 64, amax=am_gT)
             v1 = c.bn1[t]
-            A1 = Act(c.z1[t], 64, 0, 64, v1[0], v1[1], v1[2], v1[3])
+            A1 = Act(c.z1[t], 64, 0, 64, v1[0], v1[1], v1[2], v1[3], amax=c.am_z1[t])
             self._wgrad(c, A1, DZ2, seq[4], grads, name + ".4", False)
             g1 = buf(64)
             self._dgrad(c, DZ2, seq[4], 0, 64, g1, 64, 0, mask=A1, bn=True)

@@ -24,7 +24,7 @@ def T():
     return M
 
 
-@pytest.mark.parametrize("impl", ["f32", "bf16x6"])
+@pytest.mark.parametrize("impl", ["f32", "bf16x6", "fp16x3"])
 @pytest.mark.parametrize("ks,cin,cout,B,H,W,affine", [
     (3, 64, 64, 3, 40, 40, False), (5, 64, 64, 2, 40, 40, True), (3, 128, 128, 2, 40, 40, True),
     (5, 128, 128, 2, 16, 24, False), (1, 256, 64, 3, 40, 40, True), (3, 128, 64, 5, 13, 21, True),
@@ -34,6 +34,10 @@ def test_conv2d_wgrad(T, ks, cin, cout, B, H, W, affine, impl):
     g = torch.Generator().manual_seed(ks + cin + cout + B)
     araw = torch.randn(B, cin, H, W, generator=g)
     dz = torch.randn(B, cout, H, W, generator=g)
+    if impl == "fp16x3":        # gradient-like dynamic range: tiny values with a few large outliers
+        dz = dz * 1e-4
+        dz[0, 0, 0, 0] = 0.37
+        araw[0, 1, 2, 3] = 41.0
     sc = torch.rand(cin, generator=g) + 0.5
     sh = torch.randn(cin, generator=g) * 0.3
     a = F.relu(araw * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if affine else araw
@@ -51,8 +55,10 @@ def test_conv2d_wgrad(T, ks, cin, cout, B, H, W, affine, impl):
         call("tsr_conv2d_wgrad", ptr(ad), I(cin + 16), I(16), I(cin), ptr(scd), ptr(shd), ptr(dzd), I(cout + 32), I(16),
              I(cout), I(ks), ptr(slab), ptr(bslab), I(ns), I(B), I(H), I(W), stream())
     else:
+        am = torch.stack([araw.abs().max(), dz.abs().max()]).cuda()      # producers publish these in the engine
         call("tsr_conv2d_wgrad_bf16s", ptr(ad), I(cin + 16), I(16), I(cin), ptr(scd), ptr(shd), ptr(dzd), I(cout + 32),
-             I(16), I(cout), I(ks), I(3), ptr(slab), ptr(bslab), I(ns), I(B), I(H), I(W), stream())
+             I(16), I(cout), I(ks), I(3 if impl == "bf16x6" else -2), ptr(am[0:1]), ptr(am[1:2]), ptr(slab),
+             ptr(bslab), I(ns), I(B), I(H), I(W), stream())
     out = torch.empty(cout, cin, ks, ks, device="cuda")
     outb = torch.empty(cout, device="cuda")
     call("tsr_reduce_splits", ptr(slab), ptr(out), L(n), I(ns), Fl(1.0), stream())
@@ -103,8 +109,10 @@ def test_conv2d_dgrad_with_mask_and_bn_sums(T, ks, cin, cout, B, H, W, NP):
         call("tsr_bn_bwd_finalize", ptr(slab), I(entries), I(NP), D(float(B * H * W)), ptr(vec[0, o:o + NP]),
              ptr(vec[2, o:o + NP]), ptr(vec[3, o:o + NP]), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]),
              ptr(out[4]), ptr(work), stream())
+        am = torch.zeros(1, device="cuda")
         call("tsr_bn_bwd_apply", ptr(gbuf), I(cin), I(o), ptr(zd), I(cin), I(o), ptr(out[2]), ptr(out[3]), ptr(out[4]),
-             I(NP), I(B), I(H * W), stream())
+             I(NP), I(B), I(H * W), ptr(am), stream())
+        assert am.item() == T.from_cb16(gbuf, B, cin, H, W)[:, o:o + NP].abs().max().item()
         dgam.append(out[0].clone())
         dbet.append(out[1].clone())
     assert relerr(T.from_cb16(gbuf, B, cin, H, W), gz) < 2e-5
@@ -117,7 +125,9 @@ def _subs(t, k=512):
     return t[:: max(1, t.numel() // k)].cpu().numpy()
 
 
-def test_train_forward_backward_vs_reference_golden(T, golden):
+@pytest.mark.parametrize("impl", ["bf16x6", "fp16x3", "f32"])
+def test_train_forward_backward_vs_reference_golden(T, golden, impl, monkeypatch):
+    monkeypatch.setenv("TSR_TRAIN_IMPL", impl)
     g = golden("train")
     cfg = dict(patternFeatureExtraLayerCnt=2)
     sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), int(g["seed"]))
@@ -160,11 +170,13 @@ def test_train_forward_backward_vs_reference_golden(T, golden):
     assert all(p.grad is not None for p in m.parameters())
 
 
-def test_full_step_adam_vs_reference_golden(T, golden):
+@pytest.mark.parametrize("impl", ["bf16x6", "fp16x3"])
+def test_full_step_adam_vs_reference_golden(T, golden, impl, monkeypatch):
     """train_cal_loss + zero_grad/backward/Adam(L2) step through the HIP path, twice; post-step weights,
     running stats and the second-step loss vs the reference's own run."""
     from tactilesr_amd import optim
     from tactilesr_amd.train import tactileSR_train as TR
+    monkeypatch.setenv("TSR_TRAIN_IMPL", impl)
     g = golden("train")
     cfg = dict(patternFeatureExtraLayerCnt=2)
     sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), int(g["seed"]))
