@@ -61,12 +61,14 @@ def main():
                          "powers of two and split into 2 fp16 planes, 3 f16-MFMA products (fp32-grade, default); "
                          "bf16x6 = 3 bf16 planes, 6 products (fp32-equivalent); f32 = fp32 MFMA; "
                          "bf16x3 / bf16 = reduced precision (not the headline)")
-    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+    ap.add_argument("--mode", choices=["infer", "train", "tpsf"], default="infer",
                     help="infer = BASELINE configs[1] (headline); train = data-parallel train step "
                          "(train_cal_loss + backward + RCCL grad all-reduce + Adam), configs[3] shape")
     args = ap.parse_args()
     if args.mode == "train":
         return main_train(args)
+    if args.mode == "tpsf":
+        return main_tpsf(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -249,6 +251,86 @@ def main_train(args):
                          "algorithmic_vs_f32_mfma_peak": round(value / world * train_flop / PEAK_F32_MFMA, 4),
                          "traffic": None, "kernel": "whole train step (43.9 GFLOP/sample algorithmic)"},
             "loss": float(ld["total_loss"]),
+        }), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_tpsf(args):
+    """tPSFNet (reference model/tPSFNet.py:78-141): one step = Trainer_tPSF.train_cal_loss + backward + Adam
+    (train/tPSFNet_train.py:180-190) on `--batch` samples (default 8192, BASELINE configs[2]); the forward-only
+    rate (the dataset-generator use, data/SRdataset/depth2tactile.py:104-160) is reported beside it.  Single GPU
+    or independent replicas (no gradient exchange is timed here; the MLP has 0.54 M parameters)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    import tactilesr_amd
+    from tactilesr_amd import optim
+    from tactilesr_amd.train import tPSFNet_train as TP
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        from tactilesr_amd import ddp
+        ddp.init_distributed(os.environ.get("TSR_BENCH_DIST_BACKEND", "nccl"))
+    torch.manual_seed(42)
+    net = tactilesr_amd.tPSFNet(gama=1.4, perception_scale=None).to(dev).train()
+    opt = optim.Adam(net.parameters(), lr=1e-3, weight_decay=0.0)
+    B = args.batch if args.batch != 4096 else 8192
+    g = torch.Generator().manual_seed(42 + rank)
+    batch = ((torch.rand(B, 3, 4, 4, generator=g) * 800).to(dev), (torch.rand(B, 100, 100, generator=g) * 10).to(dev))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        loss, _ = TP.train_cal_loss(net, batch)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+
+    def fwd():
+        with torch.no_grad():
+            return net(batch[0] / 100.0, batch[1].unsqueeze(1))
+
+    for _ in range(args.warmup):
+        step()
+        fwd()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        fwd()
+    barrier()
+    dtf = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([dt, dtf], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, dtf = float(t[0]), float(t[1])
+    if rank == 0:
+        value = B * world * args.steps / dt
+        vf = B * world * args.steps / dtf
+        fwd_bytes = 4 * (10000 + 10000 + 9801 + 16 + 48 + 3)      # depth in; HR, psf, LR_degrade out
+        print(json.dumps({
+            "metric": "tPSFNet train samples/sec (depth 100x100 -> HR 100x100 + 4x4 taxels)", "value": round(value, 1),
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "tPSFNet train step (MLP + separable PSF conv fwd, analytic bwd, Adam), batch/GPU=%d "
+                                   "(BASELINE configs[2] shape)" % B, "batch_per_gpu": B, "parallelism": f"replicas x{world}"},
+            "forward_only": {"samples_per_s": round(vf, 1), "ms_per_batch": round(dtf / args.steps * 1e3, 3)},
+            "roofline": {"bound": "hbm", "achieved": round(vf / world * fwd_bytes / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(vf / world * fwd_bytes / 8e12, 4), "traffic": None,
+                         "kernel": "tpsf_fwd_kernel (forward-only rate x %d algorithmic bytes/sample)" % fwd_bytes},
+            "loss": float(loss.detach()),
         }), flush=True)
     if world > 1:
         dist.barrier()

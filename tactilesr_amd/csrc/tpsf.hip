@@ -57,89 +57,6 @@ __device__ __forceinline__ void row_pass(const float* __restrict__ D, const floa
   }
 }
 
-__global__ __launch_bounds__(256) void tpsf_fwd_kernel(const float* __restrict__ depth,
-                                                       const float* __restrict__ ab,   // (B,3)
-                                                       float* __restrict__ HR, float* __restrict__ LRd,
-                                                       float* __restrict__ psf) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* D = sm;                 // [100][100] depth, later the final HR
-  float* R = sm + NPIX;          // [100][100] row pass
-  float* g = R + NPIX;           // [99]
-  float* ea = g + 128;           // [4][100] mask factors
-  float* P = ea + 400;           // [4][100]
-  float* red = P + 400;          // [8]
-  double* redd = (double*)(red + 8);
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const float alpha = ab[b * 3 + 0], beta = ab[b * 3 + 1], gamma = ab[b * 3 + 2];
-  const float cpsf = KP / (beta * beta);
-  const float cm = KM / gamma;
-  for (int i = tid; i < PS; i += 256) { const float t = (float)(i - 49); g[i] = expf(-cpsf * t * t); }
-  for (int i = tid; i < 400; i += 256) {
-    const int a = i / 100, x = i - a * 100;
-    const float t = (float)(x - (12 + 25 * a));
-    ea[i] = expf(-cm * t * t);
-  }
-  const float* dp = depth + (size_t)b * NPIX;
-  float dmax = -INFINITY;
-  for (int i = tid; i < NPIX; i += 256) { const float v = dp[i]; D[i] = v; dmax = fmaxf(dmax, v); }
-  dmax = block_reduce_max(dmax, red);
-  __syncthreads();
-  // psf output (B,1,99,99)
-  float* pp = psf + (size_t)b * PS * PS;
-  for (int i = tid; i < PS * PS; i += 256) { const int u = i / PS, v = i - u * PS; pp[i] = alpha * (g[u] * g[v]); }
-  row_pass(D, g, R);
-  __syncthreads();
-  // column pass + plateau mask; raw HR kept in registers (40 px / thread)
-  float hr[40];
-  float fmax_out = 0.f;          // tmp[mask] = 0 takes part in the max (the mask is never empty)
-  const float thr = dmax - 1e-3f;
-#pragma unroll
-  for (int k = 0; k < 40; ++k) {
-    const int i = tid + k * 256;
-    hr[k] = 0.f;
-    if (i < NPIX) {
-      const int y = i / HS, x = i - y * HS;
-      const int u0 = 49 - y > 0 ? 49 - y : 0;
-      const int u1 = 148 - y < PS - 1 ? 148 - y : PS - 1;
-      float s = 0.f;
-      for (int u = u0; u <= u1; ++u) s = fmaf(R[(y + u - 49) * HS + x], g[u], s);
-      hr[k] = alpha * s;
-      if (!(D[i] > thr)) fmax_out = fmaxf(fmax_out, hr[k]);
-    }
-  }
-  const float fill = block_reduce_max(fmax_out, red);
-  __syncthreads();
-  float* hp = HR + (size_t)b * NPIX;
-  double s0 = 0;
-#pragma unroll
-  for (int k = 0; k < 40; ++k) {
-    const int i = tid + k * 256;
-    if (i < NPIX) {
-      const float v = D[i] > thr ? fill : hr[k];
-      hp[i] = v;
-      s0 += (double)v;
-      R[i] = v;               // final HR for the pooling (R is free now)
-    }
-  }
-  const double S0 = block_reduce_sum(s0, redd);
-  __syncthreads();
-  // separable Gaussian-masked pooling: P[a][col] = sum_row ea[a][row] * HR[row][col]
-  for (int i = tid; i < 400; i += 256) {
-    const int a = i / 100, col = i - a * 100;
-    float s = 0.f;
-    for (int row = 0; row < HS; ++row) s = fmaf(ea[a * 100 + row], R[row * HS + col], s);
-    P[i] = s;
-  }
-  __syncthreads();
-  if (tid < 16) {
-    const int a = tid >> 2, c = tid & 3;
-    float s = 0.f;
-    for (int col = 0; col < HS; ++col) s = fmaf(P[a * 100 + col], ea[c * 100 + col], s);
-    const float mn = expf(-100.0f / gamma);
-    LRd[b * 16 + tid] = (s - mn * (float)S0) / (1.0f - mn) * 1e-4f;
-  }
-}
-
 // Backward of the forward model w.r.t. (alpha, beta, gamma) for one sample, given dL/dLRd (16).
 __global__ __launch_bounds__(256) void tpsf_bwd_kernel(const float* __restrict__ depth, const float* __restrict__ ab,
                                                        const float* __restrict__ dLRd, float* __restrict__ dab) {
@@ -271,16 +188,6 @@ __global__ __launch_bounds__(256) void tpsf_bwd_kernel(const float* __restrict__
     dab[b * 3 + 1] = (float)(DB * (double)alpha * 2.0 * (double)KP / ((double)beta * beta * beta));
     dab[b * 3 + 2] = (float)DG;
   }
-}
-
-extern "C" int tpsf_forward(const float* depth, const float* alpha_beta, float* HR, float* LR_deg, float* psf,
-                            int B, void* stream) {
-  if (!depth || !alpha_beta || !HR || !LR_deg || !psf || B <= 0) return TSR_ERR_ARG;
-  const size_t smem = (size_t)(2 * NPIX + 128 + 400 + 400 + 8 + 16) * 4;
-  static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)tpsf_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  hipLaunchKernelGGL(tpsf_fwd_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, depth, alpha_beta, HR, LR_deg, psf);
-  return tsr_check_launch();
 }
 
 extern "C" int tpsf_backward(const float* depth, const float* alpha_beta, const float* dLR_deg, float* d_alpha_beta,
