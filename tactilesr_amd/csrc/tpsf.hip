@@ -21,186 +21,6 @@
 #define KP (100.0f / 4802.0f)      // 10^2 / (49^2 + 49^2)
 #define KM (100.0f / 15138.0f)     // 10^2 / (87^2 + 87^2): farthest pixel (99,99) from centre (12,12)
 
-__device__ __forceinline__ float block_reduce_max(float v, float* sh) {
-  const int tid = threadIdx.x;
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  __syncthreads();
-  if ((tid & 63) == 0) sh[tid >> 6] = v;
-  __syncthreads();
-  float r = sh[0];
-  for (int k = 1; k < (int)(blockDim.x >> 6); ++k) r = fmaxf(r, sh[k]);
-  return r;
-}
-
-__device__ __forceinline__ double block_reduce_sum(double v, double* sh) {
-  const int tid = threadIdx.x;
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  __syncthreads();
-  if ((tid & 63) == 0) sh[tid >> 6] = v;
-  __syncthreads();
-  double r = 0;
-  for (int k = 0; k < (int)(blockDim.x >> 6); ++k) r += sh[k];
-  return r;
-}
-
-// row pass: R[y][x] = sum_v D[y][x+v-49] * f[v]  (zero padded)
-__device__ __forceinline__ void row_pass(const float* __restrict__ D, const float* __restrict__ f,
-                                         float* __restrict__ R) {
-  for (int i = threadIdx.x; i < NPIX; i += blockDim.x) {
-    const int y = i / HS, x = i - y * HS;
-    const int v0 = 49 - x > 0 ? 49 - x : 0;
-    const int v1 = 148 - x < PS - 1 ? 148 - x : PS - 1;
-    const float* dr = D + y * HS + x - 49;
-    float s = 0.f;
-    for (int v = v0; v <= v1; ++v) s = fmaf(dr[v], f[v], s);
-    R[i] = s;
-  }
-}
-
-// Backward of the forward model w.r.t. (alpha, beta, gamma) for one sample, given dL/dLRd (16).
-__global__ __launch_bounds__(256) void tpsf_bwd_kernel(const float* __restrict__ depth, const float* __restrict__ ab,
-                                                       const float* __restrict__ dLRd, float* __restrict__ dab) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* D = sm;                 // depth, later final HR
-  float* Rg = sm + NPIX;         // row pass with g
-  float* Rh = Rg + NPIX;         // row pass with h = (t-49)^2 g
-  float* g = Rh + NPIX;          // [99]
-  float* h = g + 128;            // [99]
-  float* ea = h + 128;           // [4][100]
-  float* ea2 = ea + 400;         // [4][100]  ea * (x-cx)^2
-  float* P = ea2 + 400;          // [4][100]  sum_row ea*HR
-  float* P2 = P + 400;           // [4][100]  sum_row ea2*HR
-  float* dl = P2 + 400;          // [16]
-  float* red = dl + 16;          // [8]
-  double* redd = (double*)(red + 8);
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const float alpha = ab[b * 3 + 0], beta = ab[b * 3 + 1], gamma = ab[b * 3 + 2];
-  const float cpsf = KP / (beta * beta);
-  const float cm = KM / gamma;
-  const float mn = expf(-100.0f / gamma);
-  for (int i = tid; i < PS; i += 256) {
-    const float t = (float)(i - 49);
-    g[i] = expf(-cpsf * t * t);
-    h[i] = t * t * g[i];
-  }
-  for (int i = tid; i < 400; i += 256) {
-    const int a = i / 100, x = i - a * 100;
-    const float t = (float)(x - (12 + 25 * a));
-    ea[i] = expf(-cm * t * t);
-    ea2[i] = t * t * ea[i];
-  }
-  if (tid < 16) dl[tid] = dLRd[b * 16 + tid];
-  const float* dp = depth + (size_t)b * NPIX;
-  float dmax = -INFINITY;
-  for (int i = tid; i < NPIX; i += 256) { const float v = dp[i]; D[i] = v; dmax = fmaxf(dmax, v); }
-  dmax = block_reduce_max(dmax, red);
-  __syncthreads();
-  row_pass(D, g, Rg);
-  row_pass(D, h, Rh);
-  __syncthreads();
-  const float thr = dmax - 1e-3f;
-  float hr[40], dhb[40];
-  float fmax_out = 0.f;
-#pragma unroll
-  for (int k = 0; k < 40; ++k) {
-    const int i = tid + k * 256;
-    hr[k] = 0.f; dhb[k] = 0.f;
-    if (i < NPIX) {
-      const int y = i / HS, x = i - y * HS;
-      const int u0 = 49 - y > 0 ? 49 - y : 0;
-      const int u1 = 148 - y < PS - 1 ? 148 - y : PS - 1;
-      float s = 0.f, sb = 0.f;
-      for (int u = u0; u <= u1; ++u) {
-        const float rg = Rg[(y + u - 49) * HS + x], rh = Rh[(y + u - 49) * HS + x];
-        s = fmaf(rg, g[u], s);
-        sb = fmaf(rg, h[u], fmaf(rh, g[u], sb));
-      }
-      hr[k] = alpha * s;
-      dhb[k] = sb;                              // d(raw conv)/d(cpsf) = -sb ; times dcpsf/dbeta below
-      if (!(D[i] > thr)) fmax_out = fmaxf(fmax_out, hr[k]);
-    }
-  }
-  const float fill = block_reduce_max(fmax_out, red);
-  __syncthreads();
-  // G[row][col] = dL/dHR = 1e-4/(1-mn) * sum_ab dl_ab (ea_a(row) eb_b(col) - mn), zero on the plateau
-  const float k0 = 1e-4f / (1.0f - mn);
-  float dlsum = 0.f;
-  for (int t = 0; t < 16; ++t) dlsum += dl[t];
-  double da = 0, db = 0, s0 = 0;
-#pragma unroll
-  for (int k = 0; k < 40; ++k) {
-    const int i = tid + k * 256;
-    if (i < NPIX) {
-      const int row = i / HS, col = i - row * HS;
-      const bool plateau = D[i] > thr;
-      const float v = plateau ? fill : hr[k];
-      s0 += (double)v;
-      if (!plateau) {
-        float gsum = 0.f;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const float er = ea[a * 100 + row];
-          gsum += er * (dl[a * 4 + 0] * ea[0 * 100 + col] + dl[a * 4 + 1] * ea[1 * 100 + col] +
-                        dl[a * 4 + 2] * ea[2 * 100 + col] + dl[a * 4 + 3] * ea[3 * 100 + col]);
-        }
-        const float G = k0 * (gsum - mn * dlsum);
-        da += (double)(G * hr[k]);
-        db += (double)(G * dhb[k]);
-      }
-      Rg[i] = v;      // final HR; every column-pass read of Rg finished before the fill reduction's barrier
-    }
-  }
-  __syncthreads();
-  const double S0 = block_reduce_sum(s0, redd);
-  const double DA = block_reduce_sum(da, redd);
-  const double DB = block_reduce_sum(db, redd);
-  __syncthreads();
-  for (int i = tid; i < 400; i += 256) {
-    const int a = i / 100, col = i - a * 100;
-    float s = 0.f, s2 = 0.f;
-    for (int row = 0; row < HS; ++row) {
-      const float v = Rg[row * HS + col];
-      s = fmaf(ea[a * 100 + row], v, s);
-      s2 = fmaf(ea2[a * 100 + row], v, s2);
-    }
-    P[i] = s; P2[i] = s2;
-  }
-  __syncthreads();
-  double dg = 0;
-  if (tid < 16) {
-    const int a = tid >> 2, c = tid & 3;
-    float S = 0.f, Sd = 0.f;    // S_ab = sum HR m_ab ; Sd = sum HR m_ab d^2_ab
-    for (int col = 0; col < HS; ++col) {
-      S = fmaf(P[a * 100 + col], ea[c * 100 + col], S);
-      Sd = fmaf(P2[a * 100 + col], ea[c * 100 + col], fmaf(P[a * 100 + col], ea2[c * 100 + col], Sd));
-    }
-    const double gm = gamma, mnd = mn;
-    const double mnp = mnd * 100.0 / (gm * gm);                 // d mn / d gamma
-    const double dS = (double)Sd * (double)KM / (gm * gm);      // d S_ab / d gamma
-    const double num = (double)S - mnd * S0, den = 1.0 - mnd;
-    const double dLR = 1e-4 * ((dS - mnp * S0) * den + num * mnp) / (den * den);
-    dg = (double)dl[tid] * dLR;
-  }
-  const double DG = block_reduce_sum(dg, redd);
-  if (tid == 0) {
-    dab[b * 3 + 0] = (float)(DA / (double)alpha);
-    // raw = sum D e^{-cpsf r^2}: d raw/d beta = sum D e r^2 * 2 KP / beta^3 ; HR = alpha*raw
-    dab[b * 3 + 1] = (float)(DB * (double)alpha * 2.0 * (double)KP / ((double)beta * beta * beta));
-    dab[b * 3 + 2] = (float)DG;
-  }
-}
-
-extern "C" int tpsf_backward(const float* depth, const float* alpha_beta, const float* dLR_deg, float* d_alpha_beta,
-                             int B, void* stream) {
-  if (!depth || !alpha_beta || !dLR_deg || !d_alpha_beta || B <= 0) return TSR_ERR_ARG;
-  const size_t smem = (size_t)(3 * NPIX + 256 + 1600 + 16 + 8 + 16) * 4;
-  static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)tpsf_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  hipLaunchKernelGGL(tpsf_bwd_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, depth, alpha_beta, dLR_deg,
-                     d_alpha_beta);
-  return tsr_check_launch();
-}
-
 // ------------------------------------------------------------------------------------------
 // small strided SGEMM with fused bias + activation, for the 48-256-1024-256-3 MLP and its backward:
 //   C[i][j] = act( sum_k A(i,k) B(k,j) + bias[j] ),  A(i,k) = A[i*sa0+k*sa1], B(k,j) = B[k*sb0+j*sb1]

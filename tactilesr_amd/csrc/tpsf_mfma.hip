@@ -41,8 +41,122 @@ __device__ __forceinline__ float pow2_scale_to_2p13(float m) {
   return __uint_as_float((unsigned)be << 23);
 }
 
+// m = all ones -> a, 0 -> b; integer arithmetic only (the epilogues avoid bool selects: hipcc turns those into
+// per-pixel branches whose live-through values it then spills)
+__device__ __forceinline__ float bitsel(unsigned m, float a, float b) {
+  return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m));
+}
+
 __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+}  // namespace
+
+namespace {
+// Toeplitz table of a symmetric 99-tap filter tab[0..98] (centre 49), times `scale`, as 8 shifted copies x 2 fp16
+// planes: copy r holds T[m + r], T[i] = tab[49 + i - T_OFF] (0 outside the +-49 band)
+__device__ __forceinline__ void build_toeplitz(char* Tc, const float* tab, float scale, int tid) {
+  for (int i = tid; i < 8 * (TC_STRIDE / 2); i += 256) {
+    const int r = i / (TC_STRIDE / 2), m = i - r * (TC_STRIDE / 2);
+    const int d = m + r - T_OFF;
+    const float v = (d >= -49 && d <= 49) ? tab[49 + d] * scale : 0.f;
+    const _Float16 hi = (_Float16)v;
+    *(_Float16*)(Tc + r * TC_STRIDE + 2 * m) = hi;
+    *(_Float16*)(Tc + T_PLANE + r * TC_STRIDE + 2 * m) = (_Float16)(v - (float)hi);
+  }
+}
+
+// acc[nt] += A(rows of this wave, fp16 planes in registers) * Toeplitz(Tc)   -- 28 (k step, column tile) steps of 3
+// MFMAs; the table fragments run two steps ahead in a 3-slot register ring, and a scheduling barrier per step keeps
+// hipcc from hoisting all 56 ds_reads to the top
+__device__ __forceinline__ void gemm_rows_toeplitz(f32x16 (&acc)[4], const f16x8 (&a_hi)[7], const f16x8 (&a_lo)[7],
+                                                   const char* Tc, int laneT) {
+  f16x8 bh[3], bl[3];
+#define G1_LOAD(i)                                                                                   \
+  {                                                                                                  \
+    bh[(i) % 3] = *(const f16x8*)(Tc + laneT + 32 * ((i) / 4) - 64 * ((i) % 4));                    \
+    bl[(i) % 3] = *(const f16x8*)(Tc + T_PLANE + laneT + 32 * ((i) / 4) - 64 * ((i) % 4));          \
+  }
+  G1_LOAD(0);
+  G1_LOAD(1);
+#pragma unroll
+  for (int i = 0; i < 28; ++i) {
+    if (i + 2 < 28) G1_LOAD(i + 2);
+    const int ks = i / 4, nt = i % 4;
+    acc[nt] = mfma16(a_lo[ks], bh[i % 3], acc[nt]);
+    acc[nt] = mfma16(a_hi[ks], bl[i % 3], acc[nt]);
+    acc[nt] = mfma16(a_hi[ks], bh[i % 3], acc[nt]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef G1_LOAD
+}
+
+// R^T planes -> LDS: RT[x][y'] = acc * f1 split in two fp16 planes (rows y' >= 100 of the accumulators are exact
+// zeros: they pad K to 104)
+__device__ __forceinline__ void store_rt(const f32x16 (&acc)[4], float f1, char* RT, int w, int h, int li) {
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int x = 32 * nt + li;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int y0 = 32 * w + 8 * rq + 4 * h;
+      f16x4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = acc[nt][rq * 4 + j] * f1;
+        hi[j] = (_Float16)t;
+        lo[j] = (_Float16)(t - (float)hi[j]);
+      }
+      if (x < HS && y0 < 104) {
+        *(f16x4*)(RT + x * RT_STRIDE + 2 * y0) = hi;
+        *(f16x4*)(RT + RT_PLANE + x * RT_STRIDE + 2 * y0) = lo;
+      }
+    }
+  }
+}
+
+// acc[nt] += Toeplitz(Tc)(rows of this wave) * R(RT)   (K columns >= 104 of the last step are masked in A)
+__device__ __forceinline__ void gemm_toeplitz_rt(f32x16 (&acc)[4], const char* Tc, const char* RT, int laneT, int w,
+                                                 int h, int li) {
+  f16x8 gh[2], gl[2], rh[3], rl[3];
+  const int rtl0 = (li < HS ? li : HS - 1) * RT_STRIDE + 16 * h;             // column tiles 0..2: x = 32 nt + li < 100
+  const int rtl3 = (96 + li < HS ? 96 + li : HS - 1) * RT_STRIDE + 16 * h;   // tile 3: clamp x to 99
+#define G2_LOADA(ks)                                                                                 \
+  {                                                                                                  \
+    gh[(ks) & 1] = *(const f16x8*)(Tc + laneT + 32 * (ks) - 64 * w);                                 \
+    gl[(ks) & 1] = *(const f16x8*)(Tc + T_PLANE + laneT + 32 * (ks) - 64 * w);                       \
+    if ((ks) == 6 && h == 1) {                                                                       \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) { gh[(ks) & 1][j] = (_Float16)0.f; gl[(ks) & 1][j] = (_Float16)0.f; } \
+    }                                                                                                \
+  }
+#define G2_LOADB(i)                                                                                  \
+  {                                                                                                  \
+    const int off_ = ((i) % 4 == 3 ? rtl3 : rtl0 + ((i) % 4) * 32 * RT_STRIDE) + 32 * ((i) / 4);     \
+    rh[(i) % 3] = *(const f16x8*)(RT + off_);                                                        \
+    rl[(i) % 3] = *(const f16x8*)(RT + RT_PLANE + off_);                                             \
+  }
+  G2_LOADA(0);
+  G2_LOADB(0);
+  G2_LOADB(1);
+#pragma unroll
+  for (int i = 0; i < 28; ++i) {
+    const int ks = i / 4, nt = i % 4;
+    if (i + 2 < 28) G2_LOADB(i + 2);
+    if (nt == 0 && ks + 1 < 7) G2_LOADA(ks + 1);
+    acc[nt] = mfma16(gl[ks & 1], rh[i % 3], acc[nt]);
+    acc[nt] = mfma16(gh[ks & 1], rl[i % 3], acc[nt]);
+    acc[nt] = mfma16(gh[ks & 1], rh[i % 3], acc[nt]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef G2_LOADA
+#undef G2_LOADB
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 }
 }  // namespace
 
@@ -114,15 +228,7 @@ __global__ __launch_bounds__(256, 2) void tpsf_fwd_mfma_kernel(const float* __re
     mabs = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     const float dmax = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
 
-    // ---- Toeplitz table, 8 shifted copies x 2 planes
-    for (int i = tid; i < 8 * (TC_STRIDE / 2); i += 256) {
-      const int r = i / (TC_STRIDE / 2), m = i - r * (TC_STRIDE / 2);
-      const int d = m + r - T_OFF;
-      const float v = (d >= -49 && d <= 49) ? g[49 + d] * G_SCALE : 0.f;
-      const _Float16 hi = (_Float16)v;
-      *(_Float16*)(Tc + r * TC_STRIDE + 2 * m) = hi;
-      *(_Float16*)(Tc + T_PLANE + r * TC_STRIDE + 2 * m) = (_Float16)(v - (float)hi);
-    }
+    build_toeplitz(Tc, g, G_SCALE, tid);
     // ---- psf output (B,1,99,99)
     float* pp = psf + (size_t)b * PS * PS;
     {
@@ -157,98 +263,14 @@ __global__ __launch_bounds__(256, 2) void tpsf_fwd_mfma_kernel(const float* __re
     }
     __syncthreads();                                                      // (2) table copies
 
-    // ---- GEMM1: R = D * G
+    // ---- GEMM1: R = D * G;  R^T planes -> LDS;  GEMM2: HR = G * R
     f32x16 acc[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-    {
-      // 28 (k step, column tile) steps of 3 MFMAs; the table fragments run two steps ahead in a 3-slot register
-      // ring, and a scheduling barrier per step keeps hipcc from hoisting all 56 ds_reads to the top
-      f16x8 bh[3], bl[3];
-#define G1_LOAD(i)                                                                                   \
-  {                                                                                                  \
-    bh[(i) % 3] = *(const f16x8*)(Tc + laneT + 32 * ((i) / 4) - 64 * ((i) % 4));                    \
-    bl[(i) % 3] = *(const f16x8*)(Tc + T_PLANE + laneT + 32 * ((i) / 4) - 64 * ((i) % 4));          \
-  }
-      G1_LOAD(0);
-      G1_LOAD(1);
-#pragma unroll
-      for (int i = 0; i < 28; ++i) {
-        if (i + 2 < 28) G1_LOAD(i + 2);
-        const int ks = i / 4, nt = i % 4;
-        acc[nt] = mfma16(a_lo[ks], bh[i % 3], acc[nt]);
-        acc[nt] = mfma16(a_hi[ks], bl[i % 3], acc[nt]);
-        acc[nt] = mfma16(a_hi[ks], bh[i % 3], acc[nt]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#undef G1_LOAD
-    }
-    // ---- R^T planes -> LDS (rows y' >= 100 of the accumulators are exact zeros: they pad K to 104)
-    {
-      const float f1 = sR / (sD * G_SCALE);
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int x = 32 * nt + li;
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          const int y0 = 32 * w + 8 * rq + 4 * h;
-          f16x4 hi, lo;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float t = acc[nt][rq * 4 + j] * f1;
-            hi[j] = (_Float16)t;
-            lo[j] = (_Float16)(t - (float)hi[j]);
-          }
-          if (x < HS && y0 < 104) {
-            *(f16x4*)(RT + x * RT_STRIDE + 2 * y0) = hi;
-            *(f16x4*)(RT + RT_PLANE + x * RT_STRIDE + 2 * y0) = lo;
-          }
-        }
-      }
-    }
+    zero_acc(acc);
+    gemm_rows_toeplitz(acc, a_hi, a_lo, Tc, laneT);
+    store_rt(acc, sR / (sD * G_SCALE), RT, w, h, li);
     __syncthreads();                                                      // (3) R^T
-
-    // ---- GEMM2: HR = G * R   (A = table with nt -> w; K columns >= 104 of the last step are masked in A)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-    {
-      f16x8 gh[2], gl[2], rh[3], rl[3];
-      const int rtl0 = (li < HS ? li : HS - 1) * RT_STRIDE + 16 * h;             // column tiles 0..2: x = 32 nt + li < 100
-      const int rtl3 = (96 + li < HS ? 96 + li : HS - 1) * RT_STRIDE + 16 * h;   // tile 3: clamp x to 99
-#define G2_LOADA(ks)                                                                                 \
-  {                                                                                                  \
-    gh[(ks) & 1] = *(const f16x8*)(Tc + laneT + 32 * (ks) - 64 * w);                                 \
-    gl[(ks) & 1] = *(const f16x8*)(Tc + T_PLANE + laneT + 32 * (ks) - 64 * w);                       \
-    if ((ks) == 6 && h == 1) {                                                                       \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j) { gh[(ks) & 1][j] = (_Float16)0.f; gl[(ks) & 1][j] = (_Float16)0.f; } \
-    }                                                                                                \
-  }
-#define G2_LOADB(i)                                                                                  \
-  {                                                                                                  \
-    const int off_ = ((i) % 4 == 3 ? rtl3 : rtl0 + ((i) % 4) * 32 * RT_STRIDE) + 32 * ((i) / 4);     \
-    rh[(i) % 3] = *(const f16x8*)(RT + off_);                                                        \
-    rl[(i) % 3] = *(const f16x8*)(RT + RT_PLANE + off_);                                             \
-  }
-      G2_LOADA(0);
-      G2_LOADB(0);
-      G2_LOADB(1);
-#pragma unroll
-      for (int i = 0; i < 28; ++i) {
-        const int ks = i / 4, nt = i % 4;
-        if (i + 2 < 28) G2_LOADB(i + 2);
-        if (nt == 0 && ks + 1 < 7) G2_LOADA(ks + 1);
-        acc[nt] = mfma16(gl[ks & 1], rh[i % 3], acc[nt]);
-        acc[nt] = mfma16(gh[ks & 1], rl[i % 3], acc[nt]);
-        acc[nt] = mfma16(gh[ks & 1], rh[i % 3], acc[nt]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#undef G2_LOADA
-#undef G2_LOADB
-    }
+    zero_acc(acc);
+    gemm_toeplitz_rt(acc, Tc, RT, laneT, w, h, li);
 
     if (b + (int)gridDim.x < B) load_depth(b + gridDim.x);   // the A planes are dead: their registers take the next rows
 
@@ -258,25 +280,33 @@ __global__ __launch_bounds__(256, 2) void tpsf_fwd_mfma_kernel(const float* __re
     int li_o = li, h_o = h;
     asm volatile("" : "+v"(li_o), "+v"(h_o));
     const int yb = 32 * w + 4 * h_o;               // accumulator row r -> image row yb + (r & 3) + 8 (r >> 2)
-    const bool vx3 = li_o < HS - 96;               // column tile 3 holds x = 96..99 only
+    const unsigned vx3 = ((unsigned)(li_o - (HS - 96)) >> 31);   // column tile 3 holds x = 96..99 only
     const float f2 = alpha / (G_SCALE * sR);
     unsigned long long plateau = 0ull;
     float fmax_out = 0.f;          // tmp[mask] = 0 takes part in the max (the mask is never empty)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int yy = yb + (r & 3) + 8 * (r >> 2);
-      const bool vy = yy < HS;
+      const unsigned vy = ((unsigned)(yy - HS) >> 31);             // 1 inside the image
       const uint4 mrow = *(const uint4*)(pmask + yy * 16);
       const unsigned mw[4] = {mrow.x, mrow.y, mrow.z, mrow.w};
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const bool valid = vy && (nt < 3 || vx3);
-        const bool pl = valid && ((mw[nt] >> li_o) & 1u);
-        const float v = valid ? acc[nt][r] * f2 : 0.f;
-        if (pl) plateau |= 1ull << (nt * 16 + r);
-        else fmax_out = fmaxf(fmax_out, v);
+        const unsigned vi = nt < 3 ? vy : (vy & vx3);
+        const unsigned pli = (mw[nt] >> li_o) & vi;
+        const float v = acc[nt][r] * f2 * (float)vi;              // the accumulators outside the image are finite
+        plateau |= (unsigned long long)pli << (nt * 16 + r);
+        fmax_out = fmaxf(fmax_out, v * (float)(1u - pli));
         acc[nt][r] = v;
       }
+      asm volatile("" ::: "memory");     // keep the row's LDS reads and arithmetic in its iteration (hipcc
+      __builtin_amdgcn_sched_barrier(0); // otherwise regroups the unrolled rows and spills hundreds of values)
+    }
+    {
+      // opaque copy: hipcc otherwise keeps the 64 per-pixel conditions alive as lane masks instead of these bits
+      unsigned plo = (unsigned)plateau, phi = (unsigned)(plateau >> 32);
+      asm volatile("" : "+v"(plo), "+v"(phi));
+      plateau = ((unsigned long long)phi << 32) | plo;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) fmax_out = fmaxf(fmax_out, __shfl_xor(fmax_out, o));
@@ -297,16 +327,19 @@ __global__ __launch_bounds__(256, 2) void tpsf_fwd_mfma_kernel(const float* __re
     for (int r = 0; r < 16; ++r) {
       const int yy = yb + (r & 3) + 8 * (r >> 2);
       const bool vy = yy < HS;
-      const int yc = vy ? yy : HS - 1;
+      const int yc = yy < HS - 1 ? yy : HS - 1;
       const float e[4] = {ea[yc], ea[100 + yc], ea[200 + yc], ea[300 + yc]};
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const float v = ((plateau >> (nt * 16 + r)) & 1ull) ? fill : acc[nt][r];   // 0 outside the image
+        const unsigned pm = 0u - (unsigned)((plateau >> (nt * 16 + r)) & 1ull);
+        const float v = bitsel(pm, fill, acc[nt][r]);             // 0 outside the image
         if (vy && (nt < 3 || vx3)) hp[yy * HS + 32 * nt] = v;
         s0 += v;
 #pragma unroll
         for (int a = 0; a < 4; ++a) pa[nt][a] = fmaf(e[a], v, pa[nt][a]);
       }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -340,11 +373,365 @@ __global__ __launch_bounds__(256, 2) void tpsf_fwd_mfma_kernel(const float* __re
   }
 }
 
+// Backward of the forward model w.r.t. (alpha, beta, gamma) for one sample, given dL/dLRd (16)
+// (autograd of reference model/tPSFNet.py:78-141 as train/tPSFNet_train.py:180-190 drives it).  With H the Toeplitz
+// matrix of h(t) = (t-49)^2 g(t):
+//   hr  = a G D G                                  (forward value, needed for the plateau and d/da)
+//   dhb = -(d/dc) (G D G) = H D G + G D H          (c = Kp / b^2)
+// so the kernel runs five Toeplitz GEMMs on the matrix cores: Rg = D G, hr = G Rg, dhb = H Rg, Rh = D H,
+// dhb += G Rh (accumulator rescaled by an exact power of two between the two dhb terms, whose operand scales
+// differ), and reduces dL/dHR-weighted sums from the accumulator registers.
+// (one workgroup per CU: two accumulator sets + the depth planes need the 512-register budget; at the
+// 256-register budget of two resident workgroups hipcc spills ~340 values per lane and runs 2.5x slower)
+__global__ __launch_bounds__(256, 1) void tpsf_bwd_mfma_kernel(const float* __restrict__ depth,
+                                                               const float* __restrict__ ab,
+                                                               const float* __restrict__ dLRd,
+                                                               float* __restrict__ dab, int B) {
+  __shared__ __attribute__((aligned(16))) char Tg[2 * T_PLANE];
+  __shared__ __attribute__((aligned(16))) char Th[2 * T_PLANE];
+  __shared__ __attribute__((aligned(16))) char RT[2 * RT_PLANE + 16];
+  __shared__ float g[128], hh[128];           // g[0..98], h[0..98]
+  __shared__ float ea[400], ea2[400];         // [4][100] mask factors, and (x-cx)^2 times them
+  __shared__ float Pp[4 * 4 * 100], P2p[4 * 4 * 100];   // [wave][a][x] pooling partials with ea / ea2
+  __shared__ __attribute__((aligned(16))) unsigned char pmask[128 * 16];
+  __shared__ float dl[16];
+  __shared__ float red[16];
+  __shared__ double redd[16];
+
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, li = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < 4) ((float*)(RT + 2 * RT_PLANE))[tid] = 0.f;
+  for (int i = tid; i < 128 * 4; i += 256) ((unsigned*)pmask)[i] = 0u;
+  const int y = 32 * w + li;
+  const int q8 = (li + 7) & ~7, rcopy = q8 - li;
+  const int laneT = rcopy * TC_STRIDE + 2 * (T_OFF + 8 * h - q8);
+
+  f32x4 dA[7][2];
+  auto load_depth = [&](int b) {
+    const float* dp = depth + (size_t)b * NPIX + y * HS + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        dA[ks][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (y < HS && 16 * ks + 8 * h + 4 * q < HS) dA[ks][q] = *(const f32x4*)(dp + 16 * ks + 4 * q);
+      }
+  };
+  if ((int)blockIdx.x < B) load_depth(blockIdx.x);
+
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const float alpha = ab[b * 3 + 0], beta = ab[b * 3 + 1], gamma = ab[b * 3 + 2];
+    const float cpsf = KP / (beta * beta);
+    const float cm = KM / gamma;
+    const float mn = expf(-100.0f / gamma);
+
+    float mabs = 0.f, mx = -INFINITY;
+#pragma unroll
+    for (int ks = 0; ks < 7; ++ks)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (y < HS && 16 * ks + 8 * h + 4 * q < HS) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            mabs = fmaxf(mabs, fabsf(dA[ks][q][j]));
+            mx = fmaxf(mx, dA[ks][q][j]);
+          }
+        }
+    for (int i = tid; i < PS; i += 256) {
+      const float t = (float)(i - 49);
+      const float gi = expf(-cpsf * t * t);
+      g[i] = gi;
+      hh[i] = t * t * gi;
+    }
+    for (int i = tid; i < 400; i += 256) {
+      const int a = i / 100, x = i - a * 100;
+      const float t = (float)(x - (12 + 25 * a));
+      const float e = expf(-cm * t * t);
+      ea[i] = e;
+      ea2[i] = t * t * e;
+    }
+    if (tid < 16) dl[tid] = dLRd[b * 16 + tid];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mabs = fmaxf(mabs, __shfl_xor(mabs, o));
+      mx = fmaxf(mx, __shfl_xor(mx, o));
+    }
+    if (lane == 0) { red[w] = mabs; red[4 + w] = mx; }
+    __syncthreads();                                                      // (1) tables, red
+    mabs = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float dmax = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+
+    // ---- operand scales (every wave derives the same values): sums / max of the two filters bound R = D*filter
+    float sumg = lane < 50 ? g[49 + lane] : 0.f, sumh = lane < 50 ? hh[49 + lane] : 0.f;
+    float hmax = sumh;
+    if (lane > 0) { sumg *= 2.f; sumh *= 2.f; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      sumg += __shfl_xor(sumg, o);
+      sumh += __shfl_xor(sumh, o);
+      hmax = fmaxf(hmax, __shfl_xor(hmax, o));
+    }
+    const float sD = pow2_scale_to_2p13(mabs);
+    const float sH = pow2_scale_to_2p13(hmax);
+    const float sRg = pow2_scale_to_2p13(mabs * sumg * 1.0001f);
+    const float sRh = pow2_scale_to_2p13(mabs * sumh * 1.0001f);
+    build_toeplitz(Tg, g, G_SCALE, tid);
+    build_toeplitz(Th, hh, sH, tid);
+
+    const float thr = dmax - 1e-3f;
+    f32x16 acc[4];
+    {
+      f16x8 a_hi[7], a_lo[7];
+#pragma unroll
+      for (int ks = 0; ks < 7; ++ks) {
+        unsigned bits = 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = dA[ks][j >> 2][j & 3];
+          bits |= (d > thr ? 1u : 0u) << j;
+          const float t = d * sD;
+          const _Float16 hi = (_Float16)t;
+          a_hi[ks][j] = hi;
+          a_lo[ks][j] = (_Float16)(t - (float)hi);
+        }
+        if (16 * ks + 8 * h < 104) pmask[y * 16 + 2 * ks + h] = (unsigned char)bits;
+      }
+      __syncthreads();                                                    // (2) table copies, plateau bits
+
+      // ---- Rg = D G -> R^T;  hr = a G Rg
+      zero_acc(acc);
+      gemm_rows_toeplitz(acc, a_hi, a_lo, Tg, laneT);
+    }
+    store_rt(acc, sRg / (sD * G_SCALE), RT, w, h, li);
+    __syncthreads();                                                      // (3) R^T = Rg
+    zero_acc(acc);
+    gemm_toeplitz_rt(acc, Tg, RT, laneT, w, h, li);
+
+    int li_o = li, h_o = h;
+    asm volatile("" : "+v"(li_o), "+v"(h_o));
+    const int yb = 32 * w + 4 * h_o;
+    const unsigned vx3 = ((unsigned)(li_o - (HS - 96)) >> 31);
+    unsigned long long plateau = 0ull, inside = 0ull;      // inside: pixel of the 100x100 image
+    float fmax_out = 0.f;
+    {
+      const float f2 = alpha / (G_SCALE * sRg);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int yy = yb + (r & 3) + 8 * (r >> 2);
+        const unsigned vy = ((unsigned)(yy - HS) >> 31);
+        const uint4 mrow = *(const uint4*)(pmask + yy * 16);
+        const unsigned mw[4] = {mrow.x, mrow.y, mrow.z, mrow.w};
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const unsigned vi = nt < 3 ? vy : (vy & vx3);
+          const unsigned pli = (mw[nt] >> li_o) & vi;
+          const float v = acc[nt][r] * f2 * (float)vi;
+          inside |= (unsigned long long)vi << (nt * 16 + r);
+          plateau |= (unsigned long long)pli << (nt * 16 + r);
+          fmax_out = fmaxf(fmax_out, v * (float)(1u - pli));
+          acc[nt][r] = v;
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    {
+      // opaque copies: hipcc otherwise keeps the 128 per-pixel conditions alive as lane masks instead of these bits
+      unsigned plo = (unsigned)plateau, phi = (unsigned)(plateau >> 32);
+      unsigned ilo = (unsigned)inside, ihi = (unsigned)(inside >> 32);
+      asm volatile("" : "+v"(plo), "+v"(phi), "+v"(ilo), "+v"(ihi));
+      plateau = ((unsigned long long)phi << 32) | plo;
+      inside = ((unsigned long long)ihi << 32) | ilo;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) fmax_out = fmaxf(fmax_out, __shfl_xor(fmax_out, o));
+    if (lane == 0) red[8 + w] = fmax_out;
+    __syncthreads();                                                      // (4) fill
+    const float fill = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
+
+    // dL/dHR = k0 (sum_ac dl_ac ea_a(row) ea_c(col) - mn sum dl) off the plateau (the plateau value is a constant)
+    const float k0 = 1e-4f / (1.0f - mn);
+    float dlsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) dlsum += dl[t];
+    float s0 = 0.f, da = 0.f;
+    {
+      float pa[4][4], pa2[4][4], qd[4][4];        // qd[nt][a] = sum_c dl[a][c] ea_c(col)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int xc = 32 * nt + li_o < HS ? 32 * nt + li_o : HS - 1;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          pa[nt][a] = 0.f;
+          pa2[nt][a] = 0.f;
+          qd[nt][a] = dl[a * 4 + 0] * ea[xc] + dl[a * 4 + 1] * ea[100 + xc] + dl[a * 4 + 2] * ea[200 + xc] +
+                      dl[a * 4 + 3] * ea[300 + xc];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int yy = yb + (r & 3) + 8 * (r >> 2);
+        const int yc = yy < HS - 1 ? yy : HS - 1;
+        const float e[4] = {ea[yc], ea[100 + yc], ea[200 + yc], ea[300 + yc]};
+        const float e2[4] = {ea2[yc], ea2[100 + yc], ea2[200 + yc], ea2[300 + yc]};
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const unsigned pm = 0u - (unsigned)((plateau >> (nt * 16 + r)) & 1ull);
+          const float hrv = acc[nt][r];                         // 0 outside the image
+          const float v = bitsel(pm, fill, hrv);
+          s0 += v;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            pa[nt][a] = fmaf(e[a], v, pa[nt][a]);
+            pa2[nt][a] = fmaf(e2[a], v, pa2[nt][a]);
+          }
+          const float gsum = e[0] * qd[nt][0] + e[1] * qd[nt][1] + e[2] * qd[nt][2] + e[3] * qd[nt][3];
+          da = fmaf(k0 * (gsum - mn * dlsum), bitsel(pm, 0.f, hrv), da);
+        }
+        asm volatile("" ::: "memory");     // keep the row's LDS reads and arithmetic in its iteration (hipcc
+        __builtin_amdgcn_sched_barrier(0); // otherwise regroups the unrolled rows and spills hundreds of values)
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          pa[nt][a] += __shfl_xor(pa[nt][a], 32);
+          pa2[nt][a] += __shfl_xor(pa2[nt][a], 32);
+          if (h == 0 && 32 * nt + li < HS) {
+            Pp[(w * 4 + a) * 100 + 32 * nt + li] = pa[nt][a];
+            P2p[(w * 4 + a) * 100 + 32 * nt + li] = pa2[nt][a];
+          }
+        }
+    }
+
+    // ---- dhb = H Rg + G Rh
+    zero_acc(acc);
+    gemm_toeplitz_rt(acc, Th, RT, laneT, w, h, li);                       // scale sH * sRg
+    __syncthreads();                                                      // (5) every wave is done with Rg
+    {
+      // the depth rows again (L2): their fp16 planes were not kept across the first epilogue
+      load_depth(b);
+      f16x8 a_hi[7], a_lo[7];
+#pragma unroll
+      for (int ks = 0; ks < 7; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = dA[ks][j >> 2][j & 3] * sD;
+          const _Float16 hi = (_Float16)t;
+          a_hi[ks][j] = hi;
+          a_lo[ks][j] = (_Float16)(t - (float)hi);
+        }
+      f32x16 accr[4];
+      zero_acc(accr);
+      gemm_rows_toeplitz(accr, a_hi, a_lo, Th, laneT);
+      store_rt(accr, sRh / (sD * sH), RT, w, h, li);
+    }
+    __syncthreads();                                                      // (6) R^T = Rh
+    {
+      const float resc = (G_SCALE * sRh) / (sH * sRg);                    // exact power of two
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] *= resc;
+    }
+    gemm_toeplitz_rt(acc, Tg, RT, laneT, w, h, li);                       // scale 2^13 * sRh
+    if (b + (int)gridDim.x < B) load_depth(b + gridDim.x);
+
+    float db = 0.f;
+    {
+      const float f3 = 1.0f / (G_SCALE * sRh);
+      float qd[4][4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int xc = 32 * nt + li_o < HS ? 32 * nt + li_o : HS - 1;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+          qd[nt][a] = dl[a * 4 + 0] * ea[xc] + dl[a * 4 + 1] * ea[100 + xc] + dl[a * 4 + 2] * ea[200 + xc] +
+                      dl[a * 4 + 3] * ea[300 + xc];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int yy = yb + (r & 3) + 8 * (r >> 2);
+        const int yc = yy < HS - 1 ? yy : HS - 1;
+        const float e[4] = {ea[yc], ea[100 + yc], ea[200 + yc], ea[300 + yc]};
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const unsigned um = 0u - (unsigned)(((inside & ~plateau) >> (nt * 16 + r)) & 1ull);
+          const float gsum = e[0] * qd[nt][0] + e[1] * qd[nt][1] + e[2] * qd[nt][2] + e[3] * qd[nt][3];
+          db = fmaf(k0 * (gsum - mn * dlsum), bitsel(um, acc[nt][r] * f3, 0.f), db);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    double s0d = (double)s0, dad = (double)da, dbd = (double)db;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s0d += __shfl_xor(s0d, o);
+      dad += __shfl_xor(dad, o);
+      dbd += __shfl_xor(dbd, o);
+    }
+    if (lane == 0) { redd[w] = s0d; redd[4 + w] = dad; redd[8 + w] = dbd; }
+    __syncthreads();                                                      // (7) partial sums, pooling partials
+    const double S0 = (redd[0] + redd[1]) + (redd[2] + redd[3]);
+    double dg = 0.0;
+    {
+      const int pair = tid >> 4, sub = tid & 15, a = pair >> 2, c = pair & 3;
+      float S = 0.f, Sd = 0.f;      // S_ac = sum HR m_ac ; Sd = sum HR m_ac d^2_ac
+      for (int x = sub; x < HS; x += 16) {
+        const float p = (Pp[(0 * 4 + a) * 100 + x] + Pp[(1 * 4 + a) * 100 + x]) +
+                        (Pp[(2 * 4 + a) * 100 + x] + Pp[(3 * 4 + a) * 100 + x]);
+        const float p2 = (P2p[(0 * 4 + a) * 100 + x] + P2p[(1 * 4 + a) * 100 + x]) +
+                         (P2p[(2 * 4 + a) * 100 + x] + P2p[(3 * 4 + a) * 100 + x]);
+        S = fmaf(p, ea[c * 100 + x], S);
+        Sd = fmaf(p2, ea[c * 100 + x], fmaf(p, ea2[c * 100 + x], Sd));
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        S += __shfl_xor(S, o);
+        Sd += __shfl_xor(Sd, o);
+      }
+      if (sub == 0) {
+        const double gm = gamma, mnd = mn;
+        const double mnp = mnd * 100.0 / (gm * gm);                 // d mn / d gamma
+        const double dS = (double)Sd * (double)KM / (gm * gm);      // d S_ac / d gamma
+        const double num = (double)S - mnd * S0, den = 1.0 - mnd;
+        const double dLR = 1e-4 * ((dS - mnp * S0) * den + num * mnp) / (den * den);
+        dg = (double)dl[pair] * dLR;
+      }
+      // the four pairs of a wave sit in lanes 0, 16, 32, 48
+      dg += __shfl_xor(dg, 16);
+      dg += __shfl_xor(dg, 32);
+      if (lane == 0) redd[12 + w] = dg;
+    }
+    __syncthreads();                                                      // (8)
+    if (tid == 0) {
+      const double DA = (redd[4] + redd[5]) + (redd[6] + redd[7]);
+      const double DB = (redd[8] + redd[9]) + (redd[10] + redd[11]);
+      const double DG = (redd[12] + redd[13]) + (redd[14] + redd[15]);
+      dab[b * 3 + 0] = (float)(DA / (double)alpha);
+      // raw = sum D e^{-c r^2}: d raw / d beta = dhb * 2 Kp / beta^3 ; HR = alpha * raw
+      dab[b * 3 + 1] = (float)(DB * (double)alpha * 2.0 * (double)KP / ((double)beta * beta * beta));
+      dab[b * 3 + 2] = (float)DG;
+    }
+    __syncthreads();                                                      // (9) LDS free for the next sample
+  }
+}
+
 extern "C" int tpsf_forward(const float* depth, const float* alpha_beta, float* HR, float* LR_deg, float* psf,
                             int B, void* stream) {
   if (!depth || !alpha_beta || !HR || !LR_deg || !psf || B <= 0) return TSR_ERR_ARG;
   const int grid = B < 512 ? B : 512;          // 2 resident workgroups x 256 CUs, persistent over the batch
   hipLaunchKernelGGL(tpsf_fwd_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, depth, alpha_beta, HR,
                      LR_deg, psf, B);
+  return tsr_check_launch();
+}
+
+extern "C" int tpsf_backward(const float* depth, const float* alpha_beta, const float* dLR_deg, float* d_alpha_beta,
+                             int B, void* stream) {
+  if (!depth || !alpha_beta || !dLR_deg || !d_alpha_beta || B <= 0) return TSR_ERR_ARG;
+  const int grid = B < 256 ? B : 256;          // one persistent workgroup per CU
+  hipLaunchKernelGGL(tpsf_bwd_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, depth, alpha_beta, dLR_deg,
+                     d_alpha_beta, B);
   return tsr_check_launch();
 }
