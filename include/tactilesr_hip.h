@@ -237,6 +237,10 @@ int tpsf_backward(const float* depth, const float* alpha_beta, const float* dLR_
  * 1 ReLU, 2 Softplus: the nn.Linear layers of MLP_layer (:26-36) and their backward GEMMs. */
 int tsr_sgemm(const float* A, long long sa0, long long sa1, const float* B, long long sb0, long long sb1,
               const float* bias, float* C, int M, int N, int K, int act, void* stream);
+/* Split-K form for the reductions over the batch (dW = dy^T x, db = 1^T dy of the same layers): slab[s][M][N]
+ * receives the partial product of K range s (no bias / activation); add the slabs with tsr_reduce_splits. */
+int tsr_sgemm_splitk(const float* A, long long sa0, long long sa1, const float* B, long long sb0, long long sb1,
+                     float* slab, int M, int N, int K, int nsplit, void* stream);
 /* dy *= act'(.) in place from the stored activation output (1 ReLU, 2 Softplus). */
 int tsr_act_bwd(float* dy, const float* y, long long n, int mode, void* stream);
 

@@ -370,14 +370,16 @@ def tpsf_mlp(p: Params, x: torch.Tensor) -> torch.Tensor:
     return F.softplus(F.linear(h, p["MLP_layer.7.weight"], p["MLP_layer.7.bias"]))
 
 
-def tpsf_forward(p: Params, x: torch.Tensor, depth: torch.Tensor, geom=None):
-    """tPSFNet.forward, model/tPSFNet.py:102-127 (+ :78-100, :129-141): per sample
-    psf = a*exp(-sdf^2/b^2); HR = conv2d(ZeroPad48(depth), psf, padding=1); plateau
-    fill (HR[mask] = max(HR outside mask)); 16 Gaussian-masked sums * 1e-4."""
-    assert x.shape[0] == depth.shape[0], "Batch size of LR tactile and depth should be the same!"
+def tpsf_forward_from_ab(ab: torch.Tensor, depth: torch.Tensor, geom=None):
+    """The PSF forward model for given (alpha, beta, gamma) rows `ab` (B,3) and depth (B,1,100,100) or (B,100,100),
+    model/tPSFNet.py:78-100,102-127,129-141: per sample psf = a*exp(-sdf^2/b^2); HR = conv2d(ZeroPad48(depth), psf,
+    padding=1); plateau fill (HR[mask] = max(HR outside mask)); 16 Gaussian-masked sums * 1e-4.  Runs in the dtype
+    of `ab` (tests use float64 as the yardstick)."""
     psf_sdf, mask_sdf = geom if geom is not None else tpsf_geometry()
-    ab = tpsf_mlp(p, x)
-    B = x.shape[0]
+    psf_sdf, mask_sdf = psf_sdf.to(ab.dtype), mask_sdf.to(ab.dtype)
+    if depth.dim() == 3:
+        depth = depth.unsqueeze(1)
+    B = ab.shape[0]
     HRs, LRs, psfs = [], [], []
     for i in range(B):
         psf = ab[i, 0] * torch.exp(-psf_sdf ** 2 / (ab[i, 1] ** 2))
@@ -394,7 +396,15 @@ def tpsf_forward(p: Params, x: torch.Tensor, depth: torch.Tensor, geom=None):
         HRs.append(HR)
         LRs.append(LRd.view(1, 1, 4, 4))
         psfs.append(psf)
-    return torch.cat(HRs), torch.cat(LRs), torch.cat(psfs), ab.view(B, 1, 3)
+    return torch.cat(HRs), torch.cat(LRs), torch.cat(psfs)
+
+
+def tpsf_forward(p: Params, x: torch.Tensor, depth: torch.Tensor, geom=None):
+    """tPSFNet.forward, model/tPSFNet.py:102-127: MLP -> (alpha, beta, gamma) -> the PSF forward model above."""
+    assert x.shape[0] == depth.shape[0], "Batch size of LR tactile and depth should be the same!"
+    ab = tpsf_mlp(p, x)
+    HR, LRd, psf = tpsf_forward_from_ab(ab, depth, geom)
+    return HR, LRd, psf, ab.view(x.shape[0], 1, 3)
 
 
 def tpsf_train_cal_loss(p: Params, LR_raw: torch.Tensor, depth: torch.Tensor, scale_num=100.0,

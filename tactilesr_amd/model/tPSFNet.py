@@ -5,7 +5,8 @@ constructor, attributes (``gama``, ``perception_scale``, ``MLP_layer``, ``PSF_sd
 ``LR_masking_sdf``), ``state_dict`` keys (``MLP_layer.{1,3,5,7}.{weight,bias}``), init
 (Linear weights N(0, 0.03), default biases; reference :57-65) and the 4-tuple return of
 ``forward(x, depth)`` -> ``(HR, LR_deg, psf, alphaBeta)`` (:102-127).  The python loop over the
-batch is replaced by one batched HIP launch (separable 99-tap PSF convolution in LDS), and the
+batch is replaced by one batched HIP launch (the separable PSF convolution as two Toeplitz GEMMs on the
+matrix cores, csrc/tpsf_mfma.hip), the MLP runs on an fp32-MFMA SGEMM, and the
 whole forward is one ``autograd.Function`` so ``Trainer_tPSF.train_cal_loss``'s
 ``MSE(LR[:,2:3], LR_deg).backward()`` (train/tPSFNet_train.py:180-190) reaches the MLP weights.
 No CPU fallback.
@@ -27,6 +28,17 @@ def _linear(x, w, b, act):
     y = torch.empty(M, N, dtype=torch.float32, device=x.device)
     call("tsr_sgemm", ptr(x), _L(K), _L(1), ptr(w), _L(1), _L(K), ptr(b), ptr(y), _I(M), _I(N), _I(K), _I(act), stream())
     return y
+
+
+def _splitk(a, sa0, sa1, b, sb0, sb1, out, M, N, K):
+    """out[M][N] = sum_k a(i,k) b(k,j) with K split over enough workgroups to fill the chip; the partial slabs
+    are added in a fixed order (tsr_reduce_splits)."""
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    ns = max(1, min((1024 + tiles - 1) // tiles, (K + 63) // 64))
+    slab = torch.empty(ns * M * N, dtype=torch.float32, device=out.device)
+    call("tsr_sgemm_splitk", ptr(a), _L(sa0), _L(sa1), ptr(b), _L(sb0), _L(sb1), ptr(slab), _I(M), _I(N), _I(K), _I(ns),
+         stream())
+    call("tsr_reduce_splits", ptr(slab), ptr(out), _L(M * N), _I(ns), _lib.c_float(1.0), stream())
 
 
 class _TPSFFn(torch.autograd.Function):
@@ -64,12 +76,10 @@ class _TPSFFn(torch.autograd.Function):
             call("tsr_act_bwd", ptr(dy), ptr(h[i + 1]), _L(dy.numel()), _I(1 if i < 3 else 2), stream())
             w = ws[i].detach().contiguous()
             N, K = w.shape
-            gw = torch.empty(N, K, dtype=torch.float32, device=d.device)      # dW = dy^T x
-            call("tsr_sgemm", ptr(dy), _L(1), _L(N), ptr(h[i]), _L(K), _L(1), ptr(None), ptr(gw), _I(N), _I(K), _I(B),
-                 _I(0), stream())
+            gw = torch.empty(N, K, dtype=torch.float32, device=d.device)      # dW = dy^T x   (reduction over the batch)
+            _splitk(dy, 1, N, h[i], K, 1, gw, N, K, B)
             gb = torch.empty(1, N, dtype=torch.float32, device=d.device)      # db = 1^T dy
-            call("tsr_sgemm", ptr(ones), _L(1), _L(1), ptr(dy), _L(N), _L(1), ptr(None), ptr(gb), _I(1), _I(N), _I(B),
-                 _I(0), stream())
+            _splitk(ones, 1, 1, dy, N, 1, gb, 1, N, B)
             grads = [gw, gb.view(N)] + grads
             if i > 0:
                 dx = torch.empty(B, K, dtype=torch.float32, device=d.device)  # dx = dy W

@@ -84,3 +84,70 @@ def test_dataset_generator_matches_batch1_loop(tmp_path):
             assert torch.equal(it["HR"], HR[0].cpu()) and torch.equal(it["LR_degrade"], LRd[0].cpu())
             assert torch.equal(it["alphaBeta"], ab[0, 0].cpu()) and it["depth"].shape == (1, 100, 100)
             assert torch.allclose(it["LR"], LR_raw[i] / 100)
+
+
+@pytest.mark.parametrize("M,N,K,act,ta,tb", [
+    (37, 3, 256, 2, False, True), (130, 256, 48, 1, False, True), (64, 64, 16, 0, False, False),
+    (100, 70, 33, 0, True, False), (1, 129, 300, 0, False, False), (257, 65, 1030, 1, True, True),
+])
+def test_sgemm_mfma_strides_activations_and_splitk(M, N, K, act, ta, tb):
+    """tsr_sgemm (fp32 matrix cores) with every stride form the MLP uses, ragged tiles, the three epilogues,
+    and the split-K form + tsr_reduce_splits -- against torch fp64."""
+    from tactilesr_amd._lib import call, ptr, stream, c_int as I, c_longlong as L, c_float as Fl
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(K, M, generator=g).cuda() if ta else torch.randn(M, K, generator=g).cuda()
+    Bm = torch.randn(N, K, generator=g).cuda() if tb else torch.randn(K, N, generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    sa = (1, M) if ta else (K, 1)
+    sb = (1, K) if tb else (N, 1)
+    A64 = (A.t() if ta else A).double().cpu()
+    B64 = (Bm.t() if tb else Bm).double().cpu()
+    ref = A64 @ B64 + bias.double().cpu()
+    if act == 1:
+        ref = ref.clamp_min(0)
+    elif act == 2:
+        ref = torch.nn.functional.softplus(ref)
+    C = torch.empty(M, N, device="cuda")
+    call("tsr_sgemm", ptr(A), L(sa[0]), L(sa[1]), ptr(Bm), L(sb[0]), L(sb[1]), ptr(bias), ptr(C), I(M), I(N), I(K), I(act),
+         stream())
+    assert relerr(C, ref) < 2e-6
+    for ns in (1, 3, 8):
+        slab = torch.full((ns, M, N), float("nan"), device="cuda")
+        call("tsr_sgemm_splitk", ptr(A), L(sa[0]), L(sa[1]), ptr(Bm), L(sb[0]), L(sb[1]), ptr(slab), I(M), I(N), I(K), I(ns),
+             stream())
+        out = torch.empty(M, N, device="cuda")
+        call("tsr_reduce_splits", ptr(slab), ptr(out), L(M * N), I(ns), Fl(1.0), stream())
+        assert relerr(out, A64 @ B64) < 2e-6, ns
+
+
+def test_tpsf_kernels_wide_dynamic_range_batch():
+    """MFMA Toeplitz-GEMM forward/backward (two scaled fp16 planes) against an fp64 torch restatement on inputs the
+    golden fixture does not reach: signed depth, tiny and large magnitudes, narrow and wide PSFs, 300 samples so that
+    the persistent workgroups loop."""
+    from tactilesr_amd._lib import call, ptr, stream, c_int as I
+    B = 300
+    g = torch.Generator().manual_seed(5)
+    depth = torch.rand(B, 100, 100, generator=g) * 10
+    depth[1] = depth[1] * 1e-3
+    depth[2] = (depth[2] - 5) * 40                  # signed, large
+    depth[3] = 0
+    depth[3, 40:60, 40:60] = 7.5                    # a real plateau
+    ab = torch.rand(B, 3, generator=g) * torch.tensor([1.0, 3.0, 2.0]) + torch.tensor([0.2, 0.25, 0.6])
+    dl = torch.randn(B, 16, generator=g)
+    d, a_, dl_ = depth.cuda(), ab.cuda(), dl.cuda()
+    HR = torch.empty(B, 1, 100, 100, device="cuda")
+    LRd = torch.empty(B, 16, device="cuda")
+    psf = torch.empty(B, 1, 99, 99, device="cuda")
+    dab = torch.empty(B, 3, device="cuda")
+    call("tpsf_forward", ptr(d), ptr(a_), ptr(HR), ptr(LRd), ptr(psf), I(B), stream())
+    call("tpsf_backward", ptr(d), ptr(a_), ptr(dl_), ptr(dab), I(B), stream())
+    n = 24                                          # fp64 restatement (oracle functions) on a subset
+    ab64 = ab[:n].double().requires_grad_(True)
+    HR64, LR64, psf64 = O.tpsf_forward_from_ab(ab64, depth[:n].double())
+    (LR64.reshape(n, 16) * dl[:n].double()).sum().backward()
+    for i in range(n):
+        assert relerr(HR[i], HR64[i]) < 1e-5, i
+        assert relerr(psf[i], psf64[i]) < 1e-5, i
+    assert relerr(LRd[:n], LR64.reshape(n, 16)) < 1e-5
+    assert relerr(dab[:n], ab64.grad) < 2e-5
+    assert torch.isfinite(HR).all() and torch.isfinite(dab).all()
