@@ -25,6 +25,7 @@
 #include "conv_epilogue.h"
 #include "tactilesr_hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -63,7 +64,11 @@ constexpr int row_slots(int hh, int pixs, int rmod) {
 
 // WN = waves across C_out: 2 -> 2 images per workgroup, wave = (image, C_out half); 1 -> 4 images per workgroup, wave
 // = image x all C_out (used for C_out = 64, where a half would leave a single 32-wide block per wave).
-template <int KS, int COUT, int NS, bool EXT, bool F16, int WN>
+// DBH = double-buffered halo (3x3 kernels, C_in/16 even): the next channel block's slab is staged into the other
+// halo buffer in the middle of the current block (loads at its first step, conversion + LDS writes at its
+// second-to-last), so a block boundary costs no extra barrier pair and the first tap's fragments are prefetched
+// like any other tap's.  Blocks are processed in pairs: buffer and fragment-set parity stay compile-time.
+template <int KS, int COUT, int NS, bool EXT, bool F16, int WN, bool DBH = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArgs a) {
   typedef typename Plane<F16>::T PT;
   typedef typename Plane<F16>::V8 PV8;
@@ -90,9 +95,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
   constexpr int PA[6] = {NS == 3 ? 2 : (NS == 2 ? 1 : 0), NS == 3 ? 0 : 0, NS == 3 ? 1 : 0, 1, 0, 0};
   constexpr int PB[6] = {0, NS == 3 ? 2 : (NS == 2 ? 1 : 0), NS == 3 ? 1 : 0, 0, 1, 0};
 
-  __shared__ __attribute__((aligned(16))) char lds[HALO_B + 3 * WSLAB_B];
+  static_assert(!DBH || (NSTEP >= 3 && (T & 1)), "double-buffered halo needs >= 3 steps per block and an odd tap count");
+  constexpr int NHB = DBH ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) char lds[NHB * HALO_B + 3 * WSLAB_B];
   char* halo = lds;
-  char* wbuf = lds + HALO_B;        // 3-slot ring: slab s lives in slot s % 3
+  char* wbuf = lds + NHB * HALO_B;  // 3-slot ring: slab s lives in slot s % 3
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
       if (st_src[k] >= 0) hv[k] = *(const f32x4*)(inc + st_src[k]);
     }
   };
-  auto store_halo = [&](const f32x4* hv, int c) {
+  auto store_halo = [&](const f32x4* hv, int c, int hb) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       if (st_dst[k] >= 0) {
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
             bq[j] = (PT)v[j];
             v[j] -= (float)bq[j];
           }
-          *(PV4*)(halo + st_dst[k] + p * 32) = bq;
+          *(PV4*)(halo + hb * HALO_B + st_dst[k] + p * 32) = bq;
         }
       }
     }
@@ -232,12 +239,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
       if ((v + 1) * 256 <= WITEMS || tid + v * 256 < WITEMS) ((f32x4*)wb_)[tid + v * 256] = wreg[v]; \
   }
   // fragments of one (block, tap) step -> register set `set` (compile-time index after unrolling)
-#define LOAD_FRAGS(set, slot, tapoff, kh_, kw_)                                          \
+#define LOAD_FRAGS(set, slot, tapoff, kh_, kw_, hb_)                                     \
   {                                                                                      \
     const char* wb_ = wbuf + (slot) * WSLAB_B + (tapoff) * WTAP_B;                       \
     _Pragma("unroll") for (int p = 0; p < NS; ++p) {                                     \
       _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                   \
-        fa[set][p][mb] = *(const PV8*)(halo + laneA + (4 * mb + (kh_)) * ROWB + (kw_) * PIXB + p * 32); \
+        fa[set][p][mb] = *(const PV8*)(halo + (hb_) * HALO_B + laneA + (4 * mb + (kh_)) * ROWB + (kw_) * PIXB + p * 32); \
       _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                  \
         fb[set][p][nb] = *(const PV8*)(wb_ + laneB + p * (2 * COUT * 16) + nb * (32 * 16)); \
     }                                                                                    \
@@ -249,29 +256,37 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
   LOAD_W(0);
   STORE_W(0);
   if (S > 1) { LOAD_W(1); STORE_W(1); }
-  store_halo(hv, 0);
+  store_halo(hv, 0, 0);
   if (S > 2) LOAD_W(2);
   __syncthreads();
 
   PV8 fa[2][NS][2], fb[2][NS][NB];        // ping-pong fragment sets, statically indexed
-  LOAD_FRAGS(0, 0, 0, 0, 0);
+  LOAD_FRAGS(0, 0, 0, 0, 0, 0);
 
   int s = 0;
   int slot = 0;                            // s % 3, kept incrementally
-  for (int c = 0; c < nchunk; ++c) {
+  // one channel block; P = parity of the block (compile time in DBH mode: halo buffer and first fragment set)
+  auto block = [&](int c, auto parity) {
+    constexpr int P = decltype(parity)::value;
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
       const int slot1 = slot == 2 ? 0 : slot + 1;
       const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
+      if (DBH && st == 0 && c + 1 < nchunk) load_halo(c + 1, hv);   // next block's slab: in flight for NSTEP-2 steps
 #pragma unroll
       for (int tt = 0; tt < TPS; ++tt) {
         const int t = st * TPS + tt;
         if (t < T) {
-          const int cur = t & 1, nxt = cur ^ 1;
+          const int cur = (t + P * T) & 1, nxt = cur ^ 1;
+          constexpr bool PF = true;
           if (t + 1 < T) {        // next tap's fragments: its weights were published by an earlier barrier
             const int nkh = (t + 1) / KS, nkw = (t + 1) - nkh * KS;
-            if (tt + 1 < TPS) { LOAD_FRAGS(nxt, slot, tt + 1, nkh, nkw); }
-            else { LOAD_FRAGS(nxt, slot1, 0, nkh, nkw); }
+            if (tt + 1 < TPS) { LOAD_FRAGS(nxt, slot, tt + 1, nkh, nkw, P); }
+            else { LOAD_FRAGS(nxt, slot1, 0, nkh, nkw, P); }
+          } else if (DBH) {
+            // first tap of the next block out of the other halo buffer (published two barriers ago; after the
+            // last block this reads stale but mapped LDS and the values are dropped)
+            LOAD_FRAGS(nxt, slot1, 0, 0, 0, P ^ 1);
           } else if (c + 1 < nchunk) {
             load_halo(c + 1, hv); // next block's slab: global loads fly under this tap's MFMAs
           }
@@ -283,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
               for (int nb = 0; nb < NB; ++nb)
                 acc[mb][nb] = Plane<F16>::mfma(fa[cur][PA[6 - NPROD + q]][mb], fb[cur][PB[6 - NPROD + q]][nb],
                                                acc[mb][nb]);
-          if (t + 1 < T) {
+          if (PF && (t + 1 < T || DBH)) {
             // interleave the next tap's fragment reads with this tap's MFMAs (hipcc otherwise sinks all ds_reads
             // below the MFMA block, exposing their latency in front of the barrier's lgkmcnt(0) every step)
             constexpr int NRD = NS * (2 + NB), NMF = NPROD * 2 * NB, PER = NMF / NRD > 0 ? NMF / NRD : 1;
@@ -295,19 +310,26 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
           }
         }
       }
+      if (DBH && st == NSTEP - 2 && c + 1 < nchunk) store_halo(hv, c + 1, P ^ 1);   // other buffer: last read a block ago
       if (s + 2 < S) STORE_W(slot2);           // slot (s+2)%3 was last read one barrier ago
       if (s + 3 < S) LOAD_W(s + 3);
-#ifndef TSR_EXPERIMENT_NOBAR
       __syncthreads();
-#endif
-      if (st + 1 == NSTEP && c + 1 < nchunk) {
-        store_halo(hv, c + 1);  // every wave is past its last read of the old slab (barrier above)
+      if (!DBH && st + 1 == NSTEP && c + 1 < nchunk) {
+        store_halo(hv, c + 1, 0);  // every wave is past its last read of the old slab (barrier above)
         __syncthreads();
-        LOAD_FRAGS(0, slot1, 0, 0, 0);         // T is odd: a block always starts on fragment set 0
+        LOAD_FRAGS(0, slot1, 0, 0, 0, 0);      // T is odd: a block always starts on fragment set 0
       }
       ++s;
       slot = slot1;
     }
+  };
+  if (DBH) {
+    for (int c = 0; c < nchunk; c += 2) {      // launch guarantees an even block count
+      block(c, std::integral_constant<int, 0>());
+      block(c + 1, std::integral_constant<int, 1>());
+    }
+  } else {
+    for (int c = 0; c < nchunk; ++c) block(c, std::integral_constant<int, 0>());
   }
 #undef LOAD_W
 #undef STORE_W
@@ -405,7 +427,13 @@ static int launch_bf16s(const ConvArgs& a, hipStream_t st) {
   constexpr int WN = (!EXT && COUT == 64 && F16 && KS > 1) ? 1 : 2;
   constexpr int IMG = 4 / WN;
   const int grid = ((a.B + IMG - 1) / IMG) * a.tiles_x * a.tiles_y;
-  hipLaunchKernelGGL((conv_mfma_split16_kernel<KS, COUT, NS, EXT, F16, WN>), dim3(grid), dim3(256), 0, st, a);
+  if constexpr (KS == 3 && !(COUT == 64 && WN == 1)) {      // (4-image workgroups: two slabs would not leave 2 per CU)
+    if (((a.cin >> 4) & 1) == 0) {     // double-buffered halo (needs the channel blocks in pairs)
+      hipLaunchKernelGGL((conv_mfma_split16_kernel<KS, COUT, NS, EXT, F16, WN, true>), dim3(grid), dim3(256), 0, st, a);
+      return tsr_check_launch();
+    }
+  }
+  hipLaunchKernelGGL((conv_mfma_split16_kernel<KS, COUT, NS, EXT, F16, WN, false>), dim3(grid), dim3(256), 0, st, a);
   return tsr_check_launch();
 }
 

@@ -25,7 +25,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define KM (100.0f / 15138.0f)     // 10^2 / (87^2 + 87^2)
 
 namespace {
-constexpr int TC_STRIDE = 544;              // bytes per shifted copy of the Toeplitz table (272 halves; 34 chunks)
+constexpr int TC_STRIDE = 480;              // bytes per shifted copy of the Toeplitz table (240 halves; 30 chunks)
 constexpr int T_PLANE = 8 * TC_STRIDE;      // 8 copies, copy r holds T[m + r]
 constexpr int T_OFF = 128;                  // T[i] = g(49 + i - T_OFF)
 constexpr int RT_STRIDE = 208;              // bytes per row of R^T (104 halves; 13 chunks: conflict-free b128 reads)
@@ -160,7 +160,10 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
 }
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void tpsf_fwd_mfma_kernel(const float* __restrict__ depth,
+#ifndef TPSF_FWD_OCC
+#define TPSF_FWD_OCC 2      // resident workgroups per CU the forward kernel is compiled for
+#endif
+__global__ __launch_bounds__(256, TPSF_FWD_OCC) void tpsf_fwd_mfma_kernel(const float* __restrict__ depth,
                                                                const float* __restrict__ ab,   // (B,3)
                                                                float* __restrict__ HR, float* __restrict__ LRd,
                                                                float* __restrict__ psf, int B) {
@@ -168,14 +171,14 @@ __global__ __launch_bounds__(256, 2) void tpsf_fwd_mfma_kernel(const float* __re
   __shared__ __attribute__((aligned(16))) char RT[2 * RT_PLANE + 16]; // R^T planes (+ finite tail for the K over-read)
   __shared__ float g[128];        // g[0..98]
   __shared__ float ea[400];       // [4][100] mask factors
-  __shared__ __attribute__((aligned(16))) unsigned char pmask[128 * 16];   // plateau bit per pixel: row y, bit x
+  __shared__ __attribute__((aligned(16))) unsigned char pmask[HS * 16];   // plateau bit per pixel: row y, bit x
   __shared__ float red[16];
-  static_assert(2 * T_PLANE >= 4 * 4 * 128 * 4, "pooling partials alias the table");
+  static_assert(2 * T_PLANE >= 4 * 4 * HS * 4, "pooling partials alias the table");
 
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, li = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index, uniform
   if (tid < 4) ((float*)(RT + 2 * RT_PLANE))[tid] = 0.f;
-  for (int i = tid; i < 128 * 4; i += 256) ((unsigned*)pmask)[i] = 0u;    // bytes x >= 104 are never written again
+  for (int i = tid; i < HS * 4; i += 256) ((unsigned*)pmask)[i] = 0u;    // bytes x >= 104 are never written again
   const int y = 32 * w + li;                       // image row of this lane in the A (and GEMM2 A) layout
   const int q8 = (li + 7) & ~7, rcopy = q8 - li;   // table copy whose 16-B chunks line up with this lane's diagonal
   const int laneT = rcopy * TC_STRIDE + 2 * (T_OFF + 8 * h - q8);
@@ -193,12 +196,17 @@ __global__ __launch_bounds__(256, 2) void tpsf_fwd_mfma_kernel(const float* __re
         if (y < HS && 16 * ks + 8 * h + 4 * q < HS) dA[ks][q] = *(const f32x4*)(dp + 16 * ks + 4 * q);
       }
   };
+#if TPSF_FWD_OCC == 2
   if ((int)blockIdx.x < B) load_depth(blockIdx.x);
+#endif
 
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const float alpha = ab[b * 3 + 0], beta = ab[b * 3 + 1], gamma = ab[b * 3 + 2];
     const float cpsf = KP / (beta * beta);
     const float cm = KM / gamma;
+#if TPSF_FWD_OCC != 2
+    load_depth(b);
+#endif
 
     float mabs = 0.f, mx = -INFINITY;
 #pragma unroll
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void tpsf_fwd_mfma_kernel(const float* __re
         a_hi[ks][j] = hi;
         a_lo[ks][j] = (_Float16)(t - (float)hi);
       }
-      if (16 * ks + 8 * h < 104) pmask[y * 16 + 2 * ks + h] = (unsigned char)bits;   // rows / columns >= 100: depth 0
+      if (16 * ks + 8 * h < 104 && y < HS) pmask[y * 16 + 2 * ks + h] = (unsigned char)bits;
     }
     __syncthreads();                                                      // (2) table copies
 
@@ -272,7 +280,9 @@ __global__ __launch_bounds__(256, 2) void tpsf_fwd_mfma_kernel(const float* __re
     zero_acc(acc);
     gemm_toeplitz_rt(acc, Tc, RT, laneT, w, h, li);
 
+#if TPSF_FWD_OCC == 2
     if (b + (int)gridDim.x < B) load_depth(b + gridDim.x);   // the A planes are dead: their registers take the next rows
+#endif
 
     // ---- plateau fill: HR[mask] = max(HR outside mask, 0), mask = depth > depth.max() - 1e-3
     // (lane constants re-derived from an opaque copy per sample: hipcc would otherwise hoist 64 loop-invariant
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void tpsf_fwd_mfma_kernel(const float* __re
     for (int r = 0; r < 16; ++r) {
       const int yy = yb + (r & 3) + 8 * (r >> 2);
       const unsigned vy = ((unsigned)(yy - HS) >> 31);             // 1 inside the image
-      const uint4 mrow = *(const uint4*)(pmask + yy * 16);
+      const uint4 mrow = *(const uint4*)(pmask + (yy < HS - 1 ? yy : HS - 1) * 16);
       const unsigned mw[4] = {mrow.x, mrow.y, mrow.z, mrow.w};
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void tpsf_fwd_mfma_kernel(const float* __re
 
     // ---- HR store + separable Gaussian-masked pooling partials  P[a][x] = sum_y ea[a][y] HR[y][x]
     float* hp = HR + (size_t)b * NPIX + li_o;
-    float* Ppart = (float*)Tc;       // [4 waves][4 a][128 x]
+    float* Ppart = (float*)Tc;       // [4 waves][4 a][100 x]
     float s0 = 0.f;
     float pa[4][4];
 #pragma unroll
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void tpsf_fwd_mfma_kernel(const float* __re
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         pa[nt][a] += __shfl_xor(pa[nt][a], 32);
-        if (h == 0) Ppart[(w * 4 + a) * 128 + 32 * nt + li] = pa[nt][a];
+        if (h == 0 && 32 * nt + li < HS) Ppart[(w * 4 + a) * HS + 32 * nt + li] = pa[nt][a];
       }
     double s0d = (double)s0;
 #pragma unroll
@@ -357,8 +367,8 @@ __global__ __launch_bounds__(256, 2) void tpsf_fwd_mfma_kernel(const float* __re
       const int pair = tid >> 4, sub = tid & 15, a = pair >> 2, c = pair & 3;
       float s = 0.f;
       for (int x = sub; x < HS; x += 16) {
-        const float p = (Ppart[(0 * 4 + a) * 128 + x] + Ppart[(1 * 4 + a) * 128 + x]) +
-                        (Ppart[(2 * 4 + a) * 128 + x] + Ppart[(3 * 4 + a) * 128 + x]);
+        const float p = (Ppart[(0 * 4 + a) * HS + x] + Ppart[(1 * 4 + a) * HS + x]) +
+                        (Ppart[(2 * 4 + a) * HS + x] + Ppart[(3 * 4 + a) * HS + x]);
         s = fmaf(p, ea[c * 100 + x], s);
       }
 #pragma unroll
@@ -721,7 +731,7 @@ __global__ __launch_bounds__(256, 1) void tpsf_bwd_mfma_kernel(const float* __re
 extern "C" int tpsf_forward(const float* depth, const float* alpha_beta, float* HR, float* LR_deg, float* psf,
                             int B, void* stream) {
   if (!depth || !alpha_beta || !HR || !LR_deg || !psf || B <= 0) return TSR_ERR_ARG;
-  const int grid = B < 512 ? B : 512;          // 2 resident workgroups x 256 CUs, persistent over the batch
+  const int grid = B < 256 * TPSF_FWD_OCC ? B : 256 * TPSF_FWD_OCC;      // resident workgroups x 256 CUs, persistent
   hipLaunchKernelGGL(tpsf_fwd_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, depth, alpha_beta, HR,
                      LR_deg, psf, B);
   return tsr_check_launch();
