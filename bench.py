@@ -33,6 +33,19 @@ PEAK_BF16_MFMA = 2500e12                      # MI355X_MICROARCH.md: dense bf16 
 LAYER_BYTES_PER_SAMPLE = 48.38e6              # SURVEY.md section 8(d), layer-wise fp32 bytes
 
 
+def make_model(args):
+    """(model, LR channels, HR side, config overrides, fwd FLOP/sample): every conv runs at the output resolution,
+    so forward MACs/sample = H*W * (number of conv weights) -- 14,642,380,800 FLOP for the default model."""
+    import tactilesr_amd
+    kw = dict(scale_factor=25, seqsCnt=8) if args.seqs else {}
+    model = tactilesr_amd.TactileSR(**kw)
+    sf, T = model.scale_factor, model.seqsCnt
+    nw = sum(p.numel() for n, p in model.named_parameters() if p.dim() == 4)
+    flop = 2 * (4 * sf) ** 2 * nw
+    assert args.seqs or flop == FWD_FLOP_PER_SAMPLE
+    return model, 3 * T, 4 * sf, dict(scale_factor=sf, seqsCnt=T), flop
+
+
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/rNN_pmc_summary.json, made by tools/summarize_prof.py: separate --pmc
@@ -61,10 +74,14 @@ def main():
                          "powers of two and split into 2 fp16 planes, 3 f16-MFMA products (fp32-grade, default); "
                          "bf16x6 = 3 bf16 planes, 6 products (fp32-equivalent); f32 = fp32 MFMA; "
                          "bf16x3 / bf16 = reduced precision (not the headline)")
+    ap.add_argument("--seqs", action="store_true",
+                    help="tactileSRSeqs shape (BASELINE configs[4]): TactileSR(scale_factor=25, seqsCnt=8), 4x4x24 -> "
+                         "100x100, for --mode infer / train (default batch 512 / 256 per GPU)")
     ap.add_argument("--mode", choices=["infer", "train", "tpsf"], default="infer",
                     help="infer = BASELINE configs[1] (headline); train = data-parallel train step "
                          "(train_cal_loss + backward + RCCL grad all-reduce + Adam), configs[3] shape")
     args = ap.parse_args()
+    args.impl_given = any(x == "--impl" or x.startswith("--impl=") for x in sys.argv[1:])
     if args.mode == "train":
         return main_train(args)
     if args.mode == "tpsf":
@@ -88,12 +105,14 @@ def main():
 
     import tactilesr_amd
     torch.manual_seed(42)
-    model = tactilesr_amd.TactileSR().to(dev).eval()
+    model, cin_lr, side, _, fwd_flop = make_model(args)
+    model = model.to(dev).eval()
     model.conv_impl = args.impl
-    B = args.batch
+    B = args.batch if not (args.seqs and args.batch == 4096) else 512
     model.max_images_per_pass = B
     g = torch.Generator().manual_seed(42 + rank)
-    LR = (torch.rand(B, 3, 4, 4, generator=g) * 8).to(dev)
+    LR = (torch.rand(B, cin_lr, 4, 4, generator=g) * 8).to(dev)
+    c5_flop = 2 * side * side * 128 * 128 * 25      # one 5x5 128->128 conv launch, per sample
 
     def barrier():
         if world > 1:
@@ -118,7 +137,7 @@ def main():
 
     # secondary measurement: the strict fp32-MFMA path (v_mfma_f32_32x32x2_f32), 2 steps, same inputs
     f32_ref = None
-    if args.impl != "f32":
+    if args.impl != "f32" and not args.seqs:
         model.conv_impl = "f32"
         model(LR)
         barrier()
@@ -133,8 +152,8 @@ def main():
         model.conv_impl = args.impl
         c5 = sum(a.elapsed_time(b) for a, b in ev32) / max(1, len(ev32))
         f32_ref = {"value": round(B / dt32, 2), "unit": "samples/s per GPU", "ms_per_step": round(dt32 * 1e3, 3),
-                   "kernel": "conv_mfma_f32_kernel<5,128>", "kernel_tflops": round(B * C5_FLOP_PER_SAMPLE / (c5 * 1e-3) / 1e12, 2),
-                   "kernel_frac_of_f32_mfma_peak": round(B * C5_FLOP_PER_SAMPLE / (c5 * 1e-3) / PEAK_F32_MFMA, 4)}
+                   "kernel": "conv_mfma_f32_kernel<5,128>", "kernel_tflops": round(B * c5_flop / (c5 * 1e-3) / 1e12, 2),
+                   "kernel_frac_of_f32_mfma_peak": round(B * c5_flop / (c5 * 1e-3) / PEAK_F32_MFMA, 4)}
 
     if rank == 0:
         total = B * world * args.steps
@@ -143,7 +162,7 @@ def main():
         c5_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
         nprod = {"fp16x3": 3, "bf16x6": 6, "bf16x3": 3, "bf16": 1, "f32": 1}[args.impl]
         peak = PEAK_F32_MFMA if args.impl == "f32" else PEAK_BF16_MFMA
-        alg = B * C5_FLOP_PER_SAMPLE / (c5_ms * 1e-3) if ev else None       # algorithmic FLOP/s of the launch
+        alg = B * c5_flop / (c5_ms * 1e-3) if ev else None       # algorithmic FLOP/s of the launch
         achieved = alg * nprod / 1e12 if ev else None                        # MFMA FLOP/s actually executed
         kname = ("conv_mfma_f32_kernel<5, 128" if args.impl == "f32" else
                  "conv_mfma_split16_kernel<5, 128, %d, false, %s" % ({"fp16x3": 2, "bf16x6": 3, "bf16x3": 2, "bf16": 1}[args.impl],
@@ -155,13 +174,15 @@ def main():
                  "bf16x6": "f32 as 3 bf16 planes x 6 MFMA products, fp32 accumulate (fp32-equivalent)",
                  "f32": "f32", "bf16x3": "bf16x3 (reduced: ~16 significand bits)", "bf16": "bf16"}[args.impl]
         res = {
-            "metric": "SR samples/sec (4x4->40x40)", "value": round(value, 2), "unit": "samples/s",
+            "metric": "SR samples/sec (4x4->%dx%d)" % (side, side), "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "tactileSR_model eval forward 4x4->40x40, batch=%d/GPU, fp32 in/out (BASELINE configs[1])" % B,
-                       "batch_per_gpu": B, "scale_factor": 10, "seqsCnt": 1, "parallelism": f"replicas x{world}",
-                       "conv_impl": args.impl},
+            "config": {"workload": ("tactileSRSeqs (T=8) eval forward 4x4x24->100x100, batch=%d/GPU, fp32 in/out (BASELINE configs[4] shape)" % B)
+                       if args.seqs else
+                       ("tactileSR_model eval forward 4x4->40x40, batch=%d/GPU, fp32 in/out (BASELINE configs[1])" % B),
+                       "batch_per_gpu": B, "scale_factor": model.scale_factor, "seqsCnt": model.seqsCnt,
+                       "parallelism": f"replicas x{world}", "conv_impl": args.impl, "fwd_GFLOP_per_sample": round(fwd_flop / 1e9, 3)},
             "roofline": {"bound": "mfma", "kernel": kname + "> (5x5 128->128 conv+BN+ReLU, 54% of all FLOPs)",
                          "achieved": round(achieved, 2) if achieved else None, "peak": peak / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved * 1e12 / peak, 4) if achieved else None,
@@ -169,16 +190,16 @@ def main():
                          "algorithmic_tflops": round(alg / 1e12, 2) if alg else None,
                          "algorithmic_vs_f32_mfma_peak": round(alg / PEAK_F32_MFMA, 4) if alg else None,
                          "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": B * (2 * 128 * 1600 * 4) + 128 * 128 * 25 * 4,
+                         "algorithmic_bytes_per_launch": B * (2 * 128 * side * side * 4) + 128 * 128 * 25 * 4,
                          "avg_launch_ms": round(c5_ms, 3), "launches_timed": len(ev)},
-            "whole_step": {"algorithmic_tflops": round(value / world * FWD_FLOP_PER_SAMPLE / 1e12, 2),
-                           "algorithmic_vs_f32_mfma_peak": round(value / world * FWD_FLOP_PER_SAMPLE / PEAK_F32_MFMA, 4),
-                           "layerwise_GBps": round(value / world * LAYER_BYTES_PER_SAMPLE / 1e9, 1),
+            "whole_step": {"algorithmic_tflops": round(value / world * fwd_flop / 1e12, 2),
+                           "algorithmic_vs_f32_mfma_peak": round(value / world * fwd_flop / PEAK_F32_MFMA, 4),
+                           "layerwise_GBps": None if args.seqs else round(value / world * LAYER_BYTES_PER_SAMPLE / 1e9, 1),
                            "ms_per_step_by_kernel": per_kernel},
         }
         if f32_ref is not None:
             res["f32_mfma_path"] = f32_ref
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.seqs:
             res.update(cpu_baseline_and_psnr(model, dev))
         print(json.dumps(res), flush=True)
     if world > 1:
@@ -203,15 +224,19 @@ def main_train(args):
         import torch.distributed as dist
         ddp.init_distributed(os.environ.get("TSR_BENCH_DIST_BACKEND", "nccl"))
     torch.manual_seed(42)
-    model = tactilesr_amd.TactileSR().to(dev).train()
+    if args.impl_given:
+        os.environ["TSR_TRAIN_IMPL"] = args.impl        # read when the model builds its train engine
+    model, cin_lr, side, cfg_over, fwd_flop = make_model(args)
+    model = model.to(dev).train()
     opt = optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-2)
     sync = ddp.GradSync(model.parameters(), n_buckets=4) if world > 1 else None
     if sync:
         sync.broadcast_parameters(0)
-    B = args.batch if args.batch != 4096 else 2048
+    B = args.batch if args.batch != 4096 else (256 if args.seqs else 2048)
     g = torch.Generator().manual_seed(42 + rank)
-    batch = ((torch.rand(B, 3, 4, 4, generator=g) * 8).to(dev), (torch.rand(B, 1, 100, 100, generator=g) * 250).to(dev))
+    batch = ((torch.rand(B, cin_lr, 4, 4, generator=g) * 8).to(dev), (torch.rand(B, 1, 100, 100, generator=g) * 250).to(dev))
     conf = TR.default_config()
+    conf.update(cfg_over)
 
     def barrier():
         if world > 1:
@@ -233,23 +258,29 @@ def main_train(args):
     if rank == 0:
         value = B * world * args.steps / dt
         impl = os.environ.get("TSR_TRAIN_IMPL", "fp16x3")
-        nprod, peak = {"bf16x6": (6, PEAK_BF16_MFMA), "fp16x3": (3, PEAK_BF16_MFMA)}.get(impl, (1, PEAK_F32_MFMA))
-        train_flop = 3 * FWD_FLOP_PER_SAMPLE - 2 * 5_529_600 * 2
+        nprod, peak = {"bf16x6": (6, PEAK_BF16_MFMA), "fp16x3": (3, PEAK_BF16_MFMA),
+                       "bf16": (1, PEAK_BF16_MFMA)}.get(impl, (1, PEAK_F32_MFMA))
+        # fwd + dgrad + wgrad, minus the dgrad of the T+1 stem convs (3->64, 3x3) whose input needs no gradient
+        train_flop = 3 * fwd_flop - (model.seqsCnt + 1) * 2 * side * side * 27 * 64
         print(json.dumps({
-            "metric": "SR train samples/sec (4x4->40x40)", "value": round(value, 2), "unit": "samples/s",
+            "metric": "SR train samples/sec (4x4->%dx%d)" % (side, side), "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {6: "f32 as 3 bf16 planes x 6 MFMA products, fp32 accumulate (fp32-equivalent)",
-                      3: "f32 as 2 scaled fp16 planes x 3 MFMA products, fp32 accumulate (fp32-grade)"}.get(nprod, "f32"),
+            "dtype": {"bf16x6": "f32 as 3 bf16 planes x 6 MFMA products, fp32 accumulate (fp32-equivalent)",
+                      "fp16x3": "f32 as 2 scaled fp16 planes x 3 MFMA products, fp32 accumulate (fp32-grade)",
+                      "bf16": "bf16 conv operands, fp32 accumulate / params / activations (reduced precision)"}.get(impl, "f32"),
             "data": "synthetic",
-            "config": {"workload": "TactileSR train step (fwd+bwd+Adam L2), fp32 params/activations, batch/GPU=%d (BASELINE configs[3] shape)" % B,
-                       "batch_per_gpu": B, "parallelism": f"dp{world}", "grad_allreduce_MB": 18.33, "conv_impl": impl},
+            "config": {"workload": ("tactileSRSeqs (T=8, 100x100) " if args.seqs else "TactileSR ") +
+                       "train step (fwd+bwd+Adam L2), fp32 params/activations, batch/GPU=%d (BASELINE configs[%d] shape)" % (B, 4 if args.seqs else 3),
+                       "batch_per_gpu": B, "parallelism": f"dp{world}",
+                       "grad_allreduce_MB": round(sum(p.numel() for p in model.parameters()) * 4 / 1e6, 2), "conv_impl": impl,
+                       "train_GFLOP_per_sample": round(train_flop / 1e9, 3)},
             "roofline": {"bound": "mfma", "achieved": round(value / world * train_flop * nprod / 1e12, 2),
                          "peak": peak / 1e12, "unit": "TFLOP/s",
                          "frac": round(value / world * train_flop * nprod / peak, 4), "mfma_products_per_mac": nprod,
                          "algorithmic_tflops": round(value / world * train_flop / 1e12, 2),
                          "algorithmic_vs_f32_mfma_peak": round(value / world * train_flop / PEAK_F32_MFMA, 4),
-                         "traffic": None, "kernel": "whole train step (43.9 GFLOP/sample algorithmic)"},
+                         "traffic": None, "kernel": "whole train step (%.1f GFLOP/sample algorithmic)" % (train_flop / 1e9)},
             "loss": float(ld["total_loss"]),
         }), flush=True)
     if world > 1:

@@ -163,7 +163,8 @@ int tsr_conv2d_wgrad(const float* a, int a_ctot, int a_coff, int cin,
                      const float* dz, int dz_ctot, int dz_coff, int cout, int ks,
                      float* slab, float* bias_slab, int nsplit, int B, int H, int W, void* stream);
 /* Same on the 16-bit matrix cores with split operands: planes = 3 -> three bf16 planes, six products
- * (fp32-equivalent; a_amax/dz_amax unused); planes = -2 -> two power-of-two-scaled fp16 planes, three products,
+ * (fp32-equivalent; a_amax/dz_amax unused); planes = 1 -> plain bf16 operands (reduced precision: the "bf16"
+ * configurations, never the parity path); planes = -2 -> two power-of-two-scaled fp16 planes, three products,
  * scales derived from the device scalars a_amax = max|a| (raw tensor) and dz_amax = max|dz|. */
 int tsr_conv2d_wgrad_bf16s(const float* a, int a_ctot, int a_coff, int cin,
                            const float* a_scale, const float* a_shift,

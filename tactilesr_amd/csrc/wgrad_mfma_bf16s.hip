@@ -291,9 +291,10 @@ extern "C" int tsr_conv2d_wgrad_bf16s(const float* a, int a_ctot, int a_coff, in
                                       const float* dz, int dz_ctot, int dz_coff, int cout, int ks, int planes,
                                       const float* a_amax, const float* dz_amax,
                                       float* slab, float* bias_slab, int nsplit, int B, int H, int W, void* stream) {
-  // planes = 3: bf16 (fp32-equivalent, a_amax/dz_amax unused); planes = -2: fp16 two-plane split with the
+  // planes = 3: bf16 (fp32-equivalent, a_amax/dz_amax unused); planes = 1: plain bf16 operands (reduced
+  // precision, the "bf16" configurations); planes = -2: fp16 two-plane split with the
   // power-of-two scales derived from the device scalars a_amax = max|a| (raw) and dz_amax = max|dz|
-  if (!a || !dz || !slab || B <= 0 || H <= 0 || W <= 0 || nsplit <= 0 || (planes != 3 && planes != -2))
+  if (!a || !dz || !slab || B <= 0 || H <= 0 || W <= 0 || nsplit <= 0 || (planes != 3 && planes != 1 && planes != -2))
     return TSR_ERR_ARG;
   if (planes == -2 && (!a_amax || !dz_amax)) return TSR_ERR_ARG;
   if ((cin & 63) || (cout & 63) || (a_ctot & 15) || (a_coff & 15) || (dz_ctot & 15) || (dz_coff & 15) ||
@@ -312,6 +313,10 @@ extern "C" int tsr_conv2d_wgrad_bf16s(const float* a, int a_ctot, int a_coff, in
     if (ks == 1) hipLaunchKernelGGL((wgrad_mfma_bf16s_kernel<1, 3, false>), dim3(grid), dim3(256), 0, st, g);
     else if (ks == 3) hipLaunchKernelGGL((wgrad_mfma_bf16s_kernel<3, 3, false>), dim3(grid), dim3(256), 0, st, g);
     else hipLaunchKernelGGL((wgrad_mfma_bf16s_kernel<5, 3, false>), dim3(grid), dim3(256), 0, st, g);
+  } else if (planes == 1) {
+    if (ks == 1) hipLaunchKernelGGL((wgrad_mfma_bf16s_kernel<1, 1, false>), dim3(grid), dim3(256), 0, st, g);
+    else if (ks == 3) hipLaunchKernelGGL((wgrad_mfma_bf16s_kernel<3, 1, false>), dim3(grid), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((wgrad_mfma_bf16s_kernel<5, 1, false>), dim3(grid), dim3(256), 0, st, g);
   } else {
     if (ks == 1) hipLaunchKernelGGL((wgrad_mfma_bf16s_kernel<1, 2, true>), dim3(grid), dim3(256), 0, st, g);
     else if (ks == 3) hipLaunchKernelGGL((wgrad_mfma_bf16s_kernel<3, 2, true>), dim3(grid), dim3(256), 0, st, g);

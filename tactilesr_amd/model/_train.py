@@ -131,8 +131,9 @@ class TrainEngine:
         self.debug = None        # tests may set a dict: backward then stores clones of dz tensors in it
         import os
         # conv arithmetic of the train path: 0 = fp32 MFMA, 3 = split-bf16 (six products, fp32-equivalent),
-        # -2 = two scaled fp16 planes (three products; operand scales from device-side max|.| scalars)
-        self.nsplit = {"f32": 0, "bf16x6": 3, "fp16x3": -2}[os.environ.get("TSR_TRAIN_IMPL", "fp16x3")]
+        # -2 = two scaled fp16 planes (three products; operand scales from device-side max|.| scalars),
+        # 1 = plain bf16 operands with fp32 accumulation (reduced precision: BASELINE's "bf16" configurations only)
+        self.nsplit = {"f32": 0, "bf16x6": 3, "fp16x3": -2, "bf16": 1}[os.environ.get("TSR_TRAIN_IMPL", "fp16x3")]
         self.f16 = self.nsplit == -2
 
     def _mfma_convs(self):

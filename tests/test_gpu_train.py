@@ -322,3 +322,29 @@ def test_large_batch_train_step_tiling_invariance(T):
             continue
         l2 = float((big[k] - ref).norm() / ref.norm())
         assert l2 < 3e-3, (k, l2)          # rel-L2: robust to isolated ReLU-mask flips (see the odd-batch test)
+
+
+def test_bf16_train_mode_is_a_reduced_precision_of_the_same_step(T, golden, monkeypatch):
+    """TSR_TRAIN_IMPL=bf16 (BASELINE's "bf16" configurations: bf16 conv operands, fp32 accumulation, parameters and
+    activations) is NOT the parity path; it must still be the same computation: loss within 2e-2 of the reference's,
+    every gradient pointing the same way (cosine > 0.98 against the fp64 yardstick)."""
+    monkeypatch.setenv("TSR_TRAIN_IMPL", "bf16")
+    g = golden("train")
+    cfg = dict(patternFeatureExtraLayerCnt=2)
+    sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), int(g["seed"]))
+    m = T.TactileSR(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    LR, HR = torch.from_numpy(g["LR"]).cuda(), torch.from_numpy(g["HR_prepared"]).cuda()
+    out = m(LR[:, :3])
+    assert relerr(out, torch.from_numpy(g["out0"])) < 3e-2
+    loss = torch.nn.MSELoss()(out, HR)
+    assert abs(loss.item() - g["losses"][0]) <= 2e-2 * abs(g["losses"][0])
+    loss.backward()
+    named = dict(m.named_parameters())
+    for k in [str(k) for k in g["keys"]]:
+        if float(g[f"gradnorm/{k}"]) < 1e-4:
+            continue
+        got, ref = _subs(named[k].grad).astype(np.float64), g[f"grad64/{k}"]
+        cos = float(got @ ref / max(np.linalg.norm(got) * np.linalg.norm(ref), 1e-30))
+        assert cos > 0.98, (k, cos)
