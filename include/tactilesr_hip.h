@@ -176,7 +176,7 @@ int tsr_reduce_splits(const float* slab, float* out, long long n, int nsplit, fl
 /* nn.BatchNorm2d train mode (model/tactileSR_model.py:38,42,48,169,175,181,187), from the
  * epi_mode-1 slabs: batch mean / biased variance -> scale = gamma*invstd, shift = beta-mean*scale
  * (to apply on the bias-free conv output), xhat_a = invstd, xhat_b = -mean*invstd; running_mean/var
- * updated in place (momentum, unbiased variance, +bias on the mean).  work: 64*C*3 doubles. */
+ * updated in place (momentum, unbiased variance, +bias on the mean).  work: 512*C*3 doubles. */
 int tsr_bn_stats_finalize(const float* slab, const float* slab_cnt, int entries, int C,
                           const float* bias, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float momentum, float eps,

@@ -7,7 +7,7 @@
 // cpu/trainer.py:346-362.
 #include "tsr_common.h"
 
-#define RED_BLOCKS 64
+#define RED_BLOCKS 512     // partial-sum blocks of the slab reductions (work buffers hold RED_BLOCKS*C*3 doubles)
 
 // ------------------------------------------------------------------------------------------
 // per-channel fp64 reduction of the conv epilogue slabs: slab[entry][C][2]
@@ -21,8 +21,22 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   const int tid = threadIdx.x;
   const int per = 256 / C;           // entries handled concurrently by one block (C in {64,128})
   const int c = tid % C, el = tid / C;
-  double s0 = 0, s1 = 0, s2 = 0;
-  for (int e = blockIdx.x * per + el; e < entries; e += gridDim.x * per) {
+  double s0 = 0, s1 = 0, s2 = 0, t0 = 0, t1 = 0, t2 = 0;     // two independent chains: two loads in flight
+  const int stride = gridDim.x * per;
+  int e = blockIdx.x * per + el;
+  for (; e + stride < entries; e += 2 * stride) {
+    const float2 v = *(const float2*)(slab + ((size_t)e * C + c) * 2);
+    const float2 u = *(const float2*)(slab + ((size_t)(e + stride) * C + c) * 2);
+    if (mode == 0) {
+      const double n = (double)cnt[e], m = (double)v.x, n2 = (double)cnt[e + stride], m2 = (double)u.x;
+      s0 += n; s1 += n * m; s2 += (double)v.y + n * m * m;
+      t0 += n2; t1 += n2 * m2; t2 += (double)u.y + n2 * m2 * m2;
+    } else {
+      s0 += 1.0; s1 += (double)v.x; s2 += (double)v.y;
+      t0 += 1.0; t1 += (double)u.x; t2 += (double)u.y;
+    }
+  }
+  if (e < entries) {
     const float2 v = *(const float2*)(slab + ((size_t)e * C + c) * 2);
     if (mode == 0) {
       const double n = (double)cnt[e], m = (double)v.x;
@@ -31,6 +45,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
       s0 += 1.0; s1 += (double)v.x; s2 += (double)v.y;
     }
   }
+  s0 += t0; s1 += t1; s2 += t2;
   sh[tid * 3 + 0] = s0; sh[tid * 3 + 1] = s1; sh[tid * 3 + 2] = s2;
   __syncthreads();
   if (el == 0) {
@@ -48,12 +63,20 @@ __global__ void bn_stats_final_kernel(const double* __restrict__ part, int nbloc
                                       float* __restrict__ running_var, float momentum, float eps,
                                       float* __restrict__ scale, float* __restrict__ shift,
                                       float* __restrict__ xa, float* __restrict__ xb) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  // 16 channels per block; 16 lanes per channel walk the partial blocks, then one lane finishes
+  __shared__ double sh[256 * 3];
+  const int tid = threadIdx.x, cl = tid & 15, kl = tid >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double n = 0, s1 = 0, s2 = 0;
-  for (int k = 0; k < nblocks; ++k) {
+  for (int k = kl; k < nblocks; k += 16) {
     const double* p = part + ((size_t)k * C + c) * 3;
     n += p[0]; s1 += p[1]; s2 += p[2];
+  }
+  sh[tid * 3 + 0] = n; sh[tid * 3 + 1] = s1; sh[tid * 3 + 2] = s2;
+  __syncthreads();
+  if (kl != 0) return;
+  for (int k = 1; k < 16; ++k) {
+    n += sh[(k * 16 + cl) * 3 + 0]; s1 += sh[(k * 16 + cl) * 3 + 1]; s2 += sh[(k * 16 + cl) * 3 + 2];
   }
   const double mean = s1 / n;
   double var = s2 / n - mean * mean;          // biased (normalisation)
@@ -82,7 +105,7 @@ extern "C" int tsr_bn_stats_finalize(const float* slab, const float* slab_cnt, i
     return TSR_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(RED_BLOCKS), dim3(256), 0, st, slab, slab_cnt, entries, C, 0, work);
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(1), dim3(128), 0, st, work, RED_BLOCKS, C, bias, gamma, beta,
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C / 16), dim3(256), 0, st, work, RED_BLOCKS, C, bias, gamma, beta,
                      running_mean, running_var, momentum, eps, scale, shift, xhat_a, xhat_b);
   return tsr_check_launch();
 }
@@ -92,13 +115,18 @@ __global__ void bn_bwd_final_kernel(const double* __restrict__ part, int nblocks
                                     const float* __restrict__ xb, float* __restrict__ dgamma,
                                     float* __restrict__ dbeta, float* __restrict__ c1, float* __restrict__ c2,
                                     float* __restrict__ c3) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double sh[256 * 2];
+  const int tid = threadIdx.x, cl = tid & 15, kl = tid >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double s1 = 0, s2 = 0;
-  for (int k = 0; k < nblocks; ++k) {
+  for (int k = kl; k < nblocks; k += 16) {
     const double* p = part + ((size_t)k * C + c) * 3;
     s1 += p[1]; s2 += p[2];
   }
+  sh[tid * 2 + 0] = s1; sh[tid * 2 + 1] = s2;
+  __syncthreads();
+  if (kl != 0) return;
+  for (int k = 1; k < 16; ++k) { s1 += sh[(k * 16 + cl) * 2 + 0]; s2 += sh[(k * 16 + cl) * 2 + 1]; }
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
   // dz = scale*(g - dbeta/N - xhat*dgamma/N), xhat = z*xa + xb  ->  dz = c1*g + c2*z + c3
@@ -117,7 +145,7 @@ extern "C" int tsr_bn_bwd_finalize(const float* slab, int entries, int C, double
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(RED_BLOCKS), dim3(256), 0, st, slab, (const float*)nullptr, entries,
                      C, 1, work);
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(1), dim3(128), 0, st, work, RED_BLOCKS, C, N, scale, xhat_a, xhat_b,
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C / 16), dim3(256), 0, st, work, RED_BLOCKS, C, N, scale, xhat_a, xhat_b,
                      dgamma, dbeta, c1, c2, c3);
   return tsr_check_launch();
 }

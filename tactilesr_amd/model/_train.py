@@ -211,7 +211,7 @@ class TrainEngine:
         st_entries = lib.tsr_cb16_stats_entries(B, HW)
         c.slab = torch.empty(max(c.entries * 128 * 2, st_entries * 64 * 2), dtype=torch.float32, device=dev)
         c.slab_cnt = torch.empty(max(c.entries, st_entries), dtype=torch.float32, device=dev)
-        c.work = torch.empty(64 * 128 * 3, dtype=torch.float64, device=dev)
+        c.work = torch.empty(512 * 128 * 3, dtype=torch.float64, device=dev)
 
         def buf(ch):
             return torch.empty(B * ch * HW, dtype=torch.float32, device=dev)

@@ -96,7 +96,7 @@ def test_conv2d_dgrad_with_mask_and_bn_sums(T, ks, cin, cout, B, H, W, NP):
     gbuf = torch.empty(B * cin * H * W, device="cuda")
     lib = load()
     entries = lib.tsr_conv2d_slab_entries(B, H, W)
-    work = torch.empty(64 * 128 * 3, dtype=torch.float64, device="cuda")
+    work = torch.empty(512 * 128 * 3, dtype=torch.float64, device="cuda")
     wd = w.cuda().contiguous()
     dgam, dbet = [], []
     for o in range(0, cin, NP):
