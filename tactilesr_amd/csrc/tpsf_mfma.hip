@@ -14,6 +14,7 @@
 // One workgroup (4 waves) per sample, persistent over the batch; 52 KB LDS -> 3 workgroups per CU.
 // Per sample the kernel moves 40 KB depth in + 40 KB HR + 39 KB psf out: the roofline is HBM.
 #include "tsr_common.h"
+#include <type_traits>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -91,14 +92,16 @@ __device__ __forceinline__ void gemm_rows_toeplitz(f32x16 (&acc)[4], const f16x8
 #undef G1_LOAD
 }
 
-// R^T planes -> LDS: RT[x][y'] = acc * f1 split in two fp16 planes (rows y' >= 100 of the accumulators are exact
-// zeros: they pad K to 104)
+// R^T planes -> LDS: RT[x][y'] = acc * f1 split in two fp16 planes.  LW = the wave that owns rows 96..127: only its
+// first row group exists (rows 96..99, and exact zeros for 100..103, which pad K to 104).  Column tile 3 holds
+// x = 96..99 only: one predicated block for it instead of a predicate per write.
+template <bool LW>
 __device__ __forceinline__ void store_rt(const f32x16 (&acc)[4], float f1, char* RT, int w, int h, int li) {
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
+  constexpr int NRQ = LW ? 1 : 4;
+  auto put = [&](int nt) {
     const int x = 32 * nt + li;
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
+    for (int rq = 0; rq < NRQ; ++rq) {
       const int y0 = 32 * w + 8 * rq + 4 * h;
       f16x4 hi, lo;
 #pragma unroll
@@ -107,12 +110,14 @@ __device__ __forceinline__ void store_rt(const f32x16 (&acc)[4], float f1, char*
         hi[j] = (_Float16)t;
         lo[j] = (_Float16)(t - (float)hi[j]);
       }
-      if (x < HS && y0 < 104) {
-        *(f16x4*)(RT + x * RT_STRIDE + 2 * y0) = hi;
-        *(f16x4*)(RT + RT_PLANE + x * RT_STRIDE + 2 * y0) = lo;
-      }
+      *(f16x4*)(RT + x * RT_STRIDE + 2 * y0) = hi;
+      *(f16x4*)(RT + RT_PLANE + x * RT_STRIDE + 2 * y0) = lo;
     }
-  }
+  };
+  put(0);
+  put(1);
+  put(2);
+  if (li < HS - 96) put(3);
 }
 
 // acc[nt] += Toeplitz(Tc)(rows of this wave) * R(RT)   (K columns >= 104 of the last step are masked in A)
@@ -239,14 +244,11 @@ __global__ __launch_bounds__(256, TPSF_FWD_OCC) void tpsf_fwd_mfma_kernel(const 
     build_toeplitz(Tc, g, G_SCALE, tid);
     // ---- psf output (B,1,99,99)
     float* pp = psf + (size_t)b * PS * PS;
-    {
-      int u = tid / PS, v = tid - u * PS;          // i = tid + 256 n: (u, v) advance by (2, 58) with carry
-      for (int i = tid; i < PS * PS; i += 256) {
-        pp[i] = alpha * (g[u] * g[v]);
-        v += 256 - 2 * PS;
-        u += 2;
-        if (v >= PS) { v -= PS; ++u; }
-      }
+    if (tid < 2 * PS) {                              // two rows per pass: thread = (row parity, column v), g(v) in a register
+      const int u0 = tid >= PS ? 1 : 0, v = tid - u0 * PS;
+      const float gv = g[v];
+      float* po = pp + u0 * PS + v;
+      for (int u = u0; u < PS; u += 2, po += 2 * PS) *po = alpha * (g[u] * gv);      // exactly symmetric in (u, v)
     }
 
     // ---- operand scales; split the depth rows into fp16 planes
@@ -275,7 +277,8 @@ __global__ __launch_bounds__(256, TPSF_FWD_OCC) void tpsf_fwd_mfma_kernel(const 
     f32x16 acc[4];
     zero_acc(acc);
     gemm_rows_toeplitz(acc, a_hi, a_lo, Tc, laneT);
-    store_rt(acc, sR / (sD * G_SCALE), RT, w, h, li);
+    if (w < 3) store_rt<false>(acc, sR / (sD * G_SCALE), RT, w, h, li);
+    else store_rt<true>(acc, sR / (sD * G_SCALE), RT, w, h, li);
     __syncthreads();                                                      // (3) R^T
     zero_acc(acc);
     gemm_toeplitz_rt(acc, Tc, RT, laneT, w, h, li);
@@ -284,80 +287,96 @@ __global__ __launch_bounds__(256, TPSF_FWD_OCC) void tpsf_fwd_mfma_kernel(const 
     if (b + (int)gridDim.x < B) load_depth(b + gridDim.x);   // the A planes are dead: their registers take the next rows
 #endif
 
-    // ---- plateau fill: HR[mask] = max(HR outside mask, 0), mask = depth > depth.max() - 1e-3
-    // (lane constants re-derived from an opaque copy per sample: hipcc would otherwise hoist 64 loop-invariant
-    //  64-bit addresses and predicates out of the persistent loop and spill them)
+    // ---- plateau fill: HR[mask] = max(HR outside mask, 0), mask = depth > depth.max() - 1e-3; then the HR store
+    // and the separable Gaussian-masked pooling partials P[a][x] = sum_y ea[a][y] HR[y][x], all from the
+    // accumulator registers.  Two compile-time forms: waves 0..2 own 32 full rows (no row masks at all), wave 3 owns
+    // rows 96..99 only (accumulator rows r < 4 of the h = 0 half).  Column tile 3 holds x = 96..99: masked, and
+    // stored under one predicate.  Lane constants are re-derived from an opaque copy per sample (hipcc would
+    // otherwise hoist 64 loop-invariant addresses out of the persistent loop and spill them); integer masks instead
+    // of bool selects (those become per-pixel branches with spilled live-through values).
     int li_o = li, h_o = h;
     asm volatile("" : "+v"(li_o), "+v"(h_o));
-    const int yb = 32 * w + 4 * h_o;               // accumulator row r -> image row yb + (r & 3) + 8 (r >> 2)
-    const unsigned vx3 = ((unsigned)(li_o - (HS - 96)) >> 31);   // column tile 3 holds x = 96..99 only
+    const unsigned cm3 = 0u - ((unsigned)(li_o - (HS - 96)) >> 31);      // all ones where tile-3 column exists
     const float f2 = alpha / (G_SCALE * sR);
-    unsigned long long plateau = 0ull;
-    float fmax_out = 0.f;          // tmp[mask] = 0 takes part in the max (the mask is never empty)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int yy = yb + (r & 3) + 8 * (r >> 2);
-      const unsigned vy = ((unsigned)(yy - HS) >> 31);             // 1 inside the image
-      const uint4 mrow = *(const uint4*)(pmask + (yy < HS - 1 ? yy : HS - 1) * 16);
-      const unsigned mw[4] = {mrow.x, mrow.y, mrow.z, mrow.w};
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const unsigned vi = nt < 3 ? vy : (vy & vx3);
-        const unsigned pli = (mw[nt] >> li_o) & vi;
-        const float v = acc[nt][r] * f2 * (float)vi;              // the accumulators outside the image are finite
-        plateau |= (unsigned long long)pli << (nt * 16 + r);
-        fmax_out = fmaxf(fmax_out, v * (float)(1u - pli));
-        acc[nt][r] = v;
-      }
-      asm volatile("" ::: "memory");     // keep the row's LDS reads and arithmetic in its iteration (hipcc
-      __builtin_amdgcn_sched_barrier(0); // otherwise regroups the unrolled rows and spills hundreds of values)
-    }
-    {
-      // opaque copy: hipcc otherwise keeps the 64 per-pixel conditions alive as lane masks instead of these bits
-      unsigned plo = (unsigned)plateau, phi = (unsigned)(plateau >> 32);
-      asm volatile("" : "+v"(plo), "+v"(phi));
-      plateau = ((unsigned long long)phi << 32) | plo;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) fmax_out = fmaxf(fmax_out, __shfl_xor(fmax_out, o));
-    if (lane == 0) red[8 + w] = fmax_out;
-    __syncthreads();                                                      // (4) fill; every wave is past GEMM2
-    const float fill = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
-
-    // ---- HR store + separable Gaussian-masked pooling partials  P[a][x] = sum_y ea[a][y] HR[y][x]
     float* hp = HR + (size_t)b * NPIX + li_o;
-    float* Ppart = (float*)Tc;       // [4 waves][4 a][100 x]
+    float* Ppart = (float*)Tc;       // [4 waves][4 a][100 x]  (the table is dead after GEMM2; barrier (4) orders it)
     float s0 = 0.f;
-    float pa[4][4];
+    auto epilogue = [&](auto lastw) {
+      constexpr bool LW = decltype(lastw)::value;
+      constexpr int NR = LW ? 4 : 16;
+      const int yb = 32 * w + 4 * h_o;               // accumulator row r -> image row yb + (r & 3) + 8 (r >> 2)
+      const unsigned rowm = LW ? 0u - (unsigned)(h_o == 0) : ~0u;
+      unsigned long long plateau = 0ull;
+      float fmax_out = 0.f;          // tmp[mask] = 0 takes part in the max (the mask is never empty)
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+      for (int r = 0; r < NR; ++r) {
+        const int yy = yb + (r & 3) + 8 * (r >> 2);
+        const uint4 mrow = *(const uint4*)(pmask + (LW ? (yy < HS - 1 ? yy : HS - 1) : yy) * 16);
+        const unsigned mw[4] = {mrow.x, mrow.y, mrow.z, mrow.w};
 #pragma unroll
-      for (int a = 0; a < 4; ++a) pa[nt][a] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int yy = yb + (r & 3) + 8 * (r >> 2);
-      const bool vy = yy < HS;
-      const int yc = yy < HS - 1 ? yy : HS - 1;
-      const float e[4] = {ea[yc], ea[100 + yc], ea[200 + yc], ea[300 + yc]};
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const unsigned pm = 0u - (unsigned)((plateau >> (nt * 16 + r)) & 1ull);
-        const float v = bitsel(pm, fill, acc[nt][r]);             // 0 outside the image
-        if (vy && (nt < 3 || vx3)) hp[yy * HS + 32 * nt] = v;
-        s0 += v;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) pa[nt][a] = fmaf(e[a], v, pa[nt][a]);
+        for (int nt = 0; nt < 4; ++nt) {
+          const unsigned vm = nt < 3 ? rowm : (rowm & cm3);
+          const unsigned pli = (mw[nt] >> li_o) & 1u & vm;
+          const float v = __uint_as_float(__float_as_uint(acc[nt][r] * f2) & vm);   // accumulators outside are finite
+          plateau |= (unsigned long long)pli << (nt * 16 + r);
+          fmax_out = fmaxf(fmax_out, bitsel(0u - pli, 0.f, v));
+          acc[nt][r] = v;
+        }
+        asm volatile("" ::: "memory");     // keep the row's LDS reads and arithmetic in its iteration (hipcc
+        __builtin_amdgcn_sched_barrier(0); // otherwise regroups the unrolled rows and spills hundreds of values)
       }
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        pa[nt][a] += __shfl_xor(pa[nt][a], 32);
-        if (h == 0 && 32 * nt + li < HS) Ppart[(w * 4 + a) * HS + 32 * nt + li] = pa[nt][a];
+      {
+        // opaque copy: hipcc otherwise keeps the per-pixel conditions alive as lane masks instead of these bits
+        unsigned plo = (unsigned)plateau, phi = (unsigned)(plateau >> 32);
+        asm volatile("" : "+v"(plo), "+v"(phi));
+        plateau = ((unsigned long long)phi << 32) | plo;
       }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) fmax_out = fmaxf(fmax_out, __shfl_xor(fmax_out, o));
+      if (lane == 0) red[8 + w] = fmax_out;
+      __syncthreads();                                                    // (4) fill; every wave is past GEMM2
+      const float fill = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
+
+      float pa[4][4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) pa[nt][a] = 0.f;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int yy = yb + (r & 3) + 8 * (r >> 2);
+        const int yc = LW ? (yy < HS - 1 ? yy : HS - 1) : yy;
+        const float e[4] = {ea[yc], ea[100 + yc], ea[200 + yc], ea[300 + yc]};
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const unsigned pm = 0u - (unsigned)((plateau >> (nt * 16 + r)) & 1ull);
+          const float v = bitsel(pm, fill, acc[nt][r]);             // 0 outside the image
+          acc[nt][r] = v;
+          if (nt < 3) {
+            if (!LW) hp[yy * HS + 32 * nt] = v;
+            else if (h_o == 0) hp[yy * HS + 32 * nt] = v;
+          }
+          s0 += v;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) pa[nt][a] = fmaf(e[a], v, pa[nt][a]);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (cm3 & rowm) {                    // x = 96..99 of this wave's rows
+#pragma unroll
+        for (int r = 0; r < NR; ++r) hp[(yb + (r & 3) + 8 * (r >> 2)) * HS + 96] = acc[3][r];
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          pa[nt][a] += __shfl_xor(pa[nt][a], 32);
+          if (h == 0 && 32 * nt + li < HS) Ppart[(w * 4 + a) * HS + 32 * nt + li] = pa[nt][a];
+        }
+    };
+    if (w < 3) epilogue(std::false_type());
+    else epilogue(std::true_type());
     double s0d = (double)s0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s0d += __shfl_xor(s0d, o);
@@ -512,7 +531,8 @@ __global__ __launch_bounds__(256, 1) void tpsf_bwd_mfma_kernel(const float* __re
       zero_acc(acc);
       gemm_rows_toeplitz(acc, a_hi, a_lo, Tg, laneT);
     }
-    store_rt(acc, sRg / (sD * G_SCALE), RT, w, h, li);
+    if (w < 3) store_rt<false>(acc, sRg / (sD * G_SCALE), RT, w, h, li);
+    else store_rt<true>(acc, sRg / (sD * G_SCALE), RT, w, h, li);
     __syncthreads();                                                      // (3) R^T = Rg
     zero_acc(acc);
     gemm_toeplitz_rt(acc, Tg, RT, laneT, w, h, li);
@@ -634,7 +654,8 @@ __global__ __launch_bounds__(256, 1) void tpsf_bwd_mfma_kernel(const float* __re
       f32x16 accr[4];
       zero_acc(accr);
       gemm_rows_toeplitz(accr, a_hi, a_lo, Th, laneT);
-      store_rt(accr, sRh / (sD * sH), RT, w, h, li);
+      if (w < 3) store_rt<false>(accr, sRh / (sD * sH), RT, w, h, li);
+      else store_rt<true>(accr, sRh / (sD * sH), RT, w, h, li);
     }
     __syncthreads();                                                      // (6) R^T = Rh
     {
