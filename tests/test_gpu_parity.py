@@ -327,3 +327,25 @@ def test_stem_publishes_amax(T):
     call("tsr_stem_fwd", ptr(lr), I(3), I(0), I(3), I(4), I(4), I(10), ptr(w), ptr(None), ptr(None), ptr(out), I(64),
          I(0), I(1), I(3), ptr(amax), stream())
     assert float(amax) == float(out.max()) > 0
+
+
+def test_hip_graph_replay_is_bit_identical_to_eager(T):
+    """GraphedTactileSR: the captured forward replays to exactly the eager result, for new inputs, and refuses
+    to run after the weights changed."""
+    import tactilesr_amd
+    torch.manual_seed(3)
+    m = tactilesr_amd.TactileSR(patternFeatureExtraLayerCnt=2).cuda().eval()
+    g = tactilesr_amd.GraphedTactileSR(m, 5)
+    for seed in (1, 2):
+        x = (torch.rand(5, 3, 4, 4, generator=torch.Generator().manual_seed(seed)) * 8).cuda()
+        with torch.no_grad():
+            ref = m(x)
+        out = g(x).clone()
+        assert torch.equal(out, ref)
+    with pytest.raises(AssertionError):
+        g(torch.zeros(4, 3, 4, 4, device="cuda"))
+    with torch.no_grad():
+        next(m.parameters()).mul_(1.5)
+    m(x)                                   # the eager path notices the new weight version and re-packs
+    with pytest.raises(tactilesr_amd._lib.TactileSRHipError):
+        g(x)
