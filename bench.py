@@ -288,6 +288,16 @@ def main_train(args):
         dist.destroy_process_group()
 
 
+def tpsf_traffic(B):
+    """HBM bytes per tpsf_fwd_mfma_kernel launch from the committed PMC passes (same B only)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_tpsf_pmc.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1])).get("tpsf_fwd_mfma_kernel")
+    return d["hbm_bytes_per_launch"] if d and d.get("samples_per_launch") == B else None
+
+
 def main_tpsf(args):
     """tPSFNet (reference model/tPSFNet.py:78-141): one step = Trainer_tPSF.train_cal_loss + backward + Adam
     (train/tPSFNet_train.py:180-190) on `--batch` samples (default 8192, BASELINE configs[2]); the forward-only
@@ -359,8 +369,10 @@ def main_tpsf(args):
                                    "(BASELINE configs[2] shape)" % B, "batch_per_gpu": B, "parallelism": f"replicas x{world}"},
             "forward_only": {"samples_per_s": round(vf, 1), "ms_per_batch": round(dtf / args.steps * 1e3, 3)},
             "roofline": {"bound": "hbm", "achieved": round(vf / world * fwd_bytes / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(vf / world * fwd_bytes / 8e12, 4), "traffic": None,
-                         "kernel": "tpsf_fwd_kernel (forward-only rate x %d algorithmic bytes/sample)" % fwd_bytes},
+                         "frac": round(vf / world * fwd_bytes / 8e12, 4), "traffic": tpsf_traffic(B),
+                         "traffic_unit": "bytes/launch (PMC, profiles/r*_tpsf_pmc.json)",
+                         "algorithmic_bytes_per_launch": B * fwd_bytes,
+                         "kernel": "tpsf_fwd_mfma_kernel (+ the MLP launches: forward-only rate x %d algorithmic bytes/sample)" % fwd_bytes},
             "loss": float(loss.detach()),
         }), flush=True)
     if world > 1:
