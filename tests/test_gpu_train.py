@@ -243,8 +243,8 @@ def test_eval_func_after_training_uses_updated_running_stats(T):
     assert not torch.equal(m(batch[0].cuda()), y0)
 
 
-@pytest.mark.parametrize("Tn,nm,B", [(2, 1, 3), (2, 1, 4), (1, 2, 3)])
-def test_train_multiframe_and_odd_batch_vs_oracle(T, Tn, nm, B):
+@pytest.mark.parametrize("Tn,nm,B,sf", [(2, 1, 3, 10), (2, 1, 4, 10), (1, 2, 3, 10), (1, 1, 2, 25), (2, 1, 1, 25)])
+def test_train_multiframe_and_odd_batch_vs_oracle(T, Tn, nm, B, sf):
     """seqsCnt=2 (two stems -> channel-stacked fuse conv) and odd batches (image-pair tail): loss, running stats
     and every gradient against the CPU oracle run in fp64.
 
@@ -253,19 +253,21 @@ def test_train_multiframe_and_odd_batch_vs_oracle(T, Tn, nm, B):
     of zero makes the ReLU mask of two faithful fp32 implementations disagree on that single element (verified
     with tools/_dbg.py: at B=3 exactly 1 of 1,228,800 elements of one dz tensor differs, where the BatchNorm
     output is 1.06e-6 against a typical 0.77); its gradient then enters or leaves the sums, which moves
-    individual weight-gradient entries by ~1e-3 of the max while leaving the tensor as a whole untouched."""
-    cfg = dict(seqsCnt=Tn, patternFeatureExtraLayerCnt=nm)
+    individual weight-gradient entries by ~1e-3 of the max while leaving the tensor as a whole untouched.
+    sf=25 is the tactileSRSeqs output size: 100x100 = 12.5 patches of 8 (ragged tiles in every train-mode epilogue,
+    dgrad and wgrad)."""
+    cfg = dict(seqsCnt=Tn, patternFeatureExtraLayerCnt=nm, scale_factor=sf)
     sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), 977)
     g = torch.Generator().manual_seed(978)
     LR = torch.rand(B, 3 * Tn, 4, 4, generator=g) * 8
-    HR = torch.rand(B, 1, 40, 40, generator=g) * 25
+    HR = torch.rand(B, 1, 4 * sf, 4 * sf, generator=g) * 25
 
     def oracle(dt):
         leaves = {k: v.to(dt).requires_grad_(True) for k, v in sd.items() if O.is_trainable(k)}
         full = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}
         full.update(leaves)
         ns = {}
-        out = O.tactilesr_forward(full, LR.to(dt), training=True, new_stats=ns)
+        out = O.tactilesr_forward(full, LR.to(dt), scale_factor=sf, training=True, new_stats=ns)
         loss = F.mse_loss(out, HR.to(dt))
         gl = torch.autograd.grad(loss, list(leaves.values()))
         return loss.item(), dict(zip(leaves, gl)), ns
