@@ -149,6 +149,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
   if (a.out_amax) {     // one atomic per wave: |v| >= 0, so the uint order of the bit patterns is the float order
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    if ((h | li) == 0) atomicMax((unsigned int*)a.out_amax, __float_as_uint(amax));
+    if ((h | li) == 0) publish_amax(a.out_amax, amax);
   }
 }

@@ -21,6 +21,9 @@ __device__ __forceinline__ void bilin_src(int dst, float scale, int n_in, int& i
   lam = src - (float)i0;
 }
 
+// One workgroup = a band of RB output rows of one image.  A thread item = 4 consecutive pixels of a row x one
+// 16-channel block: per (input channel, kernel row) it reads 6 upsampled values and per tap the 16 weights, i.e.
+// 162 LDS reads for 1728 FMAs (a pixel-per-thread mapping needs 4x the weight reads and is LDS/issue bound).
 template <int CIN>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ lr, int lr_ctot, int lr_coff,
                                                    int hin, int win, int sf,
@@ -31,7 +34,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ lr,
                                                    int relu, int B, int RB, float* __restrict__ out_amax) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = hin * sf, W = win * sf;
-  const int WP = W + 2;
+  const int NQ = (W + 3) >> 2;            // pixel quads per row
+  const int WP = NQ * 4 + 2;              // padded row of the upsampled band (zero beyond the image)
   float* wl = smem;                       // [9*CIN][64]
   float* tax = wl + 9 * CIN * 64;         // [CIN][hin*win]
   float* up = tax + ((CIN * hin * win + 3) & ~3);  // [CIN][RB+2][WP]
@@ -72,51 +76,66 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ lr,
   __syncthreads();
 
   const int HW = H * W;
-  const int npix = rows * W;
+  const int nq = rows * NQ;
   const int out_blocks = out_ctot >> 4;
   float amax = 0.f;
-  for (int it = tid; it < npix * 4; it += 256) {
-    const int blk = it / npix, p = it - blk * npix;
-    const int y = p / W, x = p - y * W;
-    float acc[16];
+  for (int it = tid; it < nq * 4; it += 256) {
+    const int blk = it / nq, p = it - blk * nq;
+    const int y = p / NQ, x0 = (p - y * NQ) * 4;
+    float acc[4][16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int px = 0; px < 4; ++px)
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+      for (int j = 0; j < 16; ++j) acc[px][j] = 0.f;
+#pragma unroll 1
+    for (int ck = 0; ck < CIN * 3; ++ck) {          // (input channel, kernel row): rolled, the body is 192 FMAs
+        const int c = ck / 3, kh = ck - c * 3;
+        const float* ur = up + (c * (RB + 2) + y + kh) * WP + x0;
+        float u[6];
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw)
+        for (int j = 0; j < 6; ++j) u[j] = ur[j];
 #pragma unroll
-        for (int c = 0; c < CIN; ++c) {
-          const float u = up[(c * (RB + 2) + y + kh) * WP + x + kw];
+        for (int kw = 0; kw < 3; ++kw) {
           const f32x4* wr = (const f32x4*)(wl + ((kh * 3 + kw) * CIN + c) * 64 + blk * 16);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 wv = wr[q];
-            acc[4 * q + 0] = fmaf(u, wv[0], acc[4 * q + 0]);
-            acc[4 * q + 1] = fmaf(u, wv[1], acc[4 * q + 1]);
-            acc[4 * q + 2] = fmaf(u, wv[2], acc[4 * q + 2]);
-            acc[4 * q + 3] = fmaf(u, wv[3], acc[4 * q + 3]);
+#pragma unroll
+            for (int px = 0; px < 4; ++px)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[px][4 * q + j] = fmaf(u[px + kw], wv[j], acc[px][4 * q + j]);
           }
         }
+    }
     const int oc = out_coff + blk * 16;
-    float* o = out + (((size_t)b * out_blocks + (oc >> 4)) * HW + (size_t)(y0 + y) * W + x) * 16;
+    float* o = out + (((size_t)b * out_blocks + (oc >> 4)) * HW + (size_t)(y0 + y) * W + x0) * 16;
+    f32x4 scv[4], shv[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      f32x4 v;
+      scv[q] = scale ? *(const f32x4*)(scale + blk * 16 + 4 * q) : (f32x4){1.f, 1.f, 1.f, 1.f};
+      shv[q] = shift ? *(const f32x4*)(shift + blk * 16 + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = blk * 16 + 4 * q + j;
-        float t = acc[4 * q + j] * (scale ? scale[n] : 1.f) + (shift ? shift[n] : 0.f);
-        v[j] = relu ? fmaxf(t, 0.f) : t;
-        amax = fmaxf(amax, fabsf(v[j]));
+    for (int px = 0; px < 4; ++px) {
+      if (x0 + px < W) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float t = acc[px][4 * q + j] * scv[q][j] + shv[q][j];
+            v[j] = relu ? fmaxf(t, 0.f) : t;
+            amax = fmaxf(amax, fabsf(v[j]));
+          }
+          ((f32x4*)(o + px * 16))[q] = v;
+        }
       }
-      ((f32x4*)o)[q] = v;
     }
   }
   if (out_amax) {      // max |output| for the fp16-split consumer's power-of-two scale
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    if ((tid & 63) == 0) atomicMax((unsigned int*)out_amax, __float_as_uint(amax));
+    if ((tid & 63) == 0) publish_amax(out_amax, amax);
   }
 }
 
@@ -127,9 +146,25 @@ extern "C" int tsr_stem_fwd(const float* lr, int lr_ctot, int lr_coff, int axis_
   if ((out_ctot & 15) || (out_coff & 15) || out_coff + 64 > out_ctot || lr_coff + axis_cnt > lr_ctot)
     return TSR_ERR_ARG;
   const int H = hin * sf, W = win * sf;
-  const int RB = 8;
-  const size_t smem = (size_t)(9 * 3 * 64 + ((3 * hin * win + 3) & ~3) + 3 * (RB + 2) * (W + 2)) * 4;
-  if (smem > 64 * 1024) return TSR_ERR_ARG;
+  const int NQ = (W + 3) >> 2, WP = NQ * 4 + 2;
+  // rows per workgroup: the band (RB+2 rows of 3 channels) must fit 64 KB of LDS with the weights; among the
+  // fitting sizes take the one whose item count (rows x quads x 4 blocks) fills its 256-thread passes best
+  const size_t fixed = (size_t)(9 * 3 * 64 + ((3 * hin * win + 3) & ~3)) * 4;
+  int RB = 0;
+  double best = -1.0;
+  for (int rb = 4; rb <= H; ++rb) {
+    if (fixed + (size_t)3 * (rb + 2) * WP * 4 > 64 * 1024) break;
+    long items = 0, slots = 0;
+    for (int y = 0; y < H; y += rb) {
+      const int r = H - y < rb ? H - y : rb;
+      items += (long)r * NQ * 4;
+      slots += ((long)r * NQ * 4 + 255) / 256 * 256;
+    }
+    const double eff = (double)items / (double)slots;
+    if (eff > best + 1e-9) { best = eff; RB = rb; }
+  }
+  if (RB == 0) return TSR_ERR_ARG;
+  const size_t smem = fixed + (size_t)3 * (RB + 2) * WP * 4;
   dim3 grid((H + RB - 1) / RB, B);
   hipLaunchKernelGGL((stem_kernel<3>), grid, dim3(256), smem, (hipStream_t)stream, lr, lr_ctot, lr_coff, hin,
                      win, sf, w_oihw, scale, shift, out, out_ctot, out_coff, relu, B, RB, out_amax);

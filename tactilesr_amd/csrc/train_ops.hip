@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g
   if (out_amax) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    if ((threadIdx.x & 63) == 0) atomicMax((unsigned int*)out_amax, __float_as_uint(amax));
+    if ((threadIdx.x & 63) == 0) publish_amax(out_amax, amax);
   }
 }
 
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   if (out_amax) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    if ((tid & 63) == 0) atomicMax((unsigned int*)out_amax, __float_as_uint(amax));
+    if ((tid & 63) == 0) publish_amax(out_amax, amax);
   }
 }
 
