@@ -384,7 +384,7 @@ class TrainEngine:
         new_amax = self._amax_pool(c, dev)      # a gradient tensor consumed by an MFMA launch carries max|.|
         dout = dout.contiguous().float()
         # ---- head: out = relu(conv(h0)), h0 = relu(conv(hcat))
-        ns = max(1, min(B, 256))
+        ns = max(1, min(B, 2048))     # image splits: ~8 resident workgroups per CU hide the load latency
         dz_h0 = buf(128)
         am_dzh0 = new_amax()
         wslab = torch.empty(ns * 128 * 9, dtype=torch.float32, device=dev)
@@ -420,7 +420,7 @@ class TrainEngine:
             am = new_amax()
             self._dgrad(c, D1, rb.conv1, 0, 64, d0, 64, 0, res=dpre, mask=s.X, out_amax=am)
             dpre = Act(d0, 64, 0, 64, amax=am)
-        ns = max(1, min(B, 256))
+        ns = max(1, min(B, 2048))     # image splits: ~8 resident workgroups per CU hide the load latency
         sslab = torch.empty(ns * 64 * 27, dtype=torch.float32, device=dev)
         call("tsr_stem_wgrad", ptr(c.x), _I(c.x.shape[1]), _I(0), _I(c.hin), _I(c.win), _I(m.scale_factor),
              ptr(dpre.buf), _I(dpre.ctot), _I(dpre.coff), ptr(sslab), _I(ns), _I(B), stream())
@@ -498,7 +498,7 @@ class TrainEngine:
             self._dgrad(c, DZ2, seq[4], 0, 64, g1, 64, 0, mask=A1, bn=True)
             r = self._bn_bwd(c, g1, 64, 0, Act(c.z1[t], 64, 0, 64), 0, 64, v1, None, grads, "")
             grads[name + ".2.weight"], grads[name + ".2.bias"] = r[0].clone(), r[1].clone()
-            ns = max(1, min(B, 256))
+            ns = max(1, min(B, 2048))     # image splits: ~8 resident workgroups per CU hide the load latency
             sslab = torch.empty(ns * 64 * 27, dtype=torch.float32, device=dev)
             call("tsr_stem_wgrad", ptr(c.x), _I(c.x.shape[1]), _I(m.axisCnt * t), _I(c.hin), _I(c.win),
                  _I(m.scale_factor), ptr(g1), _I(64), _I(0), ptr(sslab), _I(ns), _I(B), stream())
