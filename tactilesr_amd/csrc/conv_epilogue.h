@@ -33,29 +33,62 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
       rbase = a.res + (((size_t)bsafe * res_blocks + (rc >> 4)) * HW) * 16 + (rc & 15);
     }
     if (!EXT || a.epi_mode == 0) {
-      // y = acc*scale + shift (+ residual) (ReLU) -> channel slice of out
-      if (!img_ok) continue;
-      const float sc = a.scale ? a.scale[n] : 1.f;
-      const float sh = a.shift ? a.shift[n] : 0.f;
-      const float rsc = (EXT && a.res_scale) ? a.res_scale[n] : 1.f;
-      const float rsh = (EXT && a.res_scale) ? a.res_shift[n] : 0.f;
+      // y = acc*scale + shift (+ residual) (ReLU) -> channel slice of out.
+      // The accumulator holds (lane = channel, register = pixel); a 4x4 transpose inside every lane quad (registers
+      // r&3 = 4 adjacent pixels of a row <-> lanes li&3 = 4 adjacent channels) turns that into (lane = pixel,
+      // registers = 4 consecutive channels), so the residual read and the store are 16 B per lane and one
+      // instruction covers whole 64-B CB16 lines (eight pixels x two channel blocks) instead of 4-B pieces.
+      const int k4 = li >> 2, j = li & 3;                       // channel quad of this nb block, pixel within the row half
+      const int nq = wn * (COUT / WN) + nb * 32 + 4 * k4;       // first of this lane's 4 channels after the transpose
+      const int oq = a.out_coff + nq;
+      f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f}, rsc4 = sc4, rsh4 = sh4;
+      if (a.scale) sc4 = *(const f32x4*)(a.scale + nq);
+      if (a.shift) sh4 = *(const f32x4*)(a.shift + nq);
+      if (EXT && a.res_scale) { rsc4 = *(const f32x4*)(a.res_scale + nq); rsh4 = *(const f32x4*)(a.res_shift + nq); }
+      float* ob4 = a.out + (((size_t)bsafe * out_blocks + (oq >> 4)) * HW) * 16 + (oq & 15);
+      const float* rb4 = nullptr;
+      if (a.res) {
+        const int rq = a.res_coff + nq;
+        rb4 = a.res + (((size_t)bsafe * res_blocks + (rq >> 4)) * HW) * 16 + (rq & 15);
+      }
+      const int gx = x0 + j + 4 * h;
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int gy = y0 + 4 * mb + (m >> 3), gx = x0 + (m & 7);
-          if (gy < a.H && gx < a.W) {
+        for (int g = 0; g < 4; ++g) {
+          float t0 = acc[mb][nb][4 * g + 0], t1 = acc[mb][nb][4 * g + 1], t2 = acc[mb][nb][4 * g + 2],
+                t3 = acc[mb][nb][4 * g + 3];
+          {   // 4x4 transpose across the lane quad: exchange with lane^1, then with lane^2
+            const float s01 = (j & 1) ? t0 : t1, s23 = (j & 1) ? t2 : t3;
+            const float x01 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s01), 0xB1, 0xF, 0xF, true));
+            const float x23 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s23), 0xB1, 0xF, 0xF, true));
+            if (j & 1) { t0 = x01; t2 = x23; } else { t1 = x01; t3 = x23; }
+            const float s02 = (j & 2) ? t0 : t2, s13 = (j & 2) ? t1 : t3;
+            const float x02 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s02), 0x4E, 0xF, 0xF, true));
+            const float x13 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s13), 0x4E, 0xF, 0xF, true));
+            if (j & 2) { t0 = x02; t1 = x13; } else { t2 = x02; t3 = x13; }
+          }
+          const int gy = y0 + 4 * mb + g;
+          if (img_ok && gy < a.H && gx < a.W) {
             const size_t po = (size_t)(gy * a.W + gx) * 16;
-            float v = (acc[mb][nb][r] * accmul) * sc + sh;
-            if (rbase) {
-              float rv = rbase[po];
-              if (EXT && a.res_scale) rv = fmaxf(fmaf(rv, rsc, rsh), 0.f);
-              v += rv;
+            f32x4 v = {t0, t1, t2, t3};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = (v[c] * accmul) * sc4[c] + sh4[c];
+            if (rb4) {
+              f32x4 rv = *(const f32x4*)(rb4 + po);
+              if (EXT && a.res_scale) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rv[c] = fmaxf(fmaf(rv[c], rsc4[c], rsh4[c]), 0.f);
+              }
+#pragma unroll
+              for (int c = 0; c < 4; ++c) v[c] += rv[c];
             }
-            if (a.relu) v = fmaxf(v, 0.f);
-            obase[po] = v;
-            amax = fmaxf(amax, fabsf(v));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (a.relu) v[c] = fmaxf(v[c], 0.f);
+              amax = fmaxf(amax, fabsf(v[c]));
+            }
+            *(f32x4*)(ob4 + po) = v;
           }
         }
       }
