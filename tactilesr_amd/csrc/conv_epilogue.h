@@ -7,6 +7,19 @@
 #include "tsr_common.h"
 #include "conv_args.h"
 
+// 4x4 transpose inside every quad of lanes: before, lane j of the quad holds (t0..t3) = its value for 4 items;
+// after, lane j holds item j's values of the quad's lanes 0..3.  Two butterfly exchanges (lane^1, lane^2) on DPP.
+__device__ __forceinline__ void quad_transpose(float& t0, float& t1, float& t2, float& t3, int j) {
+  const float s01 = (j & 1) ? t0 : t1, s23 = (j & 1) ? t2 : t3;
+  const float x01 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s01), 0xB1, 0xF, 0xF, true));
+  const float x23 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s23), 0xB1, 0xF, 0xF, true));
+  if (j & 1) { t0 = x01; t2 = x23; } else { t1 = x01; t3 = x23; }
+  const float s02 = (j & 2) ? t0 : t2, s13 = (j & 2) ? t1 : t3;
+  const float x02 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s02), 0x4E, 0xF, 0xF, true));
+  const float x13 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s13), 0x4E, 0xF, 0xF, true));
+  if (j & 2) { t0 = x02; t1 = x13; } else { t2 = x02; t3 = x13; }
+}
+
 // accmul: exact power-of-two factor undoing the operand scaling of the fp16-split path (1 otherwise).
 // WN = waves across C_out (2: each wave owns C_out/2 of one of 2 images; 1: each wave owns all C_out of one of 4).
 template <int COUT, bool EXT, int WN = 2>
@@ -58,16 +71,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
         for (int g = 0; g < 4; ++g) {
           float t0 = acc[mb][nb][4 * g + 0], t1 = acc[mb][nb][4 * g + 1], t2 = acc[mb][nb][4 * g + 2],
                 t3 = acc[mb][nb][4 * g + 3];
-          {   // 4x4 transpose across the lane quad: exchange with lane^1, then with lane^2
-            const float s01 = (j & 1) ? t0 : t1, s23 = (j & 1) ? t2 : t3;
-            const float x01 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s01), 0xB1, 0xF, 0xF, true));
-            const float x23 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s23), 0xB1, 0xF, 0xF, true));
-            if (j & 1) { t0 = x01; t2 = x23; } else { t1 = x01; t3 = x23; }
-            const float s02 = (j & 2) ? t0 : t2, s13 = (j & 2) ? t1 : t3;
-            const float x02 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s02), 0x4E, 0xF, 0xF, true));
-            const float x13 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s13), 0x4E, 0xF, 0xF, true));
-            if (j & 2) { t0 = x02; t1 = x13; } else { t2 = x02; t3 = x13; }
-          }
+          quad_transpose(t0, t1, t2, t3, j);
           const int gy = y0 + 4 * mb + g;
           if (img_ok && gy < a.H && gx < a.W) {
             const size_t po = (size_t)(gy * a.W + gx) * 16;
@@ -104,7 +108,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
           acc[mb][nb][r] *= accmul;
           if (img_ok && gy < a.H && gx < a.W) {
             const float v = acc[mb][nb][r];
-            obase[(size_t)(gy * a.W + gx) * 16] = v;
             cnt += 1.f;
             sum += v;
             amax = fmaxf(amax, fabsf(v));
@@ -138,43 +141,82 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
         sl[1] = m2m;
         if (nb == 0 && li == 0 && wn == 0) a.slab_cnt[e] = nt;
       }
+      {   // raw accumulator -> out, as 16-B stores after the quad transpose (see mode 0)
+        const int k4 = li >> 2, j = li & 3;
+        const int oq = a.out_coff + wn * (COUT / WN) + nb * 32 + 4 * k4;
+        float* ob4 = a.out + (((size_t)bsafe * out_blocks + (oq >> 4)) * HW) * 16 + (oq & 15);
+        const int gx = x0 + j + 4 * h;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float t0 = acc[mb][nb][4 * g + 0], t1 = acc[mb][nb][4 * g + 1], t2 = acc[mb][nb][4 * g + 2],
+                  t3 = acc[mb][nb][4 * g + 3];
+            quad_transpose(t0, t1, t2, t3, j);
+            const int gy = y0 + 4 * mb + g;
+            if (img_ok && gy < a.H && gx < a.W) *(f32x4*)(ob4 + (size_t)(gy * a.W + gx) * 16) = (f32x4){t0, t1, t2, t3};
+          }
+      }
     } else if (EXT) {
-      // ReLU backward by the stored activation (+ optional BN-backward partial sums)
-      const int mc = a.mask_coff + n;
-      const float* mbase = a.mask + (((size_t)bsafe * mask_blocks + (mc >> 4)) * HW) * 16 + (mc & 15);
-      const float msc = a.mask_scale ? a.mask_scale[n] : 1.f;
-      const float msh = a.mask_scale ? a.mask_shift[n] : 0.f;
-      const float ba = a.bn_a ? a.bn_a[n] : 0.f;
-      const float bb = a.bn_a ? a.bn_b[n] : 0.f;
-      const float sc = a.scale ? a.scale[n] : 1.f;
-      float s1 = 0.f, s2 = 0.f;
+      // ReLU backward by the stored activation (+ optional BN-backward partial sums), in the transposed layout of
+      // mode 0: residual, mask and output move as 16 B per lane; the per-channel sums are then reduced over the 8
+      // lanes (4 of the quad x 2 wave halves) that hold the same 4 channels.
+      const int k4 = li >> 2, j = li & 3;
+      const int nq = wn * (COUT / WN) + nb * 32 + 4 * k4;
+      const int oq = a.out_coff + nq, mq = a.mask_coff + nq;
+      float* ob4 = a.out + (((size_t)bsafe * out_blocks + (oq >> 4)) * HW) * 16 + (oq & 15);
+      const float* mb4 = a.mask + (((size_t)bsafe * mask_blocks + (mq >> 4)) * HW) * 16 + (mq & 15);
+      const float* rb4 = nullptr;
+      if (a.res) {
+        const int rq = a.res_coff + nq;
+        rb4 = a.res + (((size_t)bsafe * res_blocks + (rq >> 4)) * HW) * 16 + (rq & 15);
+      }
+      f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 sc4 = a.scale ? *(const f32x4*)(a.scale + nq) : one4;
+      const f32x4 msc4 = a.mask_scale ? *(const f32x4*)(a.mask_scale + nq) : one4;
+      const f32x4 msh4 = a.mask_scale ? *(const f32x4*)(a.mask_shift + nq) : zero4;
+      const f32x4 ba4 = a.bn_a ? *(const f32x4*)(a.bn_a + nq) : zero4;
+      const f32x4 bb4 = a.bn_a ? *(const f32x4*)(a.bn_b + nq) : zero4;
+      f32x4 s1 = zero4, s2 = zero4;
+      const int gx = x0 + j + 4 * h;
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
+      for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int gy = y0 + 4 * mb + (m >> 3), gx = x0 + (m & 7);
+        for (int g = 0; g < 4; ++g) {
+          float t0 = acc[mb][nb][4 * g + 0], t1 = acc[mb][nb][4 * g + 1], t2 = acc[mb][nb][4 * g + 2],
+                t3 = acc[mb][nb][4 * g + 3];
+          quad_transpose(t0, t1, t2, t3, j);
+          const int gy = y0 + 4 * mb + g;
           if (img_ok && gy < a.H && gx < a.W) {
             const size_t po = (size_t)(gy * a.W + gx) * 16;
-            float v = (acc[mb][nb][r] * accmul) * sc;
-            if (rbase) v += rbase[po];
-            const float mv = mbase[po];
-            if (!(fmaf(mv, msc, msh) > 0.f)) v = 0.f;
-            obase[po] = v;
-            amax = fmaxf(amax, fabsf(v));
-            s1 += v;
-            s2 = fmaf(v, fmaf(mv, ba, bb), s2);
+            f32x4 v = {t0, t1, t2, t3};
+            const f32x4 mv = *(const f32x4*)(mb4 + po);
+            f32x4 rv = zero4;
+            if (rb4) rv = *(const f32x4*)(rb4 + po);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              float x = (v[c] * accmul) * sc4[c] + rv[c];
+              if (!(fmaf(mv[c], msc4[c], msh4[c]) > 0.f)) x = 0.f;
+              v[c] = x;
+              amax = fmaxf(amax, fabsf(x));
+              s1[c] += x;
+              s2[c] = fmaf(x, fmaf(mv[c], ba4[c], bb4[c]), s2[c]);
+            }
+            *(f32x4*)(ob4 + po) = v;
           }
         }
-      }
       if (a.bn_a) {
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (h == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          s1[c] += __shfl_xor(s1[c], 1); s2[c] += __shfl_xor(s2[c], 1);
+          s1[c] += __shfl_xor(s1[c], 2); s2[c] += __shfl_xor(s2[c], 2);
+          s1[c] += __shfl_xor(s1[c], 32); s2[c] += __shfl_xor(s2[c], 32);
+        }
+        if (h == 0 && j == 0) {
           const size_t e = (size_t)bid * IMG + wm;
-          float* sl = a.slab + (e * COUT + n) * 2;
-          sl[0] = s1;
-          sl[1] = s2;
+          float* sl = a.slab + (e * COUT + nq) * 2;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { sl[2 * c] = s1[c]; sl[2 * c + 1] = s2[c]; }
         }
       }
     }
