@@ -172,6 +172,9 @@ extern "C" int tsr_stem_fwd(const float* lr, int lr_ctot, int lr_coff, int axis_
 }
 
 // ---------------------------------------------------------------------------------------
+// Thread = (pixel, channel quad): the four lanes of a pixel read the four 16-B quarters of each 64-B CB16 line, so a
+// load instruction consumes whole lines (a lane per pixel reads every line in four instructions: 4x the L1 tag
+// work on an HBM-read-bound kernel); the partial dot products meet through two DPP adds.
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ in, int in_ctot, int cin,
                                                    const float* __restrict__ w,   // OIHW (1,cin,3,3)
                                                    float* __restrict__ out, int relu, int B, int H, int W) {
@@ -186,45 +189,44 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ in,
   __syncthreads();
   const int HW = H * W;
   const int b = blockIdx.y;
-  const int p = blockIdx.x * 256 + tid;
-  if (p >= HW) return;
-  const int y = p / W, x = p - y * W;
+  const int q = tid & 3;
+  const int p = blockIdx.x * 64 + (tid >> 2);
+  const bool live = p < HW;                      // (no early return: the quad reduction below needs all four lanes)
+  const int pc = live ? p : HW - 1;
+  const int y = pc / W, x = pc - y * W;
   const int in_blocks = in_ctot >> 4;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;            // one accumulator per kernel row: three independent FMA chains
   for (int blk = 0; blk < nblk; ++blk) {
-    const float* plane = in + ((size_t)b * in_blocks + blk) * HW * 16;
+    const float* plane = in + ((size_t)b * in_blocks + blk) * HW * 16 + 4 * q;
+    const float* wb = wl + blk * 9 * 16 + 4 * q;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
       const int gy = y + kh - 1;
       if (gy < 0 || gy >= H) continue;
+      float s = 0.f;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int gx = x + kw - 1;
         if (gx < 0 || gx >= W) continue;
-        const f32x4* src = (const f32x4*)(plane + (size_t)(gy * W + gx) * 16);
-        const f32x4* wr = (const f32x4*)(wl + (blk * 9 + kh * 3 + kw) * 16);
-        const f32x4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-        const f32x4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          a0 = fmaf(v0[j], w0[j], a0);
-          a1 = fmaf(v1[j], w1[j], a1);
-          a2 = fmaf(v2[j], w2[j], a2);
-          a3 = fmaf(v3[j], w3[j], a3);
-        }
+        const f32x4 v = *(const f32x4*)(plane + (size_t)(gy * W + gx) * 16);
+        const f32x4 wv = *(const f32x4*)(wb + (kh * 3 + kw) * 16);
+        s = fmaf(v[0], wv[0], fmaf(v[1], wv[1], fmaf(v[2], wv[2], fmaf(v[3], wv[3], s))));
       }
+      if (kh == 0) a0 += s; else if (kh == 1) a1 += s; else a2 += s;
     }
   }
-  float v = (a0 + a1) + (a2 + a3);
+  float v = (a0 + a1) + a2;
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // lane ^ 2
   if (relu) v = fmaxf(v, 0.f);
-  out[(size_t)b * HW + p] = v;
+  if (live && q == 0) out[(size_t)b * HW + p] = v;
 }
 
 extern "C" int tsr_head_fwd(const float* in, int in_ctot, int cin, const float* w_oihw, float* out_nchw,
                             int relu, int B, int H, int W, void* stream) {
   if (!in || !w_oihw || !out_nchw || B <= 0 || (cin & 15) || (in_ctot & 15) || cin > in_ctot || cin <= 0)
     return TSR_ERR_ARG;
-  dim3 grid((H * W + 255) / 256, B);
+  dim3 grid((H * W + 63) / 64, B);
   const size_t smem = (size_t)cin * 9 * 4;
   hipLaunchKernelGGL(head_kernel, grid, dim3(256), smem, (hipStream_t)stream, in, in_ctot, cin, w_oihw,
                      out_nchw, relu, B, H, W);
