@@ -163,19 +163,40 @@ __global__ __launch_bounds__(256, 3) void wgrad_mfma_f32_kernel(const WgradArgs 
 }
 
 // out[i] = sum_s slab[s][i]  (fp64 accumulation, deterministic)
-__global__ void reduce_splits_kernel(const float* __restrict__ slab, float* __restrict__ out, size_t n,
-                                     int nsplit, float alpha) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    double s = 0.0;
-    for (int k = 0; k < nsplit; ++k) s += (double)slab[(size_t)k * n + i];
-    out[i] = (float)(s * alpha);
+// out[i] = alpha * sum_k slab[k][i], fp64, fixed order (deterministic).  A workgroup owns 32 outputs; its 8 groups of
+// 32 lanes each walk every 8th split (two independent chains per lane) and meet in LDS -- a lane per output with a
+// serial walk over up to 340 splits leaves small layers with ~100 latency-bound workgroups.
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                            size_t n, int nsplit, float alpha) {
+  __shared__ double part[8][32];
+  const int il = threadIdx.x & 31, kp = threadIdx.x >> 5;
+  for (size_t i0 = (size_t)blockIdx.x * 32; i0 < n; i0 += (size_t)gridDim.x * 32) {
+    const size_t i = i0 + il;
+    double s0 = 0.0, s1 = 0.0;
+    if (i < n) {
+      int k = kp;
+      for (; k + 8 < nsplit; k += 16) {
+        s0 += (double)slab[(size_t)k * n + i];
+        s1 += (double)slab[(size_t)(k + 8) * n + i];
+      }
+      if (k < nsplit) s0 += (double)slab[(size_t)k * n + i];
+    }
+    __syncthreads();
+    part[kp][il] = s0 + s1;
+    __syncthreads();
+    if (kp == 0 && i < n) {
+      double s = part[0][il];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) s += part[q][il];
+      out[i] = (float)(s * alpha);
+    }
   }
 }
 
 extern "C" int tsr_reduce_splits(const float* slab, float* out, long long n, int nsplit, float alpha, void* stream) {
   if (!slab || !out || n <= 0 || nsplit <= 0) return TSR_ERR_ARG;
-  const size_t g = ((size_t)n + 255) / 256;
-  hipLaunchKernelGGL(reduce_splits_kernel, dim3(g > 8192 ? 8192 : (int)g), dim3(256), 0, (hipStream_t)stream, slab,
+  const size_t g = ((size_t)n + 31) / 32;
+  hipLaunchKernelGGL(reduce_splits_kernel, dim3(g > 65535 ? 65535 : (int)g), dim3(256), 0, (hipStream_t)stream, slab,
                      out, (size_t)n, nsplit, alpha);
   return tsr_check_launch();
 }
