@@ -1,0 +1,1 @@
+from .device_loader import DeviceSRLoader  # noqa: F401,E402

@@ -110,3 +110,36 @@ def test_dataset_file_format_reads_like_the_reference_loader(tmp_path):
     item = ds[3].item()                              # :44  self.SRdataset[idx].item()['LR']
     assert set(item) == {"LR", "depth", "HR", "LR_degrade", "alphaBeta"}
     assert np.ascontiguousarray(item["LR"]).shape == (3, 4, 4) and float(item["HR"].mean()) == 3.0
+
+
+def test_device_resident_loader_protocol(tmp_path):
+    """DeviceSRLoader yields the (LR, HR) tuples the trainer glue takes from the reference's DataLoader: sequential
+    order without shuffle, a fresh seeded permutation per epoch with it, drop_last, rank shards, and it reads the
+    generator's dataset file."""
+    from tactilesr_amd.data import DeviceSRLoader, depth2tactile as D
+    n = 11
+    LR = torch.arange(n, dtype=torch.float32).view(n, 1, 1, 1).expand(n, 3, 4, 4).clone()
+    HR = LR[:, :1, :1, :1].expand(n, 1, 100, 100).clone() * 2
+    ld = DeviceSRLoader(LR, HR, batch_size=4, device="cpu")
+    assert len(ld) == 3
+    got = [b for b in ld]
+    assert [b[0].shape[0] for b in got] == [4, 4, 3]
+    assert torch.equal(torch.cat([b[0] for b in got]), LR) and torch.equal(torch.cat([b[1] for b in got]), HR)
+    ld = DeviceSRLoader(LR, HR, batch_size=4, shuffle=True, drop_last=True, seed=7, device="cpu")
+    assert len(ld) == 2
+    e1 = torch.cat([b[0][:, 0, 0, 0] for b in ld])
+    e2 = torch.cat([b[0][:, 0, 0, 0] for b in ld])
+    assert e1.numel() == 8 and len(set(e1.tolist())) == 8 and not torch.equal(e1, e2)
+    again = DeviceSRLoader(LR, HR, batch_size=4, shuffle=True, drop_last=True, seed=7, device="cpu")
+    assert torch.equal(torch.cat([b[0][:, 0, 0, 0] for b in again]), e1)
+    for b in DeviceSRLoader(LR, HR, batch_size=4, shuffle=True, seed=1, device="cpu"):   # pairs stay aligned
+        assert torch.equal(b[1][:, 0, 0, 0], b[0][:, 0, 0, 0] * 2)
+    shards = [DeviceSRLoader(LR, HR, batch_size=16, device="cpu", rank=r, world_size=2) for r in range(2)]
+    assert torch.equal(torch.cat([next(iter(s))[0] for s in shards]), LR)
+    entries = [[{"LR": LR[i], "depth": torch.zeros(1, 100, 100), "HR": HR[i], "LR_degrade": torch.zeros(1, 4, 4),
+                 "alphaBeta": torch.zeros(3)}] for i in range(n)]
+    path = os.path.join(tmp_path, "SRdataset_train.npy")
+    D.save_dataset(path, entries)
+    f = DeviceSRLoader.from_file(path, batch_size=n, device="cpu")
+    b = next(iter(f))
+    assert torch.equal(b[0], LR) and torch.equal(b[1], HR)
