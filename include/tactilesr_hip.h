@@ -142,6 +142,10 @@ typedef struct tsr_conv_desc {
 
 int tsr_conv2d_ex(const tsr_conv_desc* desc, void* stream);
 int tsr_conv2d_slab_entries(int B, int H, int W);
+/* Entries the launch described by (cout, ks, nsplit) writes -- the count to hand to tsr_bn_stats_finalize /
+ * tsr_bn_bwd_finalize (the fp16-split 3x3/5x5 kernels with 64 output channels use 4 images per workgroup, all other
+ * forms 2: tsr_conv2d_slab_entries is the 2-image count).  Size slabs for the larger of the two. */
+int tsr_conv2d_slab_entries_ex(int B, int H, int W, int cout, int ks, int nsplit);
 
 /* Weights of the data-gradient convolution: W'[n][co][kh][kw] = W[co][ci0+n][K-1-kh][K-1-kw],
  * n in [0,nprime), nprime in {64,128}; packed for tsr_conv2d_* with cin := cout, cout := nprime. */

@@ -308,6 +308,13 @@ extern "C" int tsr_conv2d_slab_entries(int B, int H, int W) {
   return ((B + 1) / 2) * ((W + 7) / 8) * ((H + 7) / 8) * 2;
 }
 
+// Slab entries a tsr_conv2d_ex launch with these parameters writes: one per (workgroup, image slot).  The fp16-split
+// 3x3 / 5x5 kernels with 64 output channels put 4 images in a workgroup, everything else 2.
+extern "C" int tsr_conv2d_slab_entries_ex(int B, int H, int W, int cout, int ks, int nsplit) {
+  const int img = (nsplit == -2 && cout == 64 && ks > 1) ? 4 : 2;
+  return ((B + img - 1) / img) * ((W + 7) / 8) * ((H + 7) / 8) * img;
+}
+
 int tsr_conv2d_ex_bf16s(const ConvArgs& a, int cout, int ks, int nsplit, hipStream_t st);   // conv_mfma_split16.hip
 
 extern "C" int tsr_conv2d_ex(const tsr_conv_desc* d, void* stream) {

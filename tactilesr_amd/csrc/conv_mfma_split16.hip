@@ -421,10 +421,10 @@ extern "C" int tsr_pack_conv_weight_dgrad_bf16s(const float* w_oihw, void* w_pac
 
 template <int KS, int COUT, int NS, bool EXT, bool F16>
 static int launch_bf16s(const ConvArgs& a, hipStream_t st) {
-  // inference, C_out = 64: 4 images per workgroup, every wave owns all 64 channels of one image (the training
-  // form keeps image pairs: its statistics slabs are laid out per pair, tsr_conv2d_slab_entries)
-  // (measured: helps the fp16 3x3 / 5x5 kernels; the 1x1 and the 3-plane bf16 forms are faster as pairs)
-  constexpr int WN = (!EXT && COUT == 64 && F16 && KS > 1) ? 1 : 2;
+  // C_out = 64, fp16 3x3 / 5x5: 4 images per workgroup, every wave owns all 64 channels of one image (measured: the
+  // 1x1 and the 3-plane bf16 forms are faster as pairs).  The training epilogues index their statistics slabs by
+  // (workgroup, image slot): tsr_conv2d_slab_entries_ex tells the caller how many entries this form writes.
+  constexpr int WN = (COUT == 64 && F16 && KS > 1) ? 1 : 2;
   constexpr int IMG = 4 / WN;
   const int grid = ((a.B + IMG - 1) / IMG) * a.tiles_x * a.tiles_y;
   if constexpr (KS == 3 && !(COUT == 64 && WN == 1)) {      // (4-image workgroups: two slabs would not leave 2 per CU)

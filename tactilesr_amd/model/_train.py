@@ -181,6 +181,10 @@ class TrainEngine:
         bn.num_batches_tracked.add_(1)
         return vec   # rows: scale, shift, xhat_a, xhat_b
 
+    def _entries(self, c, cout, ks):
+        """Statistics-slab entries the conv launch (cout, ks) of this engine's arithmetic writes."""
+        return _lib.load().tsr_conv2d_slab_entries_ex(c.B, c.H, c.W, cout, ks, self.nsplit)
+
     def _packw(self, c, conv):
         w = conv.weight.detach().contiguous()
         ws = c.wscale.get(id(conv), 1.0)
@@ -194,7 +198,7 @@ class TrainEngine:
         conv_ex(B=c.B, H=c.H, W=c.W, src=src, w=wp, cout=cout, ks=ks, out=out, out_ctot=out_ctot,
                 out_coff=out_coff, epi_mode=1, slab=c.slab, slab_cnt=c.slab_cnt, nsplit=self.nsplit,
                 w_inv_scale=wis, out_amax=out_amax)
-        return self._bn_finalize(c, conv.bias, bn, c.slab, c.slab_cnt, c.entries, cout)
+        return self._bn_finalize(c, conv.bias, bn, c.slab, c.slab_cnt, self._entries(c, cout, ks), cout)
 
     # ------------------------------------------------------------------ forward
     def forward(self, x: torch.Tensor):
@@ -209,8 +213,9 @@ class TrainEngine:
         lib = _lib.load()
         c.entries = lib.tsr_conv2d_slab_entries(B, H, W)
         st_entries = lib.tsr_cb16_stats_entries(B, HW)
-        c.slab = torch.empty(max(c.entries * 128 * 2, st_entries * 64 * 2), dtype=torch.float32, device=dev)
-        c.slab_cnt = torch.empty(max(c.entries, st_entries), dtype=torch.float32, device=dev)
+        e64 = max(lib.tsr_conv2d_slab_entries_ex(B, H, W, 64, k, self.nsplit) for k in (1, 3, 5))
+        c.slab = torch.empty(max(c.entries * 128 * 2, e64 * 64 * 2, st_entries * 64 * 2), dtype=torch.float32, device=dev)
+        c.slab_cnt = torch.empty(max(c.entries, e64, st_entries), dtype=torch.float32, device=dev)
         c.work = torch.empty(512 * 128 * 3, dtype=torch.float64, device=dev)
 
         def buf(ch):
@@ -358,13 +363,14 @@ class TrainEngine:
                 out_coff=out_coff, res=res, epi_mode=2 if mask is not None else 0, mask=mask, bn=bn,
                 slab=c.slab if bn else None, slab_cnt=None, nsplit=self.nsplit, w_inv_scale=1.0 / ws,
                 out_amax=out_amax)
+        c.last_entries = self._entries(c, nprime, ks)      # what a following _bn_bwd reduces
 
     def _bn_bwd(self, c, g_buf, g_ctot, g_coff, z: Act, zoff, C, bn_vec, bn_mod, grads, name, out_amax=None):
         """Finish BatchNorm backward for C channels whose masked gradient g sits in g_buf (slab sums
         were just produced by the dgrad epilogue over the same C channels)."""
         dev = g_buf.device
         out = torch.empty(5, C, dtype=torch.float32, device=dev)
-        call("tsr_bn_bwd_finalize", ptr(c.slab), _I(c.entries), _I(C), _D(float(c.B * c.HW)),
+        call("tsr_bn_bwd_finalize", ptr(c.slab), _I(c.last_entries), _I(C), _D(float(c.B * c.HW)),
              ptr(bn_vec[0]), ptr(bn_vec[2]), ptr(bn_vec[3]), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]),
              ptr(out[4]), ptr(c.work), stream())
         call("tsr_bn_bwd_apply", ptr(g_buf), _I(g_ctot), _I(g_coff), ptr(z.buf), _I(z.ctot), _I(z.coff + zoff),

@@ -95,7 +95,7 @@ def test_conv2d_dgrad_with_mask_and_bn_sums(T, ks, cin, cout, B, H, W, NP):
     zd, dyd, exd = T.to_cb16(z.cuda()), T.to_cb16(dy.cuda()), T.to_cb16(extra.cuda())
     gbuf = torch.empty(B * cin * H * W, device="cuda")
     lib = load()
-    entries = lib.tsr_conv2d_slab_entries(B, H, W)
+    entries = lib.tsr_conv2d_slab_entries_ex(B, H, W, NP, ks, 0)        # fp32-MFMA dgrad here (nsplit = 0)
     work = torch.empty(512 * 128 * 3, dtype=torch.float64, device="cuda")
     wd = w.cuda().contiguous()
     dgam, dbet = [], []
