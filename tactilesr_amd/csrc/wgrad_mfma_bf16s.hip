@@ -63,6 +63,7 @@ __device__ __forceinline__ void split_store8(const float (&v)[8], char* dst, int
 template <int KS, int NS, bool F16>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_bf16s_kernel(const WgradBArgs g) {
   typedef typename WPlane<F16>::V8 PV8;
+  typedef typename WPlane<F16>::T PV4 __attribute__((ext_vector_type(4)));
   constexpr int P = KS / 2;
   constexpr int XH = 8 + KS - 1;
   constexpr int DZ_PLANE = 8 * 64 * 16;        // bytes per bf16 plane of the dz tile
@@ -101,8 +102,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_bf16s_kernel(const WgradBAr
   const bool do_bias = g.bslab && cib == 0 && kh == 0;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};        // this thread's dz item: 4 channels, summed over rows and patches
 
-  const int laneA = (h * 64 + wc * 32 + li) * 16;
-  const int laneB = (h * 64 + wi * 32 + li) * 16;
+  // fragment pieces: a lane holds 4 of the 8 patch rows (its half h) of one column = 8 B; an MFMA K step of 16 is
+  // (2 columns x 8 rows), i.e. two pieces per lane.  The columns of consecutive taps kw overlap, so every piece is
+  // read from LDS once per work item and the 16-B fragments are sliding windows over the piece registers (reading
+  // whole 16-B fragments per (column pair, tap) moves 2.4x the LDS bytes).
+  const int pieceA = (wc * 32 + li) * 16 + 8 * h;
+  const int pieceB = (wi * 32 + li) * 16 + 8 * h;
 
   // ---- staging roles (fixed per thread).  Round 0: thread -> one (column, 4-channel quad) item, 8 rows as
   // float4 (dz items 0..127, input-tile items 0..127).  Round 1: the remaining NA-128 input-tile items are
@@ -241,16 +246,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_bf16s_kernel(const WgradBAr
     store_item();
     __syncthreads();
     if (item + 1 < it1) load_item(item + 1);     // next patch's global loads fly under this patch's MFMAs
+    PV4 ap[NS][XH];                 // input-tile pieces, one per (plane, column)
+#pragma unroll
+    for (int x = 0; x < XH; ++x)
+#pragma unroll
+      for (int p = 0; p < NS; ++p) ap[p][x] = *(const PV4*)(at + p * A_PLANE + x * (64 * 16) + pieceB);
 #pragma unroll
     for (int xp = 0; xp < 4; ++xp) {
       PV8 af[NS];
 #pragma unroll
-      for (int p = 0; p < NS; ++p) af[p] = *(const PV8*)(dzt + p * DZ_PLANE + (2 * xp) * (64 * 16) + laneA);
+      for (int p = 0; p < NS; ++p) {
+        const PV4 d0 = *(const PV4*)(dzt + p * DZ_PLANE + (2 * xp) * (64 * 16) + pieceA);
+        const PV4 d1 = *(const PV4*)(dzt + p * DZ_PLANE + (2 * xp + 1) * (64 * 16) + pieceA);
+        af[p] = __builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
 #pragma unroll
       for (int kw = 0; kw < KS; ++kw) {
         PV8 bf[NS];
 #pragma unroll
-        for (int p = 0; p < NS; ++p) bf[p] = *(const PV8*)(at + p * A_PLANE + (2 * xp + kw) * (64 * 16) + laneB);
+        for (int p = 0; p < NS; ++p)
+          bf[p] = __builtin_shufflevector(ap[p][2 * xp + kw], ap[p][2 * xp + kw + 1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
         for (int t = 0; t < NPROD; ++t)
           acc[kw] = WPlane<F16>::mfma(af[PA[6 - NPROD + t]], bf[PB[6 - NPROD + t]], acc[kw]);
