@@ -106,8 +106,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_bf16s_kernel(const WgradBAr
   // (2 columns x 8 rows), i.e. two pieces per lane.  The columns of consecutive taps kw overlap, so every piece is
   // read from LDS once per work item and the 16-B fragments are sliding windows over the piece registers (reading
   // whole 16-B fragments per (column pair, tap) moves 2.4x the LDS bytes).
-  const int pieceA = (wc * 32 + li) * 16 + 8 * h;
-  const int pieceB = (wi * 32 + li) * 16 + 8 * h;
+  // LDS slot of channel ch within a column: ch ^ ((ch >> 4) & 3).  The staging writes of one instruction go to
+  // channels 4q + j of block blk for (q, blk) = 16 lanes: unswizzled they fall on 4 of the 16 16-B bank groups
+  // (16-way conflict, ~2.5 k LDS cycles per work item against 1.9 k MFMA cycles); the XOR with the block index
+  // spreads them over all 16 and keeps 16 consecutive channels of a block on 16 different groups for the reads.
+  auto swz = [](int ch) { return ch ^ ((ch >> 4) & 3); };
+  const int pieceA = swz(wc * 32 + li) * 16 + 8 * h;
+  const int pieceB = swz(wi * 32 + li) * 16 + 8 * h;
 
   // ---- staging roles (fixed per thread).  Round 0: thread -> one (column, 4-channel quad) item, 8 rows as
   // float4 (dz items 0..127, input-tile items 0..127).  Round 1: the remaining NA-128 input-tile items are
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_bf16s_kernel(const WgradBAr
   };
   auto store_item = [&]() {
     if (r0_on) {
-      char* dst = (r0_dz ? dzt : at) + (r0_x * 64 + r0_blk * 16 + r0_q * 4) * 16;
+      char* dst = (r0_dz ? dzt : at) + (r0_x * 64) * 16;
       const int pstride = r0_dz ? DZ_PLANE : A_PLANE;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_bf16s_kernel(const WgradBAr
 #pragma unroll
           for (int y = 0; y < 8; ++y) bsum[j] += col[y];
         }
-        split_store8<NS, F16>(col, dst + j * 16, pstride, r0_dz ? s_d : s_a);
+        split_store8<NS, F16>(col, dst + swz(r0_blk * 16 + r0_q * 4 + j) * 16, pstride, r0_dz ? s_d : s_a);
       }
     }
     if (NA1 > 0 && r1_on) {
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_bf16s_kernel(const WgradBAr
         col[y] = v1[y];
         if (g.a_scale && ((ok1 >> y) & 1)) col[y] = fmaxf(fmaf(col[y], sc1, sh1), 0.f);
       }
-      split_store8<NS, F16>(col, at + (r1_x * 64 + r1_blk * 16 + r1_q * 4 + r1_j) * 16, A_PLANE, s_a);
+      split_store8<NS, F16>(col, at + (r1_x * 64 + swz(r1_blk * 16 + r1_q * 4 + r1_j)) * 16, A_PLANE, s_a);
     }
   };
 
