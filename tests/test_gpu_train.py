@@ -251,7 +251,7 @@ def test_train_multiframe_and_odd_batch_vs_oracle(T, Tn, nm, B, sf):
     Bar per tensor: max-norm error <= max(2e-5, 2.5 x the oracle's own fp32-vs-fp64 gap), OR -- the isolated
     ReLU-flip allowance -- relative L2 error <= 3e-3.  Why the allowance: a pre-activation within one fp32 ulp
     of zero makes the ReLU mask of two faithful fp32 implementations disagree on that single element (verified
-    with tools/_dbg.py: at B=3 exactly 1 of 1,228,800 elements of one dz tensor differs, where the BatchNorm
+    with tools/relu_flip_probe.py: at B=3 exactly 1 of 1,228,800 elements of one dz tensor differs, where the BatchNorm
     output is 1.06e-6 against a typical 0.77); its gradient then enters or leaves the sums, which moves
     individual weight-gradient entries by ~1e-3 of the max while leaving the tensor as a whole untouched.
     sf=25 is the tactileSRSeqs output size: 100x100 = 12.5 patches of 8 (ragged tiles in every train-mode epilogue,
