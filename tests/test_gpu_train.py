@@ -350,3 +350,33 @@ def test_bf16_train_mode_is_a_reduced_precision_of_the_same_step(T, golden, monk
         got, ref = _subs(named[k].grad).astype(np.float64), g[f"grad64/{k}"]
         cos = float(got @ ref / max(np.linalg.norm(got) * np.linalg.norm(ref), 1e-30))
         assert cos > 0.98, (k, cos)
+
+
+def test_multi_step_loss_trajectory_tracks_the_oracle(T):
+    """Ten Adam(L2) steps on a fixed batch: the loss curve of the HIP path follows the CPU oracle's step by step.
+    Two faithful fp32 implementations drift apart slowly (ReLU-mask flips, Adam's sign sensitivity near zero
+    gradients): measured 3e-7 after one step, 5e-5 after ten; bars 2e-5 for the first three steps, 1e-3 throughout.
+    (lr = 3e-5: at the reference default 1e-3 without its warm-up scheduler the final ReLU dies after one step on
+    synthetic targets -- on the oracle exactly as here, tools/train_trajectory.py.)"""
+    from tactilesr_amd import optim
+    from tactilesr_amd.train import tactileSR_train as TR
+    cfg = dict(patternFeatureExtraLayerCnt=2)
+    sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), 42)
+    g = torch.Generator().manual_seed(1)
+    B, steps, lr = 8, 10, 3e-5
+    LR = torch.rand(B, 3, 4, 4, generator=g) * 8
+    HR = F.interpolate(LR.mean(1, keepdim=True), size=(100, 100), mode="bilinear") * 30
+    p, state, ref = {k: v.clone() for k, v in sd.items()}, {}, []
+    for it in range(steps):
+        loss, _ = O.train_one_iter(p, state, it + 1, LR, HR, lr=lr, weight_decay=1e-2)
+        ref.append(loss)
+    m = T.TactileSR(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    opt = optim.Adam(m.parameters(), lr=lr, weight_decay=1e-2)
+    conf = TR.default_config()
+    got = [float(TR.train_one_iter(m, opt, (LR, HR), conf)["total_loss"]) for _ in range(steps)]
+    rel = [abs(a - b) / abs(a) for a, b in zip(ref, got)]
+    print("[trajectory]", ["%.1e" % r for r in rel])
+    assert ref[-1] < 0.8 * ref[0]                     # the curve is alive
+    assert max(rel[:3]) < 2e-5 and max(rel) < 1e-3, rel
