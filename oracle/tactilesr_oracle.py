@@ -165,29 +165,59 @@ def _bn(p: Params, prefix: str, x: torch.Tensor, training: bool,
                         False, BN_MOMENTUM, BN_EPS)
 
 
-def _conv_bn_relu(p, prefix_conv, prefix_bn, x, pad, training, new_stats):
+class ReluTap:
+    """Optional instrumentation of every ReLU of the network (tests only).
+
+    ``pre`` receives the pre-activation of each ReLU under its name; ``masks`` (name -> bool tensor)
+    REPLACES ``relu(x)`` by ``x * mask``: the forward value changes only where the given mask disagrees
+    with ``x > 0`` (|x| ~ one ulp of zero there), and the backward pass routes gradients through
+    exactly the given mask.  The GPU gradient tests use this to evaluate the fp64 gradient *on the
+    activation pattern the device actually took* (two faithful fp32 forwards disagree on the sign of
+    pre-activations that are zero to rounding; the gradient is discontinuous there).
+
+    Names: ``<bn prefix>`` for conv+BN+ReLU (e.g. ``patternFeatureExtra_layer.0.conv_3_1.1``),
+    ``<block prefix>.out`` for the MSRB / ResBlock output ReLU, ``<resblock prefix>.conv1`` for the
+    inner ResBlock ReLU, ``force_in``, ``head0`` and ``out``."""
+
+    def __init__(self, masks: Optional[Dict[str, torch.Tensor]] = None, record: bool = False):
+        self.masks = masks
+        self.pre: Optional[Dict[str, torch.Tensor]] = {} if record else None
+
+    def __call__(self, name: str, x: torch.Tensor) -> torch.Tensor:
+        if self.pre is not None:
+            self.pre[name] = x.detach()
+        if self.masks is not None:
+            return x * self.masks[name].to(x.dtype)
+        return F.relu(x)
+
+
+def _relu(tap: Optional[ReluTap], name: str, x: torch.Tensor) -> torch.Tensor:
+    return F.relu(x) if tap is None else tap(name, x)
+
+
+def _conv_bn_relu(p, prefix_conv, prefix_bn, x, pad, training, new_stats, tap=None):
     y = F.conv2d(x, p[prefix_conv + ".weight"], p.get(prefix_conv + ".bias"), padding=pad)
-    return F.relu(_bn(p, prefix_bn, y, training, new_stats))
+    return _relu(tap, prefix_bn, _bn(p, prefix_bn, y, training, new_stats))
 
 
 def msrb_forward(p: Params, prefix: str, x: torch.Tensor, training=False,
-                 new_stats: Optional[Params] = None) -> torch.Tensor:
+                 new_stats: Optional[Params] = None, tap: Optional[ReluTap] = None) -> torch.Tensor:
     """MSRB.forward, model/tactileSR_model.py:196-206."""
-    o31 = _conv_bn_relu(p, f"{prefix}.conv_3_1.0", f"{prefix}.conv_3_1.1", x, 1, training, new_stats)
-    o51 = _conv_bn_relu(p, f"{prefix}.conv_5_1.0", f"{prefix}.conv_5_1.1", x, 2, training, new_stats)
+    o31 = _conv_bn_relu(p, f"{prefix}.conv_3_1.0", f"{prefix}.conv_3_1.1", x, 1, training, new_stats, tap)
+    o51 = _conv_bn_relu(p, f"{prefix}.conv_5_1.0", f"{prefix}.conv_5_1.1", x, 2, training, new_stats, tap)
     in2 = torch.cat([o31, o51], 1)
-    o32 = _conv_bn_relu(p, f"{prefix}.conv_3_2.0", f"{prefix}.conv_3_2.1", in2, 1, training, new_stats)
-    o52 = _conv_bn_relu(p, f"{prefix}.conv_5_2.0", f"{prefix}.conv_5_2.1", in2, 2, training, new_stats)
+    o32 = _conv_bn_relu(p, f"{prefix}.conv_3_2.0", f"{prefix}.conv_3_2.1", in2, 1, training, new_stats, tap)
+    o52 = _conv_bn_relu(p, f"{prefix}.conv_5_2.0", f"{prefix}.conv_5_2.1", in2, 2, training, new_stats, tap)
     in3 = torch.cat([o32, o52], 1)
     out = F.conv2d(in3, p[f"{prefix}.confusion.weight"], p[f"{prefix}.confusion.bias"])
-    return F.relu(out + x)
+    return _relu(tap, f"{prefix}.out", out + x)
 
 
-def resblock_forward(p: Params, prefix: str, x: torch.Tensor) -> torch.Tensor:
+def resblock_forward(p: Params, prefix: str, x: torch.Tensor, tap: Optional[ReluTap] = None) -> torch.Tensor:
     """ResBlock.forward, model/tactileSR_model.py:222-225."""
-    y = F.relu(F.conv2d(x, p[f"{prefix}.conv1.weight"], p[f"{prefix}.conv1.bias"], padding=1))
+    y = _relu(tap, f"{prefix}.conv1", F.conv2d(x, p[f"{prefix}.conv1.weight"], p[f"{prefix}.conv1.bias"], padding=1))
     y = F.conv2d(y, p[f"{prefix}.conv2.weight"], p[f"{prefix}.conv2.bias"], padding=1)
-    return F.relu(x + y)
+    return _relu(tap, f"{prefix}.out", x + y)
 
 
 def _count(p: Params, stem: str) -> int:
@@ -199,9 +229,11 @@ def _count(p: Params, stem: str) -> int:
 
 def tactilesr_forward(p: Params, x: torch.Tensor, scale_factor=10, axisCnt=3,
                       training=False, new_stats: Optional[Params] = None,
-                      stages: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+                      stages: Optional[Dict[str, torch.Tensor]] = None,
+                      tap: Optional[ReluTap] = None) -> torch.Tensor:
     """TactileSR.forward, model/tactileSR_model.py:67-84.  ``stages`` (optional)
-    receives named intermediate activations for per-stage parity probes."""
+    receives named intermediate activations for per-stage parity probes; ``tap``
+    (optional, tests only) records / overrides the ReLU activation pattern."""
     seqsCnt = _count(p, "inputLayer_pattern_list")
     n_msrb = _count(p, "patternFeatureExtra_layer")
     n_res = _count(p, "forceFeatureExtra_layer")
@@ -217,25 +249,25 @@ def tactilesr_forward(p: Params, x: torch.Tensor, scale_factor=10, axisCnt=3,
     for t in range(seqsCnt):
         pre = f"inputLayer_pattern_list.{t}"
         u = bilinear_resize(x[:, axisCnt * t:axisCnt * (t + 1)], size)
-        h = _conv_bn_relu(p, f"{pre}.1", f"{pre}.2", u, 1, training, new_stats)
-        h = _conv_bn_relu(p, f"{pre}.4", f"{pre}.5", h, 1, training, new_stats)
+        h = _conv_bn_relu(p, f"{pre}.1", f"{pre}.2", u, 1, training, new_stats, tap)
+        h = _conv_bn_relu(p, f"{pre}.4", f"{pre}.5", h, 1, training, new_stats, tap)
         feats.append(rec(f"stem{t}", h))
     h = torch.cat(feats, 1) if seqsCnt > 1 else feats[0]
     h = rec("fuse", _conv_bn_relu(p, "inputContact_layer.0", "inputContact_layer.1", h, 1,
-                                  training, new_stats))
+                                  training, new_stats, tap))
     for i in range(n_msrb):
-        h = rec(f"msrb{i}", msrb_forward(p, f"patternFeatureExtra_layer.{i}", h, training, new_stats))
+        h = rec(f"msrb{i}", msrb_forward(p, f"patternFeatureExtra_layer.{i}", h, training, new_stats, tap))
     pattern = h
 
     u = bilinear_resize(x[:, :axisCnt], size)
-    f = rec("force_in", F.relu(F.conv2d(u, p["input_layer_force.1.weight"], padding=1)))
+    f = rec("force_in", _relu(tap, "force_in", F.conv2d(u, p["input_layer_force.1.weight"], padding=1)))
     for i in range(n_res):
-        f = resblock_forward(p, f"forceFeatureExtra_layer.{i}", f)
+        f = resblock_forward(p, f"forceFeatureExtra_layer.{i}", f, tap)
     rec("force", f)
 
     out = torch.cat((f, pattern), 1)           # force first (model/tactileSR_model.py:81)
-    out = rec("head0", F.relu(F.conv2d(out, p["output_layer.0.weight"], padding=1)))
-    out = F.relu(F.conv2d(out, p["output_layer.2.weight"], padding=1))
+    out = rec("head0", _relu(tap, "head0", F.conv2d(out, p["output_layer.0.weight"], padding=1)))
+    out = _relu(tap, "out", F.conv2d(out, p["output_layer.2.weight"], padding=1))
     # final F.interpolate to the same size is an exact identity (model/tactileSR_model.py:83)
     out = F.interpolate(out, size=(4 * scale_factor, 4 * scale_factor), mode="bilinear",
                         align_corners=False)

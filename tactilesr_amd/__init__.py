@@ -9,4 +9,3 @@ from .model.tactileSR_model import TactileSR, MSRB, ResBlock  # noqa: F401
 from .model.tPSFNet import tPSFNet  # noqa: F401
 
 __all__ = ["TactileSR", "MSRB", "ResBlock", "tPSFNet"]
-from .graph import GraphedTactileSR  # noqa: F401,E402

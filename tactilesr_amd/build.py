@@ -37,7 +37,9 @@ def _newer(path, deps):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
+    inc = os.path.join(os.path.dirname(HERE), "include")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]   # tsr_conv_desc lives there
     jobs = []
     objs = []
     for src in _sources():

@@ -320,7 +320,56 @@ class TrainEngine:
         call("tsr_head_fwd", ptr(c.h0), _I(128), _I(128), ptr(m.output_layer[2].weight.detach()), ptr(out), _I(1),
              _I(B), _I(H), _I(W), stream())
         c.out = out
+        if self.debug is not None:
+            self.debug["ctx"] = c
         return out, c
+
+    @torch.no_grad()
+    def activation_masks(self, c: _Ctx, img0: int = 0, nimg: int = None):
+        """The ReLU activation pattern this forward took for images [img0, img0+nimg) (default: all), as
+        {name: bool (nimg,C,H,W) tensor} keyed like the CPU
+        oracle's ``ReluTap`` (test plumbing: the parity tests evaluate the fp64 gradient on exactly this pattern).
+        BN layers store the raw conv output z plus per-channel (scale, shift); every kernel evaluates
+        ``fmaf(z, scale, shift) > 0``, whose sign equals that of the exactly evaluated z*scale+shift in fp64."""
+        from .tactileSR_model import from_cb16
+        m = self.m
+        H, W = c.H, c.W
+        B = c.B - img0 if nimg is None else nimg
+        assert 0 <= img0 and B > 0 and img0 + B <= c.B
+
+        def sub(buf, ctot):          # CB16 is image-major: a batch slice is a contiguous range
+            return buf[img0 * ctot * H * W:(img0 + B) * ctot * H * W]
+
+        def bn_mask(buf, ctot, coff, C, scale, shift):
+            z = from_cb16(sub(buf, ctot), B, C, H, W, ctot, coff).double()
+            return (z * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)) > 0
+
+        def pos(a: Act):
+            return from_cb16(sub(a.buf, a.ctot), B, a.c, H, W, a.ctot, a.coff) > 0
+
+        out = {}
+        T = m.seqsCnt
+        for t in range(T):
+            v1 = c.bn1[t]
+            out[f"inputLayer_pattern_list.{t}.2"] = bn_mask(c.z1[t], 64, 0, 64, v1[0], v1[1])
+            o = 64 * t
+            out[f"inputLayer_pattern_list.{t}.5"] = bn_mask(c.catT, 64 * T, o, 64, c.bn2[0, o:o + 64], c.bn2[1, o:o + 64])
+        out["inputContact_layer.1"] = bn_mask(c.zf, 64, 0, 64, c.bnf[0], c.bnf[1])
+        for i, s in enumerate(c.blocks):
+            pre = f"patternFeatureExtra_layer.{i}"
+            out[pre + ".conv_3_1.1"] = bn_mask(s.cat1, 128, 0, 64, s.bn_c1[0, :64], s.bn_c1[1, :64])
+            out[pre + ".conv_5_1.1"] = bn_mask(s.cat1, 128, 64, 64, s.bn_c1[0, 64:], s.bn_c1[1, 64:])
+            out[pre + ".conv_3_2.1"] = bn_mask(s.cat2, 256, 0, 128, s.bn_c2[0, :128], s.bn_c2[1, :128])
+            out[pre + ".conv_5_2.1"] = bn_mask(s.cat2, 256, 128, 128, s.bn_c2[0, 128:], s.bn_c2[1, 128:])
+            out[pre + ".out"] = pos(s.Y)
+        out["force_in"] = pos(Act(c.f0, 64, 0, 64))
+        for i, s in enumerate(c.res):
+            pre = f"forceFeatureExtra_layer.{i}"
+            out[pre + ".conv1"] = pos(s.F1)
+            out[pre + ".out"] = pos(s.Y)
+        out["head0"] = pos(Act(c.h0, 128, 0, 128))
+        out["out"] = c.out[img0:img0 + B] > 0
+        return out
 
     # ------------------------------------------------------------------ backward pieces
     def _nsplit(self, B, tiles, ks, cout, cin):

@@ -161,6 +161,8 @@ class TactileSR(nn.Module):
         import os
         self.conv_impl = os.environ.get("TSR_CONV_IMPL", "fp16x3")
         assert self.conv_impl in CONV_IMPLS, self.conv_impl
+        # arithmetic of output_layer.0 (the 128->128 conv in front of the cancellation-heavy 128->1 head); None = conv_impl
+        self.head_impl = os.environ.get("TSR_HEAD_IMPL") or None
         self.max_images_per_pass = 4096   # workspace bound: ~6.6 MB of CB16 activations per image
 
     def make_layer(self, block, num_of_layer):
@@ -171,7 +173,7 @@ class TactileSR(nn.Module):
 
     # ------------------------------------------------------------------ engine
     def _param_key(self):
-        return (self.conv_impl,) + tuple((t.data_ptr(), t._version)
+        return (self.conv_impl, self.head_impl) + tuple((t.data_ptr(), t._version)
                                          for t in list(self.parameters()) + list(self.buffers()))
 
     def _build_plan(self):
@@ -192,7 +194,7 @@ class TactileSR(nn.Module):
         plan["msrb"] = msrbs
         plan["force_w"] = self.input_layer_force[1].weight.detach().float().contiguous()
         plan["res"] = [(_PackedConv(b.conv1, None, ns), _PackedConv(b.conv2, None, ns)) for b in self.forceFeatureExtra_layer]
-        plan["head0"] = _PackedConv(self.output_layer[0], None, ns)
+        plan["head0"] = _PackedConv(self.output_layer[0], None, CONV_IMPLS[self.head_impl] if self.head_impl else ns)
         plan["head_w"] = self.output_layer[2].weight.detach().float().contiguous()
         return plan
 

@@ -6,8 +6,19 @@ import torch
 import torch.nn.functional as F
 
 from oracle import tactilesr_oracle as O
+import _gradcheck as GC
 
 pytestmark = pytest.mark.gpu
+
+
+def _debug_engine(m):
+    """Create the module's train engine with its debug dict armed (forward then keeps its context alive so the
+    test can read the activation pattern back)."""
+    from tactilesr_amd.model._train import TrainEngine
+    if m._train_engine is None:
+        m._train_engine = TrainEngine(m)
+    m._train_engine.debug = {}
+    return m._train_engine
 
 
 def relerr(a, b):
@@ -134,6 +145,7 @@ def test_train_forward_backward_vs_reference_golden(T, golden, impl, monkeypatch
     m = T.TactileSR(**cfg)
     m.load_state_dict(sd, strict=True)
     m = m.cuda().train()
+    _debug_engine(m)
     LR, HR = torch.from_numpy(g["LR"]).cuda(), torch.from_numpy(g["HR_prepared"]).cuda()
     out = m(LR[:, :3])
     assert relerr(out, torch.from_numpy(g["out0"])) < 1e-5
@@ -141,11 +153,20 @@ def test_train_forward_backward_vs_reference_golden(T, golden, impl, monkeypatch
     assert abs(loss.item() - g["losses"][0]) <= 1e-5 * abs(g["losses"][0])
     loss.backward()
     named = dict(m.named_parameters())
-    bad = []
-    # Gradients: ReLU-mask flips make this net's fp32 gradients differ from exact arithmetic by
-    # 1e-4..1e-3 of their max (the fixture stores the reference run in fp64 as the yardstick), so two
-    # faithful fp32 implementations cannot agree to 1e-5.  Bar: HIP is as close to fp64 as the
-    # reference's own fp32 CPU run is (x2.5 slack, floor 2e-5), per tensor, max-norm on a 512-probe.
+    # Gradients, hard bar: max-norm 2e-5 on EVERY parameter against the fp64 oracle gradient evaluated on the ReLU
+    # pattern the device took; the pattern itself must equal the fp64 pattern except at pre-activations that are
+    # zero to rounding (tests/_gradcheck.py explains why the two halves are separated).
+    masks = {k: v.cpu() for k, v in m._train_engine.activation_masks(m._train_engine.debug["ctx"]).items()}
+    LRc, HRc = torch.from_numpy(g["LR"])[:, :3], torch.from_numpy(g["HR_prepared"])
+    l64, _, _, pre64 = GC.oracle_grads(sd, LRc, HRc, record=True)
+    assert abs(l64 - float(g["loss64"])) <= 1e-9 * abs(l64)          # the oracle's fp64 run IS the reference's
+    flips = GC.check_pattern(masks, pre64)
+    _, g64m, _, _ = GC.oracle_grads(sd, LRc, HRc, masks=masks)
+    worst = GC.check_grads({k: p.grad for k, p in named.items()}, g64m, tol=2e-5)
+    print(f"[grad {impl}] {flips} ReLU flips vs fp64; worst on-pattern max-norm error {worst[0]:.2e} ({worst[1]})")
+    # Gradients, bridge to the reference's own numbers: the fixture holds the reference's fp32 and fp64 gradients
+    # (each on its own ReLU pattern).  The HIP gradient must sit as close to the reference's fp64 run as the
+    # reference's fp32 run does (x4: the flip sets are independent draws), in max-norm AND in relative L2.
     for k in [str(k) for k in g["keys"]]:
         gk = named[k].grad
         assert gk is not None, k
@@ -156,11 +177,10 @@ def test_train_forward_backward_vs_reference_golden(T, golden, impl, monkeypatch
             assert np.abs(got).max() < 1e-4, k
             continue
         e_hip, e_ref = np.abs(got - ref64).max() / den, np.abs(ref32 - ref64).max() / den
-        l2 = float(np.linalg.norm(got - ref64) / max(np.linalg.norm(ref64), 1e-30))
-        print(f"[grad] {k}: hip-vs-f64 {e_hip:.2e}  ref32-vs-f64 {e_ref:.2e}  rel-L2 {l2:.2e}")
-        if e_hip > max(2e-5, 2.5 * e_ref) and l2 > 3e-3:     # second clause: isolated ReLU-flip allowance (see below)
-            bad.append((k, e_hip, e_ref, l2))
-    assert not bad, bad
+        n64 = max(np.linalg.norm(ref64), 1e-30)
+        l2_hip, l2_ref = float(np.linalg.norm(got - ref64) / n64), float(np.linalg.norm(ref32 - ref64) / n64)
+        print(f"[grad] {k}: hip-vs-f64 {e_hip:.2e} (L2 {l2_hip:.2e})  ref32-vs-f64 {e_ref:.2e} (L2 {l2_ref:.2e})")
+        assert e_hip <= max(2e-5, 4 * e_ref) and l2_hip <= max(2e-5, 4 * l2_ref), (k, e_hip, e_ref, l2_hip, l2_ref)
     new_sd = m.state_dict()
     for s in [str(s) for s in g["stat_keys"]]:
         assert relerr(new_sd[s + ".running_mean"], torch.from_numpy(g[f"stat/{s}.running_mean"])) < 1e-5, s
@@ -191,10 +211,16 @@ def test_full_step_adam_vs_reference_golden(T, golden, impl, monkeypatch):
     new_sd = m.state_dict()
     for k in [str(k) for k in g["keys"]]:
         w = new_sd[k]
-        # Adam's first step moves every weight by ~lr*sign(g): a sign flip of a ~0 gradient moves a weight by 2*lr
+        # Adam's first step moves every weight by lr*g'/(|g'|+eps), g' = g + wd*w: the step is +-lr whatever |g'| is,
+        # so a weight can differ from the reference's only where the SIGN of g' differs, i.e. where |g'| is below
+        # the gradient's ReLU-flip noise floor (~1e-3 of its max, see test_train_forward_backward...).  Every probe
+        # that differs must be such a near-zero-gradient probe, must differ by at most 2*lr, and they must be few.
         diff = np.abs(_subs(w) - g[f"w1/{k}"])
-        frac_off = float((diff > 1e-6 + 1e-5 * np.abs(g[f"w1/{k}"])).mean())
-        assert diff.max() <= 2.1e-3 and frac_off < 0.02, (k, diff.max(), frac_off)
+        off = diff > 1e-6 + 1e-5 * np.abs(g[f"w1/{k}"])
+        gp = g[f"grad/{k}"].astype(np.float64) + 1e-2 * _subs(sd[k]).astype(np.float64)
+        assert diff.max() <= 2.1e-3 and off.mean() < 0.02, (k, diff.max(), off.mean())
+        if off.any():
+            assert np.abs(gp[off]).max() < 3e-3 * np.abs(gp).max(), (k, np.abs(gp[off]).max(), np.abs(gp).max())
     l1 = TR.train_one_iter(m, opt, batch, conf)["total_loss"].item()
     assert abs(l1 - g["losses"][1]) <= 2e-4 * abs(g["losses"][1])
     assert int(opt.state[next(iter(m.parameters()))]["step"]) == 2
@@ -246,84 +272,117 @@ def test_eval_func_after_training_uses_updated_running_stats(T):
 @pytest.mark.parametrize("Tn,nm,B,sf", [(2, 1, 3, 10), (2, 1, 4, 10), (1, 2, 3, 10), (1, 1, 2, 25), (2, 1, 1, 25)])
 def test_train_multiframe_and_odd_batch_vs_oracle(T, Tn, nm, B, sf):
     """seqsCnt=2 (two stems -> channel-stacked fuse conv) and odd batches (image-pair tail): loss, running stats
-    and every gradient against the CPU oracle run in fp64.
-
-    Bar per tensor: max-norm error <= max(2e-5, 2.5 x the oracle's own fp32-vs-fp64 gap), OR -- the isolated
-    ReLU-flip allowance -- relative L2 error <= 3e-3.  Why the allowance: a pre-activation within one fp32 ulp
-    of zero makes the ReLU mask of two faithful fp32 implementations disagree on that single element (verified
-    with tools/relu_flip_probe.py: at B=3 exactly 1 of 1,228,800 elements of one dz tensor differs, where the BatchNorm
-    output is 1.06e-6 against a typical 0.77); its gradient then enters or leaves the sums, which moves
-    individual weight-gradient entries by ~1e-3 of the max while leaving the tensor as a whole untouched.
+    and EVERY parameter gradient against the CPU oracle in fp64, max-norm 2e-5 on the device's own ReLU pattern
+    (tests/_gradcheck.py); the pattern may differ from fp64's only at pre-activations that are zero to rounding.
     sf=25 is the tactileSRSeqs output size: 100x100 = 12.5 patches of 8 (ragged tiles in every train-mode epilogue,
     dgrad and wgrad)."""
-    cfg = dict(seqsCnt=Tn, patternFeatureExtraLayerCnt=nm, scale_factor=sf)
-    sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), 977)
-    g = torch.Generator().manual_seed(978)
+    _train_step_vs_oracle(T, dict(seqsCnt=Tn, patternFeatureExtraLayerCnt=nm, scale_factor=sf), B, 977)
+
+
+def _train_step_vs_oracle(T, cfg, B, seed, tol=2e-5, loss_tol=1e-5):
+    sf, Tn = cfg.get("scale_factor", 10), cfg.get("seqsCnt", 1)
+    sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), seed)
+    g = torch.Generator().manual_seed(seed + 1)
     LR = torch.rand(B, 3 * Tn, 4, 4, generator=g) * 8
     HR = torch.rand(B, 1, 4 * sf, 4 * sf, generator=g) * 25
-
-    def oracle(dt):
-        leaves = {k: v.to(dt).requires_grad_(True) for k, v in sd.items() if O.is_trainable(k)}
-        full = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}
-        full.update(leaves)
-        ns = {}
-        out = O.tactilesr_forward(full, LR.to(dt), scale_factor=sf, training=True, new_stats=ns)
-        loss = F.mse_loss(out, HR.to(dt))
-        gl = torch.autograd.grad(loss, list(leaves.values()))
-        return loss.item(), dict(zip(leaves, gl)), ns
-
-    l32, g32, ns32 = oracle(torch.float32)
-    l64, g64, _ = oracle(torch.float64)
+    l64, _, ns64, pre64 = GC.oracle_grads(sd, LR, HR, scale_factor=sf, record=True)
     m = T.TactileSR(**cfg)
     m.load_state_dict(sd, strict=True)
     m = m.cuda().train()
+    eng = _debug_engine(m)
     out = m(LR.cuda())
     loss = F.mse_loss(out, HR.cuda())
-    assert abs(loss.item() - l64) < 1e-5 * abs(l64)
+    assert abs(loss.item() - l64) < loss_tol * abs(l64)
     loss.backward()
     new_sd = m.state_dict()
-    for k, v in ns32.items():
+    for k, v in ns64.items():
         if k.endswith("running_mean") or k.endswith("running_var"):
             assert relerr(new_sd[k], v) < 1e-5, k
-    bad = []
+    masks = {k: v.cpu() for k, v in eng.activation_masks(eng.debug["ctx"]).items()}
+    flips = GC.check_pattern(masks, pre64)
+    _, g64m, _, _ = GC.oracle_grads(sd, LR, HR, scale_factor=sf, masks=masks)
+    worst = GC.check_grads({k: p.grad for k, p in m.named_parameters()}, g64m, tol=tol)
+    print(f"[train-vs-oracle {cfg} B={B}] {flips} ReLU flips; worst on-pattern grad error {worst[0]:.2e} ({worst[1]})")
+    return m
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_train_step_seqs_T8_sf25_vs_oracle(T, B):
+    """BASELINE configs[4] shape as a TRAIN step: TactileSR(scale_factor=25, seqsCnt=8), 4x4x24 -> 100x100, default
+    fp16x3 arithmetic against the fp64 oracle (2 MSRBs keep the CPU side in seconds; every kernel shape of the full
+    net is exercised: 8 stems, the 512->64 fuse conv, ragged 12.5-patch tiles)."""
+    _train_step_vs_oracle(T, dict(seqsCnt=8, scale_factor=25, patternFeatureExtraLayerCnt=2), B, 1977)
+
+
+def test_train_step_seqs_T8_sf25_bf16_reduced_precision(T, monkeypatch):
+    """configs[4] as BASELINE words it ("bf16"): plain bf16 conv operands, fp32 accumulate/parameters.  Not the
+    parity path; bar 2e-2 on the loss and cosine > 0.98 per gradient tensor against fp64."""
+    monkeypatch.setenv("TSR_TRAIN_IMPL", "bf16")
+    cfg = dict(seqsCnt=8, scale_factor=25, patternFeatureExtraLayerCnt=2)
+    sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), 1977)
+    g = torch.Generator().manual_seed(1978)
+    LR = torch.rand(2, 24, 4, 4, generator=g) * 8
+    HR = torch.rand(2, 1, 100, 100, generator=g) * 25
+    l64, g64, _, _ = GC.oracle_grads(sd, LR, HR, scale_factor=25)
+    m = T.TactileSR(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    loss = F.mse_loss(m(LR.cuda()), HR.cuda())
+    assert abs(loss.item() - l64) < 2e-2 * abs(l64)
+    loss.backward()
     for k, p in m.named_parameters():
         ref = g64[k]
-        den = float(ref.abs().max())
-        if den < 1e-6:        # bias in front of a train-mode BN: exact gradient is 0
-            assert float(p.grad.abs().max()) < 1e-4, k
+        if float(ref.abs().max()) < 1e-6:
             continue
-        e_hip = float((p.grad.detach().cpu().double() - ref).abs().max()) / den
-        e_ref = float((g32[k].double() - ref).abs().max()) / den
-        l2 = float((p.grad.detach().cpu().double() - ref).norm() / ref.norm())
-        if e_hip > max(2e-5, 2.5 * e_ref) and l2 > 3e-3:
-            bad.append((k, e_hip, e_ref, l2))
-    assert not bad, bad
+        got = p.grad.detach().cpu().double().flatten()
+        cos = float(got @ ref.flatten() / (got.norm() * ref.norm()).clamp_min(1e-30))
+        assert cos > 0.98, (k, cos)
+
+
+def _tiled_train_step(T, reps, cfg, seed):
+    """Size-independent property at a large batch (B = 32 base frames tiled `reps` times): batch statistics, the MSE
+    loss and hence every gradient of a tiled batch equal those of the 32 base frames, which the CPU oracle can run.
+    The activation pattern of the first 32 frames must equal fp64's up to rounding-zero flips, all replicas must
+    carry the SAME pattern, and every gradient meets the max-norm bar on that pattern."""
+    torch.manual_seed(seed)
+    m = T.TactileSR(**cfg)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(seed + 1)
+    LRb, HRb = torch.rand(32, 3, 4, 4, generator=g) * 8, torch.rand(32, 1, 40, 40, generator=g) * 25
+    m = m.cuda().train()
+    eng = _debug_engine(m)
+    out = m(LRb.repeat(reps, 1, 1, 1).cuda())
+    loss = F.mse_loss(out, HRb.repeat(reps, 1, 1, 1).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    l64, _, _, pre64 = GC.oracle_grads(sd, LRb, HRb, record=True)
+    assert abs(loss.item() - l64) < 1e-5 * l64
+    o = out.view(reps, 32, -1)
+    assert torch.equal(o, o[:1].expand_as(o))                 # replicas are bit-identical in train mode too
+    ctx = eng.debug["ctx"]
+    masks = {k: v.cpu() for k, v in eng.activation_masks(ctx, 0, 32).items()}
+    for k, v in eng.activation_masks(ctx, 32 * (reps - 1), 32).items():      # last replica: same pattern
+        assert torch.equal(v.cpu(), masks[k]), k
+    del ctx
+    eng.debug.clear()
+    flips = GC.check_pattern(masks, pre64)
+    _, g64m, _, _ = GC.oracle_grads(sd, LRb, HRb, masks=masks)
+    worst = GC.check_grads({k: p.grad for k, p in m.named_parameters()}, g64m, tol=2e-5)
+    print(f"[tiled x{reps}] {flips} ReLU flips; worst on-pattern grad error {worst[0]:.2e} ({worst[1]})")
+    return m
 
 
 def test_large_batch_train_step_tiling_invariance(T):
-    """Size-independent property at a large batch (B=1024 = 32 frames tiled 32x): batch statistics, the MSE loss
-    and hence every gradient of a tiled batch equal those of the 32 base frames, which the CPU oracle can run."""
-    torch.manual_seed(5)
-    m = T.TactileSR(patternFeatureExtraLayerCnt=2)
-    sd = {k: v.clone() for k, v in m.state_dict().items()}
-    g = torch.Generator().manual_seed(6)
-    LRb, HRb = torch.rand(32, 3, 4, 4, generator=g) * 8, torch.rand(32, 1, 40, 40, generator=g) * 25
-    m = m.cuda().train()
-    out = m(LRb.repeat(32, 1, 1, 1).cuda())
-    loss = F.mse_loss(out, HRb.repeat(32, 1, 1, 1).cuda())
-    loss.backward()
-    big = {k: p.grad.detach().cpu().double() for k, p in m.named_parameters()}
-    leaves = {k: v.double().requires_grad_(True) for k, v in sd.items() if O.is_trainable(k)}
-    full = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
-    full.update(leaves)
-    lo = F.mse_loss(O.tactilesr_forward(full, LRb.double(), training=True, new_stats={}), HRb.double())
-    gl = torch.autograd.grad(lo, list(leaves.values()))
-    assert abs(loss.item() - lo.item()) < 1e-5 * lo.item()
-    for k, ref in zip(leaves, gl):
-        if float(ref.abs().max()) < 1e-7:
-            continue
-        l2 = float((big[k] - ref).norm() / ref.norm())
-        assert l2 < 3e-3, (k, l2)          # rel-L2: robust to isolated ReLU-mask flips (see the odd-batch test)
+    _tiled_train_step(T, 32, dict(patternFeatureExtraLayerCnt=2), 5)
+
+
+def test_train_step_B8192_tiling_invariance(T):
+    """BASELINE configs[2]/[3] per-GPU batch: one full TactileSR (6 MSRB) train step at B = 8192 (168 GB of saved
+    activations in HBM) = 32 frames x 256."""
+    torch.cuda.empty_cache()
+    m = _tiled_train_step(T, 256, dict(), 42)
+    del m
+    torch.cuda.empty_cache()
 
 
 def test_bf16_train_mode_is_a_reduced_precision_of_the_same_step(T, golden, monkeypatch):
@@ -380,3 +439,60 @@ def test_multi_step_loss_trajectory_tracks_the_oracle(T):
     print("[trajectory]", ["%.1e" % r for r in rel])
     assert ref[-1] < 0.8 * ref[0]                     # the curve is alive
     assert max(rel[:3]) < 2e-5 and max(rel) < 1e-3, rel
+
+
+def test_seqs_transplant_forward_backward_frozen_blocks(T):
+    """a12 on hardware (reference train/tactileSRSeqs_train.py:43-59,74-77): T=7 model, optimizer built BEFORE
+    ``model_param_init`` swaps in the single-frame model's feature extractors.  After the swap the engine must run
+    the transplanted modules (weight packs follow the new module objects), every live parameter gets an on-pattern
+    fp64-grade gradient, the optimizer (which still holds the discarded modules' parameters) leaves the transplanted
+    blocks frozen while their BatchNorm running statistics move, and the stems / fuse / head do train."""
+    from tactilesr_amd import optim
+    from tactilesr_amd.train import checkpoint as CK
+    cfg7 = dict(seqsCnt=7, patternFeatureExtraLayerCnt=2)
+    cfg1 = dict(seqsCnt=1, patternFeatureExtraLayerCnt=2)
+    sd7 = O.random_state_dict(O.tactilesr_state_shapes(**cfg7), 701)
+    sd1 = O.random_state_dict(O.tactilesr_state_shapes(**cfg1), 702)
+    m = T.TactileSR(**cfg7)
+    m.load_state_dict(sd7, strict=True)
+    m = m.cuda().train()
+    g = torch.Generator().manual_seed(703)
+    LR, HR = torch.rand(3, 21, 4, 4, generator=g) * 8, torch.rand(3, 1, 40, 40, generator=g) * 25
+    F.mse_loss(m(LR.cuda()), HR.cuda()).backward()             # engine + weight packs exist for the OLD modules
+    opt = optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-2)
+    old_block_params = [p for p in m.patternFeatureExtra_layer.parameters()]
+    CK.model_param_init(m, sd1, lambda: T.TactileSR(**cfg1))
+    assert all(p is not q for p, q in zip(m.patternFeatureExtra_layer.parameters(), old_block_params))
+    # the state dict the oracle sees = seqs stems/fuse/head + transplanted single-frame blocks
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    for k in sd:
+        if k.startswith("patternFeatureExtra_layer") or k.startswith("forceFeatureExtra_layer"):
+            assert torch.equal(sd[k], sd1[k]), k
+    eng = _debug_engine(m)
+    opt.zero_grad()
+    out = m(LR.cuda())
+    loss = F.mse_loss(out, HR.cuda())
+    l64, _, ns64, pre64 = GC.oracle_grads(sd, LR, HR, record=True)
+    assert abs(loss.item() - l64) < 1e-5 * abs(l64)
+    loss.backward()
+    masks = {k: v.cpu() for k, v in eng.activation_masks(eng.debug["ctx"]).items()}
+    GC.check_pattern(masks, pre64)
+    _, g64m, _, _ = GC.oracle_grads(sd, LR, HR, masks=masks)
+    GC.check_grads({k: p.grad for k, p in m.named_parameters()}, g64m, tol=2e-5)
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    opt.step()
+    after = m.state_dict()
+    for k in before:
+        moved = not torch.equal(before[k], after[k])
+        in_blocks = k.startswith("patternFeatureExtra_layer") or k.startswith("forceFeatureExtra_layer")
+        if in_blocks:
+            assert not moved, f"{k}: transplanted block must stay frozen (optimizer holds the discarded modules)"
+        elif O.is_trainable(k):
+            assert moved, f"{k}: live parameter did not train"
+    for k, v in ns64.items():                                   # BN statistics of frozen blocks still move
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert relerr(after[k], v) < 1e-5, k
+    m.eval()
+    with torch.no_grad():
+        ref = O.tactilesr_forward({k: v.cpu() for k, v in after.items()}, LR)
+    assert relerr(m(LR.cuda()), ref) < 1e-5                     # eval plan re-packed from the transplanted modules

@@ -50,8 +50,52 @@ def test_lr_warmup_matches_reference_sequence(golden, name):
     if name == "auto_shipped":   # 'auto' ignores warmup_init_lr: starts at base_lr*factor, ends on StepLR's epoch-4 rate
         assert got[0] == 1e-3 * 1e-4 and abs(got[2003] - 1e-3 * 0.8 ** 2) < 1e-12
     st = w.state_dict()
-    assert "torch_scheduler" in st and st["last_epoch"] == 6
-    assert st["last_iter"] == (0 if CASES[name]["warmup_by_epoch"] else 3000)   # epoch warm-up ignores iter_update
+    assert set(st) == {"n_iter", "n_epoch", "warm_ticks", "torch_scheduler"} and st["n_epoch"] == 6
+    assert st["n_iter"] == (0 if CASES[name]["warmup_by_epoch"] else 3000)   # epoch warm-up ignores iter_update
+
+
+@pytest.mark.filterwarnings("ignore:Detected call of")
+@pytest.mark.parametrize("name", ["auto_shipped", "by_epoch"])
+@pytest.mark.parametrize("layout", ["own", "reference"])
+def test_lr_warmup_resume_mid_schedule_continues_the_reference_sequence(golden, name, layout):
+    """Stop after 1.4 epochs (inside the warm-up), save optimizer + scheduler state, rebuild both from scratch, load,
+    continue: the concatenated sequence is still the reference's.  `reference`: the state is handed over in the key
+    layout the reference's class writes (last_iter / last_epoch / torch_scheduler), as a reference-written checkpoint
+    would hold it."""
+    ref = golden("lr_schedule")[name]
+    cfg = dict(CASES[name])
+
+    def build():
+        c = dict(cfg)
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=c.pop('lr'))
+        sch = torch.optim.lr_scheduler.StepLR(opt, step_size=c.pop('step'), gamma=0.8)
+        return opt, LRWarmupScheduler(sch, epoch_len=500, **c)
+
+    def run(opt, w, first_tick, stop_tick, lrs):
+        tick = 0
+        for _ in range(6):
+            for _ in range(500):
+                tick += 1
+                if first_tick <= tick < stop_tick:
+                    opt.step()
+                    w.iter_update()
+                    lrs.append(opt.param_groups[0]['lr'])
+            tick += 1
+            if first_tick <= tick < stop_tick:
+                w.epoch_update()
+                lrs.append(opt.param_groups[0]['lr'])
+
+    opt, w = build()
+    lrs = [opt.param_groups[0]['lr']]
+    run(opt, w, 1, 701, lrs)                       # 500 iters + epoch end + 199 iters
+    so = opt.state_dict()
+    ss = w.state_dict() if layout == "own" else w.reference_state_dict()
+    opt2, w2 = build()
+    opt2.load_state_dict(so)
+    w2.load_state_dict(ss)
+    run(opt2, w2, 701, 10 ** 9, lrs)
+    assert np.array_equal(np.array(lrs), ref)
 
 
 def test_checkpoint_layout_roundtrip(tmp_path):
