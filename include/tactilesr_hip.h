@@ -218,6 +218,15 @@ int tsr_mse_fwd_bwd(const float* y, const float* target, float* dy, float* loss,
 /* torch.optim.Adam step with L2-in-gradient weight decay (train/tactileSR_train.py:212); step is 1-based. */
 int tsr_adam_l2_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
                      float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+/* The same step for MANY tensors in one launch (the reference's optim.Adam over all 124 parameter tensors,
+ * train/tactileSR_train.py:212; cpu/trainer.py:361): `chunks` is a DEVICE array of n_chunks records, one per
+ * <= 4096-element piece of a tensor, pointers already offset to the piece.  Same arithmetic as tsr_adam_l2_step. */
+typedef struct tsr_adam_chunk {
+  float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+  int n; int reserved;
+} tsr_adam_chunk;
+int tsr_adam_l2_multi(const tsr_adam_chunk* chunks, int n_chunks, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int step, void* stream);
 
 /* Per-sample PSNR / SSIM of eval_func (train/tactileSR_train.py:87-94, utility/tools.py:49-81) for B samples
  * of n elements: PSNR = 10log10(max^2/(sum(a-b)^2/psnr_div)) with psnr_div = shape[0]*shape[1] of what the

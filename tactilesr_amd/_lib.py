@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TSR_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libtactilesr_hip.so")   # override: kernel A/B experiments
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _P, _I, _F, _L = c_void_p, c_int, c_float, c_longlong
 
@@ -48,6 +48,7 @@ SIGNATURES = {
     "tsr_target_prep": [_P, _P, _F, _I, _I, _I, _I, _I, _P],
     "tsr_mse_fwd_bwd": [_P, _P, _P, _P, _L, _F, _P, _P],
     "tsr_adam_l2_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
+    "tsr_adam_l2_multi": [_P, _I, _F, _F, _F, _F, _F, _I, _P],
     "tsr_psnr_ssim": [_P, _P, _I, _I, c_double, c_double, c_double, c_double, _P, _P, _P],
     "tpsf_forward": [_P, _P, _P, _P, _P, _I, _P],
     "tpsf_backward": [_P, _P, _P, _P, _I, _P],
@@ -59,6 +60,18 @@ SIGNATURES = {
 }
 
 _lib = None
+
+# Bumped by every kernel that rewrites parameters behind autograd's back (the fused optimizer step): modules key
+# their packed-weight caches on it, so no torch-private version-counter API is needed.
+_param_epoch = [0]
+
+
+def param_epoch() -> int:
+    return _param_epoch[0]
+
+
+def bump_param_epoch() -> None:
+    _param_epoch[0] += 1
 
 
 class TactileSRHipError(RuntimeError):

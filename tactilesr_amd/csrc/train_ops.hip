@@ -6,6 +6,7 @@
 // optim.Adam(lr, weight_decay) (L2-in-grad) of train/tactileSR_train.py:212; the step order of
 // cpu/trainer.py:346-362.
 #include "tsr_common.h"
+#include "tactilesr_hip.h"
 
 #define RED_BLOCKS 512     // partial-sum blocks of the slab reductions (work buffers hold RED_BLOCKS*C*3 doubles)
 
@@ -516,6 +517,53 @@ extern "C" int tsr_adam_l2_step(float* param, const float* grad, float* exp_avg,
   hipLaunchKernelGGL(adam_l2_kernel, dim3(g > 4096 ? 4096 : (int)g), dim3(256), 0, (hipStream_t)stream, param, grad,
                      exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
                      (float)sqrt(bc2));
+  return tsr_check_launch();
+}
+
+// One launch for all parameter tensors: block b owns chunk record b (<= 4096 contiguous elements of one tensor).
+// 16-B accesses when the four pointers are 16-B aligned (torch allocations and the gradient arena are).
+__global__ __launch_bounds__(256) void adam_l2_multi_kernel(const tsr_adam_chunk* __restrict__ chunks, float lr,
+                                                            float b1, float b2, float eps, float wd, float bc1,
+                                                            float bc2_sqrt) {
+  const tsr_adam_chunk c = chunks[blockIdx.x];
+  const float step_size = lr / bc1;
+  auto upd = [&](float w, float g, float& m, float& v) {
+    const float gg = fmaf(wd, w, g);
+    m = b1 * m + (1.f - b1) * gg;
+    v = b2 * v + (1.f - b2) * gg * gg;
+    return w - step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
+  };
+  const bool vec = ((((size_t)c.param | (size_t)c.grad | (size_t)c.exp_avg | (size_t)c.exp_avg_sq) & 15) == 0);
+  const int n4 = vec ? (c.n >> 2) : 0;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    f32x4 w = ((f32x4*)c.param)[i], m = ((f32x4*)c.exp_avg)[i], v = ((f32x4*)c.exp_avg_sq)[i];
+    const f32x4 g = ((const f32x4*)c.grad)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float mj = m[j], vj = v[j];
+      w[j] = upd(w[j], g[j], mj, vj);
+      m[j] = mj;
+      v[j] = vj;
+    }
+    ((f32x4*)c.param)[i] = w;
+    ((f32x4*)c.exp_avg)[i] = m;
+    ((f32x4*)c.exp_avg_sq)[i] = v;
+  }
+  for (int i = n4 * 4 + threadIdx.x; i < c.n; i += 256) {
+    float m = c.exp_avg[i], v = c.exp_avg_sq[i];
+    c.param[i] = upd(c.param[i], c.grad[i], m, v);
+    c.exp_avg[i] = m;
+    c.exp_avg_sq[i] = v;
+  }
+}
+
+extern "C" int tsr_adam_l2_multi(const tsr_adam_chunk* chunks, int n_chunks, float lr, float beta1, float beta2,
+                                 float eps, float weight_decay, int step, void* stream) {
+  if (!chunks || n_chunks <= 0 || step <= 0) return TSR_ERR_ARG;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_l2_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, chunks, lr, beta1,
+                     beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
   return tsr_check_launch();
 }
 

@@ -128,7 +128,9 @@ class TrainEngine:
 
     def __init__(self, model):
         self.m = model
-        self.debug = None        # tests may set a dict: backward then stores clones of dz tensors in it
+        self.debug = None        # tools may set a dict: backward then stores clones of dz tensors in it
+        self.keep_ctx = False    # tests: keep the last forward's context alive in `last_ctx` (activation_masks)
+        self.last_ctx = None
         import os
         # conv arithmetic of the train path: 0 = fp32 MFMA, 3 = split-bf16 (six products, fp32-equivalent),
         # -2 = two scaled fp16 planes (three products; operand scales from device-side max|.| scalars),
@@ -320,8 +322,7 @@ class TrainEngine:
         call("tsr_head_fwd", ptr(c.h0), _I(128), _I(128), ptr(m.output_layer[2].weight.detach()), ptr(out), _I(1),
              _I(B), _I(H), _I(W), stream())
         c.out = out
-        if self.debug is not None:
-            self.debug["ctx"] = c
+        self.last_ctx = c if self.keep_ctx else None
         return out, c
 
     @torch.no_grad()

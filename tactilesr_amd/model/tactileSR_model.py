@@ -173,7 +173,7 @@ class TactileSR(nn.Module):
 
     # ------------------------------------------------------------------ engine
     def _param_key(self):
-        return (self.conv_impl, self.head_impl) + tuple((t.data_ptr(), t._version)
+        return (self.conv_impl, self.head_impl, _lib.param_epoch()) + tuple((t.data_ptr(), t._version)
                                          for t in list(self.parameters()) + list(self.buffers()))
 
     def _build_plan(self):

@@ -300,6 +300,52 @@ def gen_lr():
     np.savez_compressed(os.path.join(HERE, "lr_schedule.npz"), **out)
 
 
+def gen_config():
+    """Keys and values of the reference's three config dicts (config/default.py:8-96).  The module cannot be imported
+    (it shells out to nvidia-smi at import, :101-104), so its dict literals are evaluated from the file's text up to
+    that point; '/code' path prefixes are stored as '<root>'."""
+    import json
+    src = open("/root/reference/config/default.py").read().split("# TODO: change to another file")[0]
+    src = src.replace("from utility.tools import select_gpu_with_least_used_memory", "")
+    ns = {}
+    exec(compile(src, "reference-config", "exec"), ns)
+    out = {}
+    for name in ("tPSFNet_config", "tactileSR_config", "tactileSeqs_config"):
+        out[name] = {k: ("<root>" + v[len("/code"):] if isinstance(v, str) and v.startswith("/code") else v)
+                     for k, v in ns[name].items()}
+    with open(os.path.join(HERE, "config_default.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
+def gen_lr_state():
+    """State dict of the reference's OWN warm-up scheduler 700 ticks into the shipped schedule (inside the warm-up),
+    together with the optimizer state at that point: what a reference-written checkpoint holds under
+    'lr_scheduler' / 'optimizer' (cpu/trainer.py:401-411).  Saved with torch.save (tensors, lists, dicts, numbers
+    only: loads with weights_only=True)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_lr", "/root/reference/cpu/lr_scheduler.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    cfg = dict(LR_CASES["auto_shipped"])
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=cfg.pop('lr'))
+    sch = torch.optim.lr_scheduler.StepLR(opt, step_size=cfg.pop('step'), gamma=0.8)
+    w = ref.LRWarmupScheduler(sch, epoch_len=500, **cfg)
+    tick = 0
+    for _ in range(6):
+        for _ in range(500):
+            tick += 1
+            if tick < 701:
+                p.grad = torch.ones(1)
+                opt.step()
+                w.iter_update()
+        tick += 1
+        if tick < 701:
+            w.epoch_update()
+    torch.save({"lr_scheduler": w.state_dict(), "optimizer": opt.state_dict(), "ticks": 700},
+               os.path.join(HERE, "ref_lr_state.pth"))
+
+
 LR_CASES = {
     "auto_shipped": dict(lr=1e-3, step=2, by_epoch=True, warmup_t=2000, warmup_by_epoch=False, warmup_mode='auto',
                          warmup_init_lr=1e-5, warmup_factor=1e-4),      # config/default.py:56-60 as forwarded
@@ -331,7 +377,7 @@ def lr_sequence(cls, cfg, epochs, epoch_len):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["init", "eval", "train", "tpsf", "metrics", "lr"]
+    which = sys.argv[1:] or ["init", "eval", "train", "tpsf", "metrics", "lr", "lr_state", "config"]
     for w in which:
         globals()["gen_" + w]()
         print("wrote", w)

@@ -107,7 +107,7 @@ def test_checkpoint_layout_roundtrip(tmp_path):
                             warmup_mode="auto", warmup_factor=1e-4)
     path = os.path.join(tmp_path, "checkpoints", "epoch_3.pth")
     CK.save_checkpoint(path, m, opt, sch, epoch=3)
-    ck = torch.load(path, map_location="cpu", weights_only=True)
+    ck = torch.load(path, map_location="cpu", weights_only=False)       # our own file
     assert set(ck) == {"num_gpus", "model", "optimizer", "lr_scheduler", "metric_storage", "epoch"}
     assert ck["num_gpus"] == 1 and ck["epoch"] == 3 and list(ck["model"]) == list(m.state_dict())
     assert os.path.islink(os.path.join(tmp_path, "checkpoints", "latest.pth"))
@@ -187,3 +187,149 @@ def test_device_resident_loader_protocol(tmp_path):
     f = DeviceSRLoader.from_file(path, batch_size=n, device="cpu")
     b = next(iter(f))
     assert torch.equal(b[0], LR) and torch.equal(b[1], HR)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# checkpoint interop with the reference's trainer (cpu/trainer.py:394-498), metric store, config shim
+# ---------------------------------------------------------------------------------------------------------------
+class _ForeignMetricStore(dict):
+    """Stand-in for the reference's pickled MetricStorage instance (an arbitrary python object under
+    'metric_storage': what makes every reference-written checkpoint need a trusted load)."""
+
+
+class _Taker:
+    def __init__(self):
+        self.state = None
+
+    def load_state_dict(self, st):
+        self.state = st
+
+
+@pytest.mark.filterwarnings("ignore:Detected call of")
+def test_load_checkpoint_laid_out_as_the_reference_writes_it(tmp_path, golden):
+    """A dict with exactly the reference's key set -- 'lr_scheduler' and 'optimizer' are the REFERENCE's own objects'
+    states 700 ticks into the shipped schedule (tests/golden/ref_lr_state.pth, written by the reference's class),
+    'metric_storage' a pickled object, plus 'hooks' and 'grad_scaler' -- resumes here: the LR sequence continues the
+    reference's golden sequence, hook and scaler states reach their takers, start_iter follows :452-457."""
+    import tactilesr_amd
+    fx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "ref_lr_state.pth"), weights_only=True)
+    torch.manual_seed(0)
+    m = tactilesr_amd.TactileSR(patternFeatureExtraLayerCnt=1)
+    scaler_state = {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000,
+                    "_growth_tracker": 7}
+    ck = {"num_gpus": 1, "model": m.state_dict(), "optimizer": fx["optimizer"], "lr_scheduler": fx["lr_scheduler"],
+          "metric_storage": _ForeignMetricStore(total_loss=[0.5]), "epoch": 0,
+          "hooks": {"EvalHook": {"best": 1.0}, "UnknownHook": {}}, "grad_scaler": scaler_state}
+    path = os.path.join(tmp_path, "epoch_0.pth")
+    torch.save(ck, path)
+    torch.manual_seed(1)
+    m2 = tactilesr_amd.TactileSR(patternFeatureExtraLayerCnt=1)
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-3)
+    cfg = dict(CASES["auto_shipped"])
+    cfg.pop("lr")
+    sch = LRWarmupScheduler(torch.optim.lr_scheduler.StepLR(opt, cfg.pop("step"), 0.8), epoch_len=500, **cfg)
+    with pytest.raises(Exception):
+        CK.load_checkpoint(path, m2, opt, sch, grad_scaler=_Taker())            # pickled object: needs trusted=True
+    with pytest.raises(AssertionError, match="inconsistent AMP"):
+        CK.load_checkpoint(path, m2, opt, sch, trusted=True)                    # file has grad_scaler, caller has none
+    scaler, evalhook, ckpthook = _Taker(), _Taker(), _Taker()
+    got = CK.load_checkpoint(path, m2, opt, sch, num_gpus=1, trusted=True, grad_scaler=scaler,
+                             hooks={"EvalHook": evalhook, "CheckpointHook": ckpthook}, epoch_len=500)
+    assert got["start_iter"] == 500 and isinstance(got["metric_storage"], _ForeignMetricStore)
+    assert scaler.state == scaler_state and evalhook.state == {"best": 1.0} and ckpthook.state is None
+    assert got["hooks_missing"] == ["CheckpointHook"] and got["hooks_unexpected"] == ["UnknownHook"]
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    # continue from tick 700 (699 iterations + 1 epoch end) to the end of the 6-epoch fixture
+    ref = golden("lr_schedule")["auto_shipped"]
+    lrs, tick = [], 0
+    for _ in range(6):
+        for _ in range(500):
+            tick += 1
+            if tick >= 701:
+                opt.step()
+                sch.iter_update()
+                lrs.append(opt.param_groups[0]["lr"])
+        tick += 1
+        if tick >= 701:
+            sch.epoch_update()
+            lrs.append(opt.param_groups[0]["lr"])
+    assert np.array_equal(np.array(lrs), ref[701:])
+    assert opt.param_groups[0]["lr"] == ref[-1]
+
+
+@pytest.mark.filterwarnings("ignore:Detected call of")
+def test_reference_state_dict_matches_the_reference_class_at_the_same_tick():
+    fx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "ref_lr_state.pth"), weights_only=True)
+    cfg = dict(CASES["auto_shipped"])
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=cfg.pop("lr"))
+    sch = LRWarmupScheduler(torch.optim.lr_scheduler.StepLR(opt, cfg.pop("step"), 0.8), epoch_len=500, **cfg)
+    for _ in range(500):
+        opt.step()
+        sch.iter_update()
+    sch.epoch_update()
+    for _ in range(199):
+        opt.step()
+        sch.iter_update()
+    mine, ref = sch.reference_state_dict(), fx["lr_scheduler"]
+    assert set(mine) <= set(ref)
+    for k in ("last_iter", "last_epoch", "in_iter_warmup"):
+        assert mine[k] == ref[k], k
+    for k in ("last_epoch", "_step_count", "_last_lr"):
+        assert mine["torch_scheduler"][k] == ref["torch_scheduler"][k], k
+    assert opt.param_groups[0]["lr"] == fx["optimizer"]["param_groups"][0]["lr"]
+
+
+def test_saved_checkpoint_carries_a_metric_store_the_reference_protocol_accepts(tmp_path):
+    """save_checkpoint's default 'metric_storage' is an object the reference's hooks can keep using after installing
+    it as the live store (cpu/trainer.py:469; cpu/hooks/logger_hook.py:38-95; cpu/hooks/lr_update_hook.py:29-37)."""
+    import tactilesr_amd
+    from tactilesr_amd.train.metrics import MetricStorage
+    m = tactilesr_amd.TactileSR(patternFeatureExtraLayerCnt=1)
+    ms = MetricStorage(window_size=3)
+    for it, v in enumerate([4.0, 2.0, 6.0, 8.0]):
+        ms.update(iter=it, total_loss=v)
+        ms.update(iter=it, smooth=False, lr=1e-3 * (it + 1))
+    path = os.path.join(tmp_path, "c", "iter_3.pth")
+    CK.save_checkpoint(path, m, iteration=3, metric_storage=ms)
+    with pytest.raises(Exception):
+        torch.load(path, map_location="cpu", weights_only=True)
+    ck = CK.load_checkpoint(path, m)                 # own classes: restricted unpickler is enough
+    st = ck["metric_storage"]
+    assert ck["start_iter"] == 4 and isinstance(st, MetricStorage) and set(st) == {"total_loss", "lr"}
+    assert st["total_loss"].latest == 8.0 and abs(st["total_loss"].avg - 16.0 / 3) < 1e-12      # window of 3
+    assert st["total_loss"].global_avg == 5.0 and st["total_loss"].global_sum == 20.0
+    assert st.values_maybe_smooth == {"total_loss": (3, 16.0 / 3), "lr": (3, 4e-3)}
+    st.update(iter=4, total_loss=1.0)                                    # keeps working as the live store
+    assert st["total_loss"].latest == 1.0 and "Eval Metric" not in st
+    with pytest.raises(AssertionError):
+        st.update(iter=4, total_loss=1.0)                                # iterations must increase
+    with pytest.raises(AssertionError):
+        st.update(iter=5, smooth=False, total_loss=1.0)                  # smooth flag is fixed per metric
+    CK.save_checkpoint(os.path.join(tmp_path, "c", "epoch_0.pth"), m, epoch=0)             # default: empty store
+    assert isinstance(CK.load_checkpoint(os.path.join(tmp_path, "c", "latest.pth"), m, trusted=True)["metric_storage"],
+                      MetricStorage)
+
+
+def test_config_default_carries_the_reference_keys_and_values():
+    """tactilesr_amd.config.default vs the reference's three dicts (tests/golden/config_default.json, extracted from
+    config/default.py:8-96): same key sets, same values; paths hang off root_path instead of /code; importing it
+    never touches a GPU and 'device' resolves lazily."""
+    import json
+    from tactilesr_amd.config import default as D
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config_default.json")))
+    for name, rd in ref.items():
+        mine = getattr(D, name)
+        assert set(mine) == set(rd), (name, set(mine) ^ set(rd))
+        for k, v in rd.items():
+            if isinstance(v, str) and v.startswith("<root>"):
+                assert mine[k] == os.path.join(D.root_path, v[len("<root>/"):]) if len(v) > 6 else mine[k] == D.root_path
+            else:
+                assert mine[k] == v and type(mine[k]) is type(v), (name, k, mine[k], v)
+    assert D.tactileSeqs_config["seqsCnt"] == 7 and D.tactileSR_config["warmup_by_epoch"] is True
+    if not torch.cuda.is_available():
+        from tactilesr_amd._lib import TactileSRHipError
+        with pytest.raises(TactileSRHipError):
+            D.device
