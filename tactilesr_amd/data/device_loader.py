@@ -23,12 +23,16 @@ class DeviceSRLoader:
                  rank: int = 0, world_size: int = 1):
         assert LR.shape[0] == HR.shape[0], "LR and HR must hold the same number of samples"
         dev = torch.device(device)
-        # contiguous shard of the set for this rank (data-parallel training: one process per GPU)
+        # shard of the set for this rank (data-parallel training: one process per GPU).  EVERY rank gets the same
+        # number of samples -- ceil(n/world), the tail wrapping around to the head like DistributedSampler's padding --
+        # so every rank runs the same number of batches per epoch and nobody is left alone in an all-reduce.
         n = LR.shape[0]
-        per = (n + world_size - 1) // world_size
-        lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
-        self.LR = LR[lo:hi].to(dev).contiguous()
-        self.HR = HR[lo:hi].to(dev).contiguous()
+        if world_size > 1:
+            from ..ddp import equal_shard
+            idx = torch.as_tensor(equal_shard(n, rank, world_size), dtype=torch.long)
+            LR, HR = LR.index_select(0, idx.to(LR.device)), HR.index_select(0, idx.to(HR.device))
+        self.LR = LR.to(dev).contiguous()
+        self.HR = HR.to(dev).contiguous()
         self.batch_size, self.shuffle, self.drop_last = int(batch_size), bool(shuffle), bool(drop_last)
         self._gen = torch.Generator(device=dev)
         self._gen.manual_seed(0 if seed is None else int(seed))

@@ -1,20 +1,33 @@
-"""Data-parallel training over the GPUs of one node: one process per GPU, weights replicated,
-batch sharded by sample, rank-local BatchNorm statistics (what torch DDP without SyncBN does --
-SURVEY.md section 5), and ONE collective per step: an all-reduce (mean) of the 18.33 MB fp32 gradient over
-RCCL/xGMI.  The reference only carries the latent hooks for this (cpu/distributed.py:171-217,
-cpu/trainer.py:172-176); no script wires it, so this is the build's own design.
+"""Data-parallel training over the GPUs of one node: one process per GPU, weights replicated, batch sharded by
+sample, rank-local BatchNorm statistics (what torch DDP without SyncBN does -- SURVEY.md section 5), and ONE
+collective per step: the all-reduce (mean) of the 18.33 MB fp32 gradient over RCCL/xGMI, cut into buckets that are
+issued FROM INSIDE backward as soon as their last gradient is final, so they run under the remaining backward
+kernels.  The reference only carries the latent hooks for this (cpu/distributed.py:171-217, cpu/trainer.py:172-176);
+no script wires it, so this is the build's own design.
 
-Gradients are copied into one flat fp32 buffer split into a few contiguous buckets; each bucket's
-all-reduce is issued asynchronously (RCCL runs it on its own stream) and they are waited on
-together before the optimizer step.  On a full-mesh xGMI node 18 MB moves in well under 1 ms,
-against >100 ms of backward compute, so bucket granularity only matters for launch latency.
+Pieces
+* ``GradArena`` -- one flat fp32 buffer holding every parameter gradient, laid out in the ORDER BACKWARD PRODUCES
+  THEM, cut into contiguous buckets.  The backward engine writes each weight gradient straight into its arena view
+  (``tsr_reduce_splits`` writes there: no copy in, no copy out) and ticks it off; when a bucket's last tensor is
+  ticked the arena fires ``on_bucket_ready``.  The arena is engine-agnostic (the CPU tests drive it from a toy
+  autograd function).
+* ``GradSync`` -- owns the process group side: on ``bucket_ready`` it enqueues ``all_reduce(bucket, async_op=True)``
+  (RCCL orders it after the producing kernels through the stream it was called on, then runs it on its own stream),
+  ``finish()`` (between ``backward()`` and ``optimizer.step()``) waits for the works, turns sums into means and
+  makes every ``p.grad`` the arena view.  ``broadcast_parameters`` sends ALL parameters and ALL buffers (BatchNorm
+  running statistics included) from one rank.
+
+On a full-mesh xGMI node 18 MB moves in well under 1 ms against >100 ms of backward compute: bucket granularity only
+decides how early the first byte leaves, not the step time.
 """
 from __future__ import annotations
 
-from typing import List
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+
+_ALIGN = 64          # arena views start on 256-B boundaries (16-B vector accesses in the fused Adam kernel)
 
 
 def init_distributed(backend: str = "nccl"):
@@ -33,63 +46,197 @@ def init_distributed(backend: str = "nccl"):
     return rank, world, local
 
 
-def shard_batch(n: int, rank: int, world: int):
+def shard_batch(n: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous sample range of this rank (global batch split B/world per GPU)."""
     per = (n + world - 1) // world
     return min(n, rank * per), min(n, (rank + 1) * per)
 
 
-class GradSync:
-    """Bucketed gradient averaging for a replicated model."""
+def equal_shard(n: int, rank: int, world: int) -> List[int]:
+    """Sample indices of this rank when EVERY rank must see the same count (a data-parallel epoch: a rank with fewer
+    batches would leave the others blocked in their all-reduce).  ceil(n/world) per rank; the tail wraps around to the
+    head of the set, like torch's DistributedSampler pads."""
+    per = (n + world - 1) // world
+    return [(rank * per + i) % n for i in range(per)] if n > 0 else []
 
-    def __init__(self, params, n_buckets: int = 4, group=None):
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+
+class GradArena:
+    """Flat gradient buffer in backward-production order, with bucket completion tracking."""
+
+    def __init__(self, layout: Sequence[Tuple[str, torch.Size]], device, n_buckets: int = 8):
+        self.names = [n for n, _ in layout]
+        self.shapes: Dict[str, torch.Size] = {n: torch.Size(s) for n, s in layout}
+        self.offsets: Dict[str, int] = {}
+        off = 0
+        for n, s in layout:
+            self.offsets[n] = off
+            off += (torch.Size(s).numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.total = off
+        self.flat = torch.zeros(max(off, 1), dtype=torch.float32, device=device)
+        # contiguous buckets of ~equal size, cut at tensor boundaries
+        target = max(1, self.total // max(1, n_buckets))
+        self.buckets: List[Tuple[int, int]] = []
+        self.bucket_of: Dict[str, int] = {}
+        start = 0
+        for i, n in enumerate(self.names):
+            self.bucket_of[n] = len(self.buckets)
+            end = self.offsets[self.names[i + 1]] if i + 1 < len(self.names) else self.total
+            if end - start >= target and len(self.buckets) < n_buckets - 1 and i + 1 < len(self.names):
+                self.buckets.append((start, end))
+                start = end
+        self.buckets.append((start, self.total))
+        self._members = [sum(1 for n in self.names if self.bucket_of[n] == k) for k in range(len(self.buckets))]
+        self._left = list(self._members)
+        self.on_bucket_ready: Optional[Callable[[int, torch.Tensor], None]] = None
+
+    def view(self, name: str) -> torch.Tensor:
+        """A FRESH view object of `name`'s slot (autograd may adopt it as .grad without a copy)."""
+        o = self.offsets[name]
+        return self.flat[o:o + self.shapes[name].numel()].view(self.shapes[name])
+
+    def begin(self) -> None:
+        self._left = list(self._members)
+
+    def done(self, name: str) -> None:
+        """`name`'s slot holds its final value; fires the bucket callback when its bucket is complete."""
+        k = self.bucket_of[name]
+        self._left[k] -= 1
+        if self._left[k] == 0 and self.on_bucket_ready is not None:
+            a, b = self.buckets[k]
+            self.on_bucket_ready(k, self.flat[a:b])
+
+    def bucket(self, k: int) -> torch.Tensor:
+        a, b = self.buckets[k]
+        return self.flat[a:b]
+
+
+class GradSink:
+    """What a backward engine writes its parameter gradients through (one per backward call).
+
+    ``owner`` is the engine: it carries ``arena`` (None until the first backward has revealed the production order),
+    ``grad_sync`` (None on one GPU) and ``n_buckets``.  Three cases:
+      direct  -- the arena exists and every parameter's .grad is None (``zero_grad()``'s default): ``dest`` hands out
+                 arena views, ``put`` ticks the arena, complete buckets go to the wire from inside backward;
+      first   -- no arena yet: gradients land in fresh tensors while the order is recorded; ``finalize`` builds the
+                 arena in that order, moves them in and binds the GradSync (buckets are reduced in ``finish``);
+      accum   -- some .grad is set (gradient accumulation, ``zero_grad(set_to_none=False)``): fresh tensors are
+                 returned so autograd can add them to the existing .grad; nothing is issued early.
+    """
+
+    def __init__(self, owner, named_params: Dict[str, torch.nn.Parameter], device):
+        self.owner, self.device = owner, device
+        arena = getattr(owner, "arena", None)
+        if arena is not None and any(n not in named_params or named_params[n].shape != arena.shapes[n]
+                                     for n in arena.names):
+            arena = owner.arena = None                                   # the module tree changed: lay out again
+        self.first = arena is None
+        self.direct = arena is not None and all(p.grad is None for p in named_params.values())
+        self.arena = arena if self.direct else None
+        if self.direct:
+            arena.begin()
+        self.out: Dict[str, torch.Tensor] = {}
+        self.order: List[Tuple[str, torch.Size]] = []
+
+    def dest(self, name: str, shape) -> torch.Tensor:
+        if self.arena is not None:
+            if name not in self.arena.offsets:
+                raise KeyError(f"gradient '{name}' has no slot in the arena (laid out for a different module tree)")
+            return self.arena.view(name)
+        return torch.empty(torch.Size(shape), dtype=torch.float32, device=self.device)
+
+    def put(self, name: str, t: torch.Tensor) -> None:
+        self.out[name] = t
+        self.order.append((name, t.shape))
+        if self.arena is not None:
+            self.arena.done(name)
+
+    def put_copy(self, name: str, src: torch.Tensor) -> None:
+        d = self.dest(name, src.shape)
+        d.copy_(src)
+        self.put(name, d)
+
+    def finalize(self) -> Dict[str, torch.Tensor]:
+        if self.first:
+            arena = GradArena(self.order, self.device, getattr(self.owner, "n_buckets", 8))
+            for n, t in self.out.items():
+                arena.view(n).copy_(t)
+            self.out = {n: arena.view(n) for n in self.out}
+            self.owner.arena = arena
+            sync = getattr(self.owner, "grad_sync", None)
+            if sync is not None:
+                sync.bind(arena)
+        return self.out
+
+
+class GradSync:
+    """Gradient averaging for a replicated model whose backward fills a ``GradArena``."""
+
+    def __init__(self, module: torch.nn.Module, group=None, engine=None):
+        self.module = module
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        total = sum(p.numel() for p in self.params)
-        p0 = self.params[0]
-        self.flat = torch.zeros(total, dtype=torch.float32, device=p0.device)
-        self.views = []
-        off = 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
-        # contiguous buckets of ~equal byte size, cut at parameter boundaries
-        target = max(1, total // max(1, n_buckets))
-        self.buckets = []
-        start = 0
-        acc = 0
-        for i, p in enumerate(self.params):
-            acc += p.numel()
-            if acc >= target and len(self.buckets) < n_buckets - 1:
-                end = sum(q.numel() for q in self.params[:i + 1])
-                self.buckets.append((start, end))
-                start, acc = end, 0
-        self.buckets.append((start, total))
+        self.arena: Optional[GradArena] = None
+        self._works: Dict[int, object] = {}
+        self.events: List[Tuple[str, int]] = []      # ("enqueue", bucket) / ("finish", n): the tests read the order
+        if engine is None and hasattr(module, "train_engine"):
+            engine = module.train_engine()           # tactilesr_amd.TactileSR: its HIP backward engine
+        if engine is not None:
+            engine.grad_sync = self
+            if getattr(engine, "arena", None) is not None:
+                self.bind(engine.arena)
 
-    def broadcast_parameters(self, src: int = 0):
-        """Make every replica start from rank `src`'s weights and BN buffers."""
+    # ---- wiring ----------------------------------------------------------------------------------------------
+    def bind(self, arena: GradArena) -> None:
+        """Called by the backward engine once its arena exists (after the first backward)."""
+        self.arena = arena
+        arena.on_bucket_ready = self._bucket_ready
+
+    def _bucket_ready(self, k: int, flat_slice: torch.Tensor) -> None:
         if self.world == 1:
             return
-        for p in self.params:
-            dist.broadcast(p.data, src, group=self.group)
+        self.events.append(("enqueue", k))
+        self._works[k] = dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def __call__(self):
-        """grad <- mean over ranks.  Call between backward() and optimizer.step()."""
+    # ---- per step --------------------------------------------------------------------------------------------
+    def finish(self) -> None:
+        """grad <- mean over ranks.  Call between backward() and optimizer.step().  Buckets that were not issued
+        from inside backward (first step: the arena is built at its end; or gradients accumulated into existing
+        .grad tensors) are reduced here."""
+        if self.world == 1 or self.arena is None:
+            return
+        arena = self.arena
+        named = dict(self.module.named_parameters())
+        stale = [n for n in arena.names if n in named and named[n].grad is not None
+                 and named[n].grad.data_ptr() != arena.flat.data_ptr() + 4 * arena.offsets[n]]
+        if stale and not self._works:
+            # gradients live outside the arena (accumulated into foreign tensors): bring them in, reduce everything
+            for n in stale:
+                arena.view(n).copy_(named[n].grad)
+        for k in range(len(arena.buckets)):
+            if k not in self._works:
+                self.events.append(("enqueue_late", k))
+                self._works[k] = dist.all_reduce(arena.bucket(k), op=dist.ReduceOp.SUM, group=self.group,
+                                                 async_op=True)
+        for k in sorted(self._works):
+            self._works[k].wait()
+        self._works.clear()
+        arena.flat.div_(self.world)
+        for n in arena.names:
+            p = named.get(n)
+            if p is not None and p.requires_grad:
+                p.grad = arena.view(n)          # autograd may have cloned the view it was handed: re-point
+        self.events.append(("finish", len(arena.buckets)))
+
+    __call__ = finish
+
+    # ---- start-up --------------------------------------------------------------------------------------------
+    def broadcast_parameters(self, src: int = 0) -> None:
+        """Every replica starts from rank `src`'s state: ALL parameters (frozen ones too) and ALL buffers
+        (BatchNorm running_mean / running_var / num_batches_tracked)."""
         if self.world == 1:
             return
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                v.zero_()
-            else:
-                v.copy_(p.grad)
-        works = [dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                 for a, b in self.buckets]
-        for w in works:
-            w.wait()
-        self.flat.div_(self.world)
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+        with torch.no_grad():
+            for t in list(self.module.parameters()) + list(self.module.buffers()):
+                dist.broadcast(t.data, src, group=self.group)
+        from . import _lib
+        _lib.bump_param_epoch()       # cached weight packs of the HIP modules are stale now

@@ -131,6 +131,12 @@ class TrainEngine:
         self.debug = None        # tools may set a dict: backward then stores clones of dz tensors in it
         self.keep_ctx = False    # tests: keep the last forward's context alive in `last_ctx` (activation_masks)
         self.last_ctx = None
+        # gradient arena (tactilesr_amd.ddp): one flat buffer in backward-production order; weight gradients are
+        # reduced straight into it, so p.grad addresses are stable across steps (the fused Adam's table is built
+        # once) and a GradSync can put finished buckets on the wire from inside backward
+        self.arena = None
+        self.grad_sync = None
+        self.n_buckets = 8
         import os
         # conv arithmetic of the train path: 0 = fp32 MFMA, 3 = split-bf16 (six products, fp32-equivalent),
         # -2 = two scaled fp16 planes (three products; operand scales from device-side max|.| scalars),
@@ -394,13 +400,13 @@ class TrainEngine:
             call("tsr_conv2d_wgrad", ptr(a.buf), _I(a.ctot), _I(a.coff), _I(cin), ptr(a.scale), ptr(a.shift),
                  ptr(dz.buf), _I(dz.ctot), _I(dz.coff), _I(cout), _I(ks), ptr(slab), ptr(bslab), _I(ns),
                  _I(c.B), _I(c.H), _I(c.W), stream())
-        gw = torch.empty_like(w)
+        gw = grads.dest(name + ".weight", w.shape)
         call("tsr_reduce_splits", ptr(slab), ptr(gw), _L(n), _I(ns), _F(1.0), stream())
-        grads[name + ".weight"] = gw
+        grads.put(name + ".weight", gw)
         if with_bias:
-            gb = torch.empty(cout, dtype=torch.float32, device=w.device)
+            gb = grads.dest(name + ".bias", (cout,))
             call("tsr_reduce_splits", ptr(bslab), ptr(gb), _L(cout), _I(ns), _F(1.0), stream())
-            grads[name + ".bias"] = gb
+            grads.put(name + ".bias", gb)
 
     def _dgrad(self, c, dz: Act, conv, ci0, nprime, out, out_ctot, out_coff, res: Act = None, mask: Act = None,
                bn=False, out_amax=None):
@@ -432,7 +438,8 @@ class TrainEngine:
         m = self.m
         dev = dout.device
         B, H, W, HW = c.B, c.H, c.W, c.HW
-        grads = {}
+        from ..ddp import GradSink
+        grads = GradSink(self, dict(m.named_parameters()), dev)
 
         def buf(ch):
             return torch.empty(B * ch * HW, dtype=torch.float32, device=dev)
@@ -447,9 +454,9 @@ class TrainEngine:
         call("tsr_head_bwd", ptr(dout), ptr(c.out), ptr(c.h0), _I(128), _I(128),
              ptr(m.output_layer[2].weight.detach()), ptr(dz_h0), _I(128), ptr(wslab), _I(ns), _I(B), _I(H), _I(W),
              ptr(am_dzh0), stream())
-        gw = torch.empty_like(m.output_layer[2].weight)
+        gw = grads.dest("output_layer.2.weight", m.output_layer[2].weight.shape)
         call("tsr_reduce_splits", ptr(wslab), ptr(gw), _L(128 * 9), _I(ns), _F(1.0), stream())
-        grads["output_layer.2.weight"] = gw
+        grads.put("output_layer.2.weight", gw)
         DZ = Act(dz_h0, 128, 0, 128, amax=am_dzh0)
         HC = Act(c.hcat, 128, 0, 128, amax=c.am_hcat)
         self._wgrad(c, HC, DZ, m.output_layer[0], grads, "output_layer.0", False)
@@ -480,9 +487,9 @@ class TrainEngine:
         sslab = torch.empty(ns * 64 * 27, dtype=torch.float32, device=dev)
         call("tsr_stem_wgrad", ptr(c.x), _I(c.x.shape[1]), _I(0), _I(c.hin), _I(c.win), _I(m.scale_factor),
              ptr(dpre.buf), _I(dpre.ctot), _I(dpre.coff), ptr(sslab), _I(ns), _I(B), stream())
-        gw = torch.empty_like(m.input_layer_force[1].weight)
+        gw = grads.dest("input_layer_force.1.weight", m.input_layer_force[1].weight.shape)
         call("tsr_reduce_splits", ptr(sslab), ptr(gw), _L(64 * 27), _I(ns), _F(1.0), stream())
-        grads["input_layer_force.1.weight"] = gw
+        grads.put("input_layer_force.1.weight", gw)
 
         # ---- pattern branch: MSRB blocks reversed
         dpre = Act(g_hcat, 128, 64, 64, amax=am_ghcat)
@@ -501,7 +508,8 @@ class TrainEngine:
                 self._dgrad(c, dpre, blk.confusion, o, 128, g2, 256, o, mask=mk, bn=True)
                 r = self._bn_bwd(c, g2, 256, o, Act(s.cat2, 256, 0, 256), o, 128, s.bn_c2[:, o:o + 128], bnm, grads,
                                  nm, out_amax=am_g2[half])
-                grads[f"{name}.{nm}.1.weight"], grads[f"{name}.{nm}.1.bias"] = r[0].clone(), r[1].clone()
+                grads.put_copy(f"{name}.{nm}.1.weight", r[0])
+                grads.put_copy(f"{name}.{nm}.1.bias", r[1])
             if self.debug is not None:
                 self.debug[f"msrb{i}.dz2"] = g2.clone()
             DZ32, DZ52 = Act(g2, 256, 0, 128, amax=am_g2[0]), Act(g2, 256, 128, 128, amax=am_g2[1])
@@ -513,8 +521,10 @@ class TrainEngine:
             self._dgrad(c, DZ52, blk.conv_5_2[0], 0, 128, g1, 128, 0, res=Act(g1, 128, 0, 128), mask=mk, bn=True)
             am_g1 = new_amax()
             r = self._bn_bwd(c, g1, 128, 0, Act(s.cat1, 128, 0, 128), 0, 128, s.bn_c1, None, grads, "", out_amax=am_g1)
-            grads[f"{name}.conv_3_1.1.weight"], grads[f"{name}.conv_3_1.1.bias"] = r[0, :64].clone(), r[1, :64].clone()
-            grads[f"{name}.conv_5_1.1.weight"], grads[f"{name}.conv_5_1.1.bias"] = r[0, 64:].clone(), r[1, 64:].clone()
+            grads.put_copy(f"{name}.conv_3_1.1.weight", r[0, :64])
+            grads.put_copy(f"{name}.conv_3_1.1.bias", r[1, :64])
+            grads.put_copy(f"{name}.conv_5_1.1.weight", r[0, 64:])
+            grads.put_copy(f"{name}.conv_5_1.1.bias", r[1, 64:])
             del g2
             if self.debug is not None:
                 self.debug[f"msrb{i}.dz1"] = g1.clone()
@@ -531,7 +541,8 @@ class TrainEngine:
             del g1
         # X of block 0 is the fuse conv's relu(bn(zf)): finish its BN backward -> dzf
         r = self._bn_bwd(c, dpre.buf, 64, 0, Act(c.zf, 64, 0, 64), 0, 64, c.bnf, None, grads, "", out_amax=dpre.amax)
-        grads["inputContact_layer.1.weight"], grads["inputContact_layer.1.bias"] = r[0].clone(), r[1].clone()
+        grads.put_copy("inputContact_layer.1.weight", r[0])
+        grads.put_copy("inputContact_layer.1.bias", r[1])
         T = m.seqsCnt
         AT = Act(c.catT, 64 * T, 0, 64 * T, c.bn2[0], c.bn2[1], c.bn2[2], c.bn2[3], amax=c.am_catT)
         self._wgrad(c, AT, dpre, m.inputContact_layer[0], grads, "inputContact_layer.0", False)
@@ -545,7 +556,8 @@ class TrainEngine:
             am_gT = new_amax()
             r = self._bn_bwd(c, gT, 64 * T, o, Act(c.catT, 64 * T, 0, 64 * T), o, 64, c.bn2[:, o:o + 64], None, grads,
                              "", out_amax=am_gT)
-            grads[name + ".5.weight"], grads[name + ".5.bias"] = r[0].clone(), r[1].clone()
+            grads.put_copy(name + ".5.weight", r[0])
+            grads.put_copy(name + ".5.bias", r[1])
             DZ2 = Act(gT, 64 * T, o, 64, amax=am_gT)
             v1 = c.bn1[t]
             A1 = Act(c.z1[t], 64, 0, 64, v1[0], v1[1], v1[2], v1[3], amax=c.am_z1[t])
@@ -553,15 +565,16 @@ class TrainEngine:
             g1 = buf(64)
             self._dgrad(c, DZ2, seq[4], 0, 64, g1, 64, 0, mask=A1, bn=True)
             r = self._bn_bwd(c, g1, 64, 0, Act(c.z1[t], 64, 0, 64), 0, 64, v1, None, grads, "")
-            grads[name + ".2.weight"], grads[name + ".2.bias"] = r[0].clone(), r[1].clone()
+            grads.put_copy(name + ".2.weight", r[0])
+            grads.put_copy(name + ".2.bias", r[1])
             ns = max(1, min(B, 2048))     # image splits: ~8 resident workgroups per CU hide the load latency
             sslab = torch.empty(ns * 64 * 27, dtype=torch.float32, device=dev)
             call("tsr_stem_wgrad", ptr(c.x), _I(c.x.shape[1]), _I(m.axisCnt * t), _I(c.hin), _I(c.win),
                  _I(m.scale_factor), ptr(g1), _I(64), _I(0), ptr(sslab), _I(ns), _I(B), stream())
-            gw = torch.empty_like(seq[1].weight)
+            gw = grads.dest(name + ".1.weight", seq[1].weight.shape)
             call("tsr_reduce_splits", ptr(sslab), ptr(gw), _L(64 * 27), _I(ns), _F(1.0), stream())
-            grads[name + ".1.weight"] = gw
-        return grads
+            grads.put(name + ".1.weight", gw)
+        return grads.finalize()
 
 
 class TactileSRTrainFn(torch.autograd.Function):

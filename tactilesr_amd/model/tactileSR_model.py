@@ -337,11 +337,9 @@ class TactileSR(nn.Module):
                                          "its input to a ROCm device (no CPU fallback)")
         if self.training:
             # batch-statistics BatchNorm + autograd through the HIP backward (model/_train.py)
-            from ._train import TrainEngine, TactileSRTrainFn
-            if self._train_engine is None:
-                self._train_engine = TrainEngine(self)
+            from ._train import TactileSRTrainFn
             named = list(self.named_parameters())
-            out = TactileSRTrainFn.apply(self._train_engine, [n for n, _ in named],
+            out = TactileSRTrainFn.apply(self.train_engine(), [n for n, _ in named],
                                          x.detach().float().contiguous(), *[p for _, p in named])
             self._plan = None      # running statistics were updated in place by the kernels
             return out
@@ -354,6 +352,13 @@ class TactileSR(nn.Module):
             b1 = min(B, b0 + step)
             self._infer_pass(x[b0:b1], out[b0:b1])
         return out
+
+    def train_engine(self):
+        """The module's HIP training engine (created on first use)."""
+        if self._train_engine is None:
+            from ._train import TrainEngine
+            self._train_engine = TrainEngine(self)
+        return self._train_engine
 
     @torch.no_grad()
     def forward_with_stages(self, x):

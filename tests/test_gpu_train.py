@@ -530,3 +530,74 @@ def test_fused_multi_tensor_adam_matches_torch_adam_in_one_launch_per_step():
     sd = opt.state_dict()
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 5
     assert relerr(sd["state"][0]["exp_avg_sq"], ref.state_dict()["state"][0]["exp_avg_sq"]) < 1e-6
+
+
+def test_gradient_arena_and_inbackward_bucket_allreduce_on_the_hip_engine(T):
+    """The data-parallel machinery on the real engine, single-rank RCCL group (the pool gives one GPU): weight
+    gradients are reduced straight into the arena (p.grad aliases it: no copies), from the second step on every bucket's
+    all-reduce is enqueued from INSIDE backward, in production order, and the result equals the un-synced gradient
+    (x 1/2: the world size is forced to 2 so that the reduce + mean path really runs; a 1-rank sum is the identity)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from tactilesr_amd import ddp, optim
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    ddp.init_distributed("nccl")
+    try:
+        cfg = dict(patternFeatureExtraLayerCnt=2)
+        sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), 31)
+        g = torch.Generator().manual_seed(32)
+        LR, HR = (torch.rand(4, 3, 4, 4, generator=g) * 8).cuda(), (torch.rand(4, 1, 40, 40, generator=g) * 25).cuda()
+
+        def fresh():
+            m = T.TactileSR(**cfg)
+            m.load_state_dict(sd, strict=True)
+            return m.cuda().train()
+
+        ref = fresh()
+        F.mse_loss(ref(LR), HR).backward()
+        ref_g = {k: p.grad.detach().clone() for k, p in ref.named_parameters()}
+        m = fresh()
+        sync = ddp.GradSync(m)
+        assert sync.world == 1 and dist.get_backend() == "nccl"
+        sync.world = 2
+        named = dict(m.named_parameters())
+        for step in range(3):
+            for p in m.parameters():
+                p.grad = None
+            with torch.no_grad():                       # same weights and BN statistics every step
+                m.load_state_dict(sd, strict=True)
+            sync.events.clear()
+            F.mse_loss(m(LR), HR).backward()
+            ev = list(sync.events)
+            arena = m.train_engine().arena
+            assert all(named[n].grad.data_ptr() == arena.flat.data_ptr() + 4 * arena.offsets[n] for n in arena.names), \\
+                "autograd did not adopt the arena views"
+            sync.finish()
+            nb = len(arena.buckets)
+            if step == 0:
+                assert ev == [] and [e[0] for e in sync.events[:nb]] == ["enqueue_late"] * nb
+            else:
+                assert ev == [("enqueue", k) for k in range(nb)], ev
+            torch.cuda.synchronize()
+            for k, p in named.items():
+                assert torch.equal(p.grad, ref_g[k] * 0.5), (step, k)
+        assert nb == 8 and set(arena.names) == set(named)
+        # production order: the head's gradients come first, the stems' last
+        assert arena.names[0] == "output_layer.2.weight" and arena.names[-1] == "inputLayer_pattern_list.0.1.weight"
+        # the fused Adam then steps from the arena with a table that is built once
+        opt = optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-2)
+        opt.step()
+        n_tables = len(opt._tables)
+        for p in m.parameters():
+            p.grad = None
+        F.mse_loss(m(LR), HR).backward()
+        sync.finish()
+        opt.step()
+        assert len(opt._tables) == n_tables == 1 and opt.launches == 2
+    finally:
+        dist.destroy_process_group()
