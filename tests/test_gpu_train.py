@@ -575,7 +575,7 @@ def test_gradient_arena_and_inbackward_bucket_allreduce_on_the_hip_engine(T):
             F.mse_loss(m(LR), HR).backward()
             ev = list(sync.events)
             arena = m.train_engine().arena
-            assert all(named[n].grad.data_ptr() == arena.flat.data_ptr() + 4 * arena.offsets[n] for n in arena.names), \\
+            assert all(named[n].grad.data_ptr() == arena.flat.data_ptr() + 4 * arena.offsets[n] for n in arena.names), \
                 "autograd did not adopt the arena views"
             sync.finish()
             nb = len(arena.buckets)
