@@ -179,7 +179,8 @@ def test_device_resident_loader_protocol(tmp_path):
     for b in DeviceSRLoader(LR, HR, batch_size=4, shuffle=True, seed=1, device="cpu"):   # pairs stay aligned
         assert torch.equal(b[1][:, 0, 0, 0], b[0][:, 0, 0, 0] * 2)
     shards = [DeviceSRLoader(LR, HR, batch_size=16, device="cpu", rank=r, world_size=2) for r in range(2)]
-    assert torch.equal(torch.cat([next(iter(s))[0] for s in shards]), LR)
+    got = [next(iter(s))[0][:, 0, 0, 0].tolist() for s in shards]          # equal sizes; the tail wraps to the head
+    assert got == [[0, 1, 2, 3, 4, 5], [6, 7, 8, 9, 10, 0]]
     entries = [[{"LR": LR[i], "depth": torch.zeros(1, 100, 100), "HR": HR[i], "LR_degrade": torch.zeros(1, 4, 4),
                  "alphaBeta": torch.zeros(3)}] for i in range(n)]
     path = os.path.join(tmp_path, "SRdataset_train.npy")
