@@ -187,3 +187,42 @@ def test_tpsf_B8192_forward_backward_tiling_invariance():
     assert abs(loss.item() - lo.item()) < 1e-5 * lo.item()
     for (k, p), ref in zip(net.named_parameters(), gl):
         assert relerr(p.grad, ref) < 1e-4, k
+
+
+def test_seqs_dataset_generator_matches_the_batch1_loop(tmp_path):
+    """The batched Seqs generator against a literal batch-1 restatement of the reference loop
+    (data/SeqsDataset/seqsDepth2Tactile.py:47-98): per item the seven LR frames newest first -> LR (21,4,4), tPSFNet on
+    the 30-degree tap only, entries {LR, depth, HR}, translation 0 -> test, 1 -> validation, rest -> train; and the
+    file reads back like utility/load_tactile_dataset.py:52-57."""
+    import os
+    import tactilesr_amd
+    from tactilesr_amd.data import seqs_depth2tactile as S
+    torch.manual_seed(4)
+    net = tactilesr_amd.tPSFNet(1.4, None).cuda()
+    nc, nt, sc = 2, 3, 4
+    N = nc * 81 * sc
+    g = torch.Generator().manual_seed(5)
+    LR_raw = torch.rand(N, 3, 4, 4, generator=g) * 800
+    depth = (torch.rand(N, 100, 100, generator=g) > 0.7).float()
+    out = S.synthesize_seqs(net, LR_raw, depth, n_contacts=nc, n_trans=nt, sample_cnt=sc, batch_size=7)
+    assert (len(out["train"]), len(out["validation"]), len(out["test"])) == (nc * 1 * sc, nc * sc, nc * sc)
+    it = {"train": 0, "validation": 0, "test": 0}
+    with torch.no_grad():
+        for c in range(nc):
+            for t in range(nt):
+                for s in range(sc):
+                    taps = [sc - 1 + sc * (r + t * 9) + sc * 81 * c for r in range(6)] + [s + sc * (6 + t * 9) + sc * 81 * c]
+                    lr = [LR_raw[i] / 100 for i in taps]                                  # 0, 5, ..., 30 degrees
+                    HR, _, _, _ = net(lr[6].unsqueeze(0).cuda(), depth[taps[6]].view(1, 1, 100, 100).cuda())
+                    split = "validation" if t == 1 else ("test" if t == 0 else "train")
+                    e = out[split][it[split]][0]
+                    it[split] += 1
+                    assert set(e) == {"LR", "depth", "HR"} and e["LR"].shape == (21, 4, 4)
+                    assert torch.equal(e["LR"], torch.cat(lr[::-1], dim=0))               # newest first
+                    assert torch.equal(e["depth"], depth[taps[6]].unsqueeze(0))
+                    assert torch.equal(e["HR"], HR[0].cpu())
+    path = os.path.join(tmp_path, "SRdataset_train_32.npy")
+    S.save_seqs_dataset(path, out["train"])
+    ds = np.load(path, allow_pickle=True)
+    assert len(ds) == len(out["train"]) and np.ascontiguousarray(ds[1].item()["LR"]).shape == (21, 4, 4)
+    assert np.ascontiguousarray(ds[1].item()["HR"]).shape == (1, 100, 100)

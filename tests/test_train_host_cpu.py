@@ -334,3 +334,21 @@ def test_config_default_carries_the_reference_keys_and_values():
         from tactilesr_amd._lib import TactileSRHipError
         with pytest.raises(TactileSRHipError):
             D.device
+
+
+def test_seqs_index_table_follows_the_reference_arithmetic():
+    """data/SeqsDataset/seqsDepth2Tactile.py:50-56: taps 0..25 degrees use the LAST sample of their sequence, the
+    30-degree tap uses seqs_idx; contact stride is 81 sequences; column order is newest (30 degrees) first."""
+    from tactilesr_amd.data.seqs_depth2tactile import seqs_index_table
+    for nc, nt, sc in ((2, 3, 4), (18, 9, 16)):
+        idx, trans = seqs_index_table(nc, nt, sc)
+        k = 0
+        for c in range(nc):
+            for t in range(nt):
+                for s in range(sc):
+                    exp = [s + sc * (6 + t * 9) + sc * 81 * c] + \
+                          [sc - 1 + sc * (r + t * 9) + sc * 81 * c for r in (5, 4, 3, 2, 1, 0)]
+                    assert idx[k].tolist() == exp and int(trans[k]) == t
+                    k += 1
+        assert k == idx.shape[0]
+    assert seqs_index_table()[0].shape == (18 * 9 * 16, 7)           # the shipped generator: 2592 items
