@@ -9,11 +9,16 @@ synthetic batch of 4096 taxel frames per GPU, inputs resident in HBM, fp32 MFMA.
 N>1: one process per GPU (torch.distributed / RCCL rendezvous); inference shards by
 sample with no data-path collective ("weak" scaling, 4096 frames per GPU).
 
+`--gpus N` without a torchrun environment starts the N ranks itself (child processes, one per GPU).
+
 One JSON line on rank 0 carries the contract fields plus
   roofline     - the dominant kernel (5x5 128->128 conv, 54 % of all FLOPs), timed live
                  with HIP events on the launch stream inside the timed region;
+                 `achieved` / `frac` are ALGORITHMIC FLOP/s (direct-conv MACs x 2) against the peak of the
+                 pipe the kernel runs on; the executed-product rate (x3 for fp16x3) is `mfma_pipe_util`;
   cpu_baseline - the CPU oracle (a port of the reference's torch CPU path) on the host
-                 cores, bounded sample (config[0]: B=32), rank 0 at N=1 only.
+                 cores, bounded sample (configs[0]: B=32): the trainer STEP (train_cal_loss + backward +
+                 Adam, cpu/trainer.py:346-362) and the eval forward; rank 0 at N=1 only.
 """
 import argparse
 import json
@@ -44,6 +49,49 @@ def make_model(args):
     flop = 2 * (4 * sf) ** 2 * nw
     assert args.seqs or flop == FWD_FLOP_PER_SAMPLE
     return model, 3 * T, 4 * sf, dict(scale_factor=sf, seqsCnt=T), flop
+
+
+def spawn_ranks_if_needed(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks here, one child process per GPU, before
+    anything touches the GPU in this process (children are fresh interpreters: subprocess, never exec), wait, and
+    exit with the worst return code.  Under torchrun (WORLD_SIZE set) this is a no-op."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
+
+
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def host_cores():
+    # the GPU box exposes all host cores but a 1-GPU job's CPU share is 16 of them
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(16, avail))
 
 
 def pmc_traffic(kernel_substr):
@@ -82,6 +130,10 @@ def main():
                          "(train_cal_loss + backward + RCCL grad all-reduce + Adam), configs[3] shape")
     args = ap.parse_args()
     args.impl_given = any(x == "--impl" or x.startswith("--impl=") for x in sys.argv[1:])
+    spawn_ranks_if_needed(args)
+    if int(os.environ.get("WORLD_SIZE", "1")) != max(1, args.gpus) and "WORLD_SIZE" in os.environ:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: the launcher's world size is used",
+              file=sys.stderr)
     if args.mode == "train":
         return main_train(args)
     if args.mode == "tpsf":
@@ -162,8 +214,8 @@ def main():
         c5_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
         nprod = {"fp16x3": 3, "bf16x6": 6, "bf16x3": 3, "bf16": 1, "f32": 1}[args.impl]
         peak = PEAK_F32_MFMA if args.impl == "f32" else PEAK_BF16_MFMA
-        alg = B * c5_flop / (c5_ms * 1e-3) if ev else None       # algorithmic FLOP/s of the launch
-        achieved = alg * nprod / 1e12 if ev else None                        # MFMA FLOP/s actually executed
+        alg = B * c5_flop / (c5_ms * 1e-3) if ev else None       # algorithmic FLOP/s of the launch (SURVEY 8d)
+        executed = alg * nprod if ev else None                               # MFMA FLOP/s actually executed
         kname = ("conv_mfma_f32_kernel<5, 128" if args.impl == "f32" else
                  "conv_mfma_split16_kernel<5, 128, %d, false, %s" % ({"fp16x3": 2, "bf16x6": 3, "bf16x3": 2, "bf16": 1}[args.impl],
                                                                      "true" if args.impl == "fp16x3" else "false"))
@@ -182,17 +234,22 @@ def main():
                        if args.seqs else
                        ("tactileSR_model eval forward 4x4->40x40, batch=%d/GPU, fp32 in/out (BASELINE configs[1])" % B),
                        "batch_per_gpu": B, "scale_factor": model.scale_factor, "seqsCnt": model.seqsCnt,
-                       "parallelism": f"replicas x{world}", "conv_impl": args.impl, "fwd_GFLOP_per_sample": round(fwd_flop / 1e9, 3)},
+                       "parallelism": f"replicas x{world}", "conv_impl": args.impl, "fwd_GFLOP_per_sample": round(fwd_flop / 1e9, 3),
+                       "dist_world_size": dist.get_world_size() if world > 1 else 1,
+                       "dist_backend": ("rccl(nccl)" if dist.get_backend() == "nccl" else dist.get_backend()) if world > 1 else None},
             "roofline": {"bound": "mfma", "kernel": kname + "> (5x5 128->128 conv+BN+ReLU, 54% of all FLOPs)",
-                         "achieved": round(achieved, 2) if achieved else None, "peak": peak / 1e12,
-                         "unit": "TFLOP/s", "frac": round(achieved * 1e12 / peak, 4) if achieved else None,
+                         "achieved": round(alg / 1e12, 2) if alg else None, "peak": peak / 1e12,
+                         "unit": "TFLOP/s", "frac": round(alg / peak, 4) if alg else None,
+                         "algorithmic_flop_per_launch": B * c5_flop,
                          "mfma_products_per_mac": nprod,
-                         "algorithmic_tflops": round(alg / 1e12, 2) if alg else None,
+                         "executed_tflops": round(executed / 1e12, 2) if executed else None,
+                         "mfma_pipe_util": round(executed / peak, 4) if executed else None,
                          "algorithmic_vs_f32_mfma_peak": round(alg / PEAK_F32_MFMA, 4) if alg else None,
                          "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": B * (2 * 128 * side * side * 4) + 128 * 128 * 25 * 4,
                          "avg_launch_ms": round(c5_ms, 3), "launches_timed": len(ev)},
             "whole_step": {"algorithmic_tflops": round(value / world * fwd_flop / 1e12, 2),
+                           "frac_of_peak": round(value / world * fwd_flop / peak, 4),
                            "algorithmic_vs_f32_mfma_peak": round(value / world * fwd_flop / PEAK_F32_MFMA, 4),
                            "layerwise_GBps": None if args.seqs else round(value / world * LAYER_BYTES_PER_SAMPLE / 1e9, 1),
                            "ms_per_step_by_kernel": per_kernel},
@@ -210,7 +267,7 @@ def main():
 def main_train(args):
     """One step = Trainer_tactileSR.train_cal_loss + zero_grad/backward/Adam (reference
     train/tactileSR_train.py:41-51, cpu/trainer.py:346-362) on a per-GPU shard of `--batch` frames;
-    N>1 adds the bucketed RCCL all-reduce of the 18.33 MB gradient (tactilesr_amd.ddp)."""
+    N>1 adds the bucketed RCCL all-reduce of the 18.33 MB gradient, issued from inside backward (tactilesr_amd.ddp)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -229,14 +286,15 @@ def main_train(args):
     model, cin_lr, side, cfg_over, fwd_flop = make_model(args)
     model = model.to(dev).train()
     opt = optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-2)
-    sync = ddp.GradSync(model.parameters(), n_buckets=4) if world > 1 else None
+    sync = ddp.GradSync(model) if world > 1 else None
     if sync:
         sync.broadcast_parameters(0)
     B = args.batch if args.batch != 4096 else (256 if args.seqs else 2048)
-    g = torch.Generator().manual_seed(42 + rank)
+    g = torch.Generator().manual_seed(42 + rank)          # per-rank data seed
     batch = ((torch.rand(B, cin_lr, 4, 4, generator=g) * 8).to(dev), (torch.rand(B, 1, 100, 100, generator=g) * 250).to(dev))
     conf = TR.default_config()
     conf.update(cfg_over)
+    eng = model.train_engine()
 
     def barrier():
         if world > 1:
@@ -246,11 +304,13 @@ def main_train(args):
     for _ in range(args.warmup):
         TR.train_one_iter(model, opt, batch, conf, sync)
     barrier()
+    eng.profile = {}             # HIP-event brackets per launch family inside the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ld = TR.train_one_iter(model, opt, batch, conf, sync)
     barrier()
     dt = time.perf_counter() - t0
+    prof, eng.profile = eng.profile, None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -262,7 +322,18 @@ def main_train(args):
                        "bf16": (1, PEAK_BF16_MFMA)}.get(impl, (1, PEAK_F32_MFMA))
         # fwd + dgrad + wgrad, minus the dgrad of the T+1 stem convs (3->64, 3x3) whose input needs no gradient
         train_flop = 3 * fwd_flop - (model.seqsCnt + 1) * 2 * side * side * 27 * 64
-        print(json.dumps({
+        # dominant kernel of the step: the 5x5 128->128 weight-gradient launches (6 per step)
+        wg = prof.get(("wgrad", 5, 128, 128), [])
+        wg_ms = sum(a.elapsed_time(b) for a, b in wg) / max(1, len(wg))
+        wg_flop = B * 2 * side * side * 128 * 128 * 25
+        wg_alg = wg_flop / (wg_ms * 1e-3) if wg else None
+        fam = {}
+        for k, v in prof.items():
+            fam.setdefault(k[0], 0.0)
+            fam[k[0]] += sum(a.elapsed_time(b) for a, b in v) / args.steps
+        wname = "wgrad_mfma_bf16s_kernel<5" if impl != "f32" else "wgrad_mfma_f32_kernel<5"
+        traffic, traffic_src = pmc_traffic(wname) if B == 2048 and not args.seqs else (None, None)
+        res = {
             "metric": "SR train samples/sec (4x4->%dx%d)" % (side, side), "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -271,21 +342,59 @@ def main_train(args):
                       "bf16": "bf16 conv operands, fp32 accumulate / params / activations (reduced precision)"}.get(impl, "f32"),
             "data": "synthetic",
             "config": {"workload": ("tactileSRSeqs (T=8, 100x100) " if args.seqs else "TactileSR ") +
-                       "train step (fwd+bwd+Adam L2), fp32 params/activations, batch/GPU=%d (BASELINE configs[%d] shape)" % (B, 4 if args.seqs else 3),
+                       "train step (train_cal_loss + backward + Adam L2), fp32 params/activations, batch/GPU=%d "
+                       "(BASELINE configs[%s])" % (B, "4] shape" if args.seqs else
+                                                   ("3] per-GPU batch" if B == 8192 else "3] is 8192/GPU: pass --batch 8192")),
                        "batch_per_gpu": B, "parallelism": f"dp{world}",
-                       "grad_allreduce_MB": round(sum(p.numel() for p in model.parameters()) * 4 / 1e6, 2), "conv_impl": impl,
-                       "train_GFLOP_per_sample": round(train_flop / 1e9, 3)},
-            "roofline": {"bound": "mfma", "achieved": round(value / world * train_flop * nprod / 1e12, 2),
-                         "peak": peak / 1e12, "unit": "TFLOP/s",
-                         "frac": round(value / world * train_flop * nprod / peak, 4), "mfma_products_per_mac": nprod,
-                         "algorithmic_tflops": round(value / world * train_flop / 1e12, 2),
-                         "algorithmic_vs_f32_mfma_peak": round(value / world * train_flop / PEAK_F32_MFMA, 4),
-                         "traffic": None, "kernel": "whole train step (%.1f GFLOP/sample algorithmic)" % (train_flop / 1e9)},
+                       "grad_allreduce_MB": round(sum(p.numel() for p in model.parameters()) * 4 / 1e6, 2),
+                       "grad_buckets": len(eng.arena.buckets) if eng.arena is not None else None,
+                       "dist_world_size": dist.get_world_size() if world > 1 else 1,
+                       "dist_backend": ("rccl(nccl)" if dist.get_backend() == "nccl" else dist.get_backend()) if world > 1 else None,
+                       "conv_impl": impl, "train_GFLOP_per_sample": round(train_flop / 1e9, 3)},
+            "roofline": {"bound": "mfma", "kernel": wname + ",...> (weight gradient of the 5x5 128->128 convs, 6 launches/step)",
+                         "achieved": round(wg_alg / 1e12, 2) if wg_alg else None, "peak": peak / 1e12, "unit": "TFLOP/s",
+                         "frac": round(wg_alg / peak, 4) if wg_alg else None,
+                         "algorithmic_flop_per_launch": wg_flop, "mfma_products_per_mac": nprod,
+                         "mfma_pipe_util": round(wg_alg * nprod / peak, 4) if wg_alg else None,
+                         "avg_launch_ms": round(wg_ms, 3), "launches_timed": len(wg),
+                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": B * (2 * 128 * side * side * 4) + 128 * 128 * 25 * 4},
+            "whole_step": {"algorithmic_tflops": round(value / world * train_flop / 1e12, 2),
+                           "frac_of_peak": round(value / world * train_flop / peak, 4),
+                           "mfma_pipe_util": round(value / world * train_flop * nprod / peak, 4),
+                           "algorithmic_vs_f32_mfma_peak": round(value / world * train_flop / PEAK_F32_MFMA, 4),
+                           "ms_per_step_by_family": {k: round(v, 2) for k, v in sorted(fam.items())}},
             "loss": float(ld["total_loss"]),
-        }), flush=True)
+        }
+        if world == 1 and not args.no_cpu_baseline and not args.seqs:
+            res["cpu_baseline"] = cpu_train_baseline()
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_train_baseline(steps=3):
+    """BASELINE configs[0]: the reference trainer's step (train_cal_loss + zero_grad/backward/Adam-L2,
+    train/tactileSR_train.py:41-51, cpu/trainer.py:346-362) as the CPU oracle restates it, B=32 fp32, on the host cores."""
+    from oracle import tactilesr_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sd = O.random_state_dict(O.tactilesr_state_shapes(), 42)
+    g = torch.Generator().manual_seed(42)
+    LR, HR = torch.rand(32, 3, 4, 4, generator=g) * 8, torch.rand(32, 1, 100, 100, generator=g) * 250
+    state = {}
+    O.train_one_iter(sd, state, 1, LR, HR)          # warm-up
+    ts = []
+    for i in range(steps):
+        t0 = time.perf_counter()
+        O.train_one_iter(sd, state, i + 2, LR, HR)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return {"value": round(32 / ts[len(ts) // 2], 2), "unit": "samples/s", "cores": torch.get_num_threads(),
+            "cpu_model": cpu_model_string(), "kind": "port",
+            "sample": "oracle trainer step (train_cal_loss + backward + Adam L2), B=32 fp32, median of %d "
+                      "(BASELINE configs[0])" % steps}
 
 
 def tpsf_traffic(B):
@@ -374,23 +483,42 @@ def main_tpsf(args):
                          "algorithmic_bytes_per_launch": B * fwd_bytes,
                          "kernel": "tpsf_fwd_mfma_kernel (+ the MLP launches: forward-only rate x %d algorithmic bytes/sample)" % fwd_bytes},
             "loss": float(loss.detach()),
+            **({"cpu_baseline": cpu_tpsf_baseline()} if world == 1 and not args.no_cpu_baseline else {}),
         }), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline_and_psnr(model, dev):
-    """Oracle (port of the reference's CPU path) timed on the host cores on a bounded
-    sample -- BASELINE configs[0]: eval forward, B=32 fp32 -- and used as the checker for
-    'PSNR vs ref' of the HIP output on the same frames."""
+def cpu_tpsf_baseline(n=32):
+    """Trainer_tPSF.train_cal_loss + backward (train/tPSFNet_train.py:180-190) as the CPU oracle restates the
+    reference's per-sample python loop, on a bounded sample of the same synthetic workload."""
     from oracle import tactilesr_oracle as O
-    # the GPU box exposes all host cores but a 1-GPU job's CPU share is 16 of them
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(16, avail))
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sd = O.random_state_dict(O.tpsf_state_shapes(), 42)
+    g = torch.Generator().manual_seed(42)
+    LR, depth = torch.rand(n, 3, 4, 4, generator=g) * 800, torch.rand(n, 100, 100, generator=g) * 10
+    geom = O.tpsf_geometry()
+    ts = []
+    for _ in range(3):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        t0 = time.perf_counter()
+        loss = O.tpsf_train_cal_loss(leaves, LR, depth, geom=geom)
+        torch.autograd.grad(loss, list(leaves.values()))
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return {"value": round(n / ts[1], 2), "unit": "samples/s", "cores": torch.get_num_threads(),
+            "cpu_model": cpu_model_string(), "kind": "port",
+            "sample": "oracle tPSFNet train_cal_loss + backward (per-sample direct 99x99 conv), B=%d fp32, median of 3" % n}
+
+
+def cpu_baseline_and_psnr(model, dev):
+    """Oracle (port of the reference's CPU path) timed on the host cores on a bounded sample, B=32 fp32: the eval
+    forward (the CPU counterpart of the headline metric) and, under `train_step`, BASELINE configs[0] proper -- the
+    reference trainer's step; the oracle is also the checker for 'PSNR vs ref' of the HIP output on the same frames."""
+    from oracle import tactilesr_oracle as O
+    cores = host_cores()
     torch.set_num_threads(cores)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(42)
@@ -408,9 +536,12 @@ def cpu_baseline_and_psnr(model, dev):
     err = float((y - ref).abs().max() / ref.abs().max())
     psnr = [float(O.calculation_psnr(y[i, 0], ref[i, 0], 250.0 / 10)) for i in range(y.shape[0])
             if float(((y[i] - ref[i]) ** 2).sum()) > 0]
+    step = cpu_train_baseline()
     return {
         "cpu_baseline": {"value": round(32 / med, 2), "unit": "samples/s", "cores": torch.get_num_threads(),
-                         "kind": "port", "sample": "oracle eval forward, B=32 fp32, median of 5 (BASELINE configs[0])"},
+                         "cpu_model": cpu_model_string(), "kind": "port",
+                         "sample": "oracle eval forward, B=32 fp32, median of 5 (the CPU counterpart of this metric)",
+                         "train_step": step},
         "parity": {"max_rel_err_vs_oracle": err, "psnr_vs_ref_db_min": round(min(psnr), 2) if psnr else None,
                    "frames": 32},
     }

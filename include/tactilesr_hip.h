@@ -225,7 +225,7 @@ typedef struct tsr_adam_chunk {
   float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
   int n; int reserved;
 } tsr_adam_chunk;
-int tsr_adam_l2_multi(const tsr_adam_chunk* chunks, int n_chunks, float lr, float beta1, float beta2, float eps,
+int tsr_adam_l2_multi(const tsr_adam_chunk* chunks, int n_chunks, float lr, double beta1, double beta2, float eps,
                       float weight_decay, int step, void* stream);
 
 /* Per-sample PSNR / SSIM of eval_func (train/tactileSR_train.py:87-94, utility/tools.py:49-81) for B samples

@@ -48,7 +48,7 @@ SIGNATURES = {
     "tsr_target_prep": [_P, _P, _F, _I, _I, _I, _I, _I, _P],
     "tsr_mse_fwd_bwd": [_P, _P, _P, _P, _L, _F, _P, _P],
     "tsr_adam_l2_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
-    "tsr_adam_l2_multi": [_P, _I, _F, _F, _F, _F, _F, _I, _P],
+    "tsr_adam_l2_multi": [_P, _I, _F, c_double, c_double, _F, _F, _I, _P],
     "tsr_psnr_ssim": [_P, _P, _I, _I, c_double, c_double, c_double, c_double, _P, _P, _P],
     "tpsf_forward": [_P, _P, _P, _P, _P, _I, _P],
     "tpsf_backward": [_P, _P, _P, _P, _I, _P],

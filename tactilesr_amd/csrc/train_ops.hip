@@ -493,13 +493,13 @@ extern "C" int tsr_mse_fwd_bwd(const float* y, const float* target, float* dy, f
 //   p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 // ------------------------------------------------------------------------------------------
 __global__ void adam_l2_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                               float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
-                               float bc1, float bc2_sqrt) {
+                               float* __restrict__ v, size_t n, float lr, float b1, float b2, float omb1, float omb2,
+                               float eps, float wd, float bc1, float bc2_sqrt) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float w = p[i];
     const float gg = fmaf(wd, w, g[i]);
-    const float mm = b1 * m[i] + (1.f - b1) * gg;
-    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    const float mm = b1 * m[i] + omb1 * gg;
+    const float vv = b2 * v[i] + omb2 * gg * gg;
     m[i] = mm;
     v[i] = vv;
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
@@ -515,22 +515,22 @@ extern "C" int tsr_adam_l2_step(float* param, const float* grad, float* exp_avg,
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const size_t g = ((size_t)n + 255) / 256;
   hipLaunchKernelGGL(adam_l2_kernel, dim3(g > 4096 ? 4096 : (int)g), dim3(256), 0, (hipStream_t)stream, param, grad,
-                     exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay, (float)bc1,
-                     (float)sqrt(bc2));
+                     exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, (float)(1.0 - (double)beta1),
+                     (float)(1.0 - (double)beta2), eps, weight_decay, (float)bc1, (float)sqrt(bc2));
   return tsr_check_launch();
 }
 
 // One launch for all parameter tensors: block b owns chunk record b (<= 4096 contiguous elements of one tensor).
 // 16-B accesses when the four pointers are 16-B aligned (torch allocations and the gradient arena are).
 __global__ __launch_bounds__(256) void adam_l2_multi_kernel(const tsr_adam_chunk* __restrict__ chunks, float lr,
-                                                            float b1, float b2, float eps, float wd, float bc1,
-                                                            float bc2_sqrt) {
+                                                            float b1, float b2, float omb1, float omb2, float eps,
+                                                            float wd, float bc1, float bc2_sqrt) {
   const tsr_adam_chunk c = chunks[blockIdx.x];
   const float step_size = lr / bc1;
   auto upd = [&](float w, float g, float& m, float& v) {
     const float gg = fmaf(wd, w, g);
-    m = b1 * m + (1.f - b1) * gg;
-    v = b2 * v + (1.f - b2) * gg * gg;
+    m = b1 * m + omb1 * gg;
+    v = b2 * v + omb2 * gg * gg;
     return w - step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
   };
   const bool vec = ((((size_t)c.param | (size_t)c.grad | (size_t)c.exp_avg | (size_t)c.exp_avg_sq) & 15) == 0);
@@ -557,13 +557,16 @@ __global__ __launch_bounds__(256) void adam_l2_multi_kernel(const tsr_adam_chunk
   }
 }
 
-extern "C" int tsr_adam_l2_multi(const tsr_adam_chunk* chunks, int n_chunks, float lr, float beta1, float beta2,
+extern "C" int tsr_adam_l2_multi(const tsr_adam_chunk* chunks, int n_chunks, float lr, double beta1, double beta2,
                                  float eps, float weight_decay, int step, void* stream) {
   if (!chunks || n_chunks <= 0 || step <= 0) return TSR_ERR_ARG;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adam_l2_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, chunks, lr, beta1,
-                     beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
+  // betas arrive as doubles and every derived constant is formed in double like torch does on the host:
+  // (1.f - 0.999f) is 1.3e-5 off 0.001
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(adam_l2_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, chunks, lr, (float)beta1,
+                     (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay, (float)bc1,
+                     (float)sqrt(bc2));
   return tsr_check_launch();
 }
 

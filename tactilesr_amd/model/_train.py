@@ -137,6 +137,25 @@ class TrainEngine:
         self.arena = None
         self.grad_sync = None
         self.n_buckets = 8
+        self.profile = None      # bench.py: dict -> HIP-event brackets per launch family, on the launch stream
+
+    def _timed(self, key):
+        """Context manager: bracket the launches inside with two HIP events when profiling is on."""
+        eng = self
+
+        class _T:
+            def __enter__(self_):
+                self_.on = eng.profile is not None
+                if self_.on:
+                    self_.e0, self_.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    self_.e0.record()
+
+            def __exit__(self_, *exc):
+                if self_.on:
+                    self_.e1.record()
+                    eng.profile.setdefault(key, []).append((self_.e0, self_.e1))
+                return False
+        return _T()
         import os
         # conv arithmetic of the train path: 0 = fp32 MFMA, 3 = split-bf16 (six products, fp32-equivalent),
         # -2 = two scaled fp16 planes (three products; operand scales from device-side max|.| scalars),
@@ -203,9 +222,10 @@ class TrainEngine:
         w = conv.weight
         cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
         wp, wis = self._packw(c, conv)
-        conv_ex(B=c.B, H=c.H, W=c.W, src=src, w=wp, cout=cout, ks=ks, out=out, out_ctot=out_ctot,
-                out_coff=out_coff, epi_mode=1, slab=c.slab, slab_cnt=c.slab_cnt, nsplit=self.nsplit,
-                w_inv_scale=wis, out_amax=out_amax)
+        with self._timed(("fwd", ks, cout, cin)):
+            conv_ex(B=c.B, H=c.H, W=c.W, src=src, w=wp, cout=cout, ks=ks, out=out, out_ctot=out_ctot,
+                    out_coff=out_coff, epi_mode=1, slab=c.slab, slab_cnt=c.slab_cnt, nsplit=self.nsplit,
+                    w_inv_scale=wis, out_amax=out_amax)
         return self._bn_finalize(c, conv.bias, bn, c.slab, c.slab_cnt, self._entries(c, cout, ks), cout)
 
     # ------------------------------------------------------------------ forward
@@ -392,14 +412,15 @@ class TrainEngine:
         n = cout * cin * ks * ks
         slab = torch.empty(ns * n, dtype=torch.float32, device=w.device)
         bslab = torch.empty(ns * cout, dtype=torch.float32, device=w.device) if with_bias else None
-        if self.nsplit:
-            call("tsr_conv2d_wgrad_bf16s", ptr(a.buf), _I(a.ctot), _I(a.coff), _I(cin), ptr(a.scale), ptr(a.shift),
-                 ptr(dz.buf), _I(dz.ctot), _I(dz.coff), _I(cout), _I(ks), _I(self.nsplit), ptr(a.amax), ptr(dz.amax),
-                 ptr(slab), ptr(bslab), _I(ns), _I(c.B), _I(c.H), _I(c.W), stream())
-        else:
-            call("tsr_conv2d_wgrad", ptr(a.buf), _I(a.ctot), _I(a.coff), _I(cin), ptr(a.scale), ptr(a.shift),
-                 ptr(dz.buf), _I(dz.ctot), _I(dz.coff), _I(cout), _I(ks), ptr(slab), ptr(bslab), _I(ns),
-                 _I(c.B), _I(c.H), _I(c.W), stream())
+        with self._timed(("wgrad", ks, cout, cin)):
+            if self.nsplit:
+                call("tsr_conv2d_wgrad_bf16s", ptr(a.buf), _I(a.ctot), _I(a.coff), _I(cin), ptr(a.scale), ptr(a.shift),
+                     ptr(dz.buf), _I(dz.ctot), _I(dz.coff), _I(cout), _I(ks), _I(self.nsplit), ptr(a.amax),
+                     ptr(dz.amax), ptr(slab), ptr(bslab), _I(ns), _I(c.B), _I(c.H), _I(c.W), stream())
+            else:
+                call("tsr_conv2d_wgrad", ptr(a.buf), _I(a.ctot), _I(a.coff), _I(cin), ptr(a.scale), ptr(a.shift),
+                     ptr(dz.buf), _I(dz.ctot), _I(dz.coff), _I(cout), _I(ks), ptr(slab), ptr(bslab), _I(ns),
+                     _I(c.B), _I(c.H), _I(c.W), stream())
         gw = grads.dest(name + ".weight", w.shape)
         call("tsr_reduce_splits", ptr(slab), ptr(gw), _L(n), _I(ns), _F(1.0), stream())
         grads.put(name + ".weight", gw)
@@ -415,10 +436,11 @@ class TrainEngine:
         cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
         ws = c.wscale.get(id(conv), 1.0)
         wp = _pack_dgrad(w, cout, cin, ks, ci0, nprime, self.nsplit, ws)
-        conv_ex(B=c.B, H=c.H, W=c.W, src=dz, w=wp, cout=nprime, ks=ks, out=out, out_ctot=out_ctot,
-                out_coff=out_coff, res=res, epi_mode=2 if mask is not None else 0, mask=mask, bn=bn,
-                slab=c.slab if bn else None, slab_cnt=None, nsplit=self.nsplit, w_inv_scale=1.0 / ws,
-                out_amax=out_amax)
+        with self._timed(("dgrad", ks, nprime, cout)):
+            conv_ex(B=c.B, H=c.H, W=c.W, src=dz, w=wp, cout=nprime, ks=ks, out=out, out_ctot=out_ctot,
+                    out_coff=out_coff, res=res, epi_mode=2 if mask is not None else 0, mask=mask, bn=bn,
+                    slab=c.slab if bn else None, slab_cnt=None, nsplit=self.nsplit, w_inv_scale=1.0 / ws,
+                    out_amax=out_amax)
         c.last_entries = self._entries(c, nprime, ks)      # what a following _bn_bwd reduces
 
     def _bn_bwd(self, c, g_buf, g_ctot, g_coff, z: Act, zoff, C, bn_vec, bn_mod, grads, name, out_amax=None):

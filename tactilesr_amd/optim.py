@@ -84,7 +84,8 @@ class Adam(torch.optim.Optimizer):
                 by_step.setdefault(int(st["step"].item()), []).append((p, g, st))     # CPU scalar: no device sync
             for step, items in by_step.items():
                 dev, n_chunks = self._table(items)
-                call("tsr_adam_l2_multi", ptr(dev), _I(n_chunks), _F(group["lr"]), _F(b1), _F(b2), _F(group["eps"]),
+                call("tsr_adam_l2_multi", ptr(dev), _I(n_chunks), _F(group["lr"]), ctypes.c_double(b1), ctypes.c_double(b2),
+                     _F(group["eps"]),
                      _F(group["weight_decay"]), _I(step), stream())
                 self.launches += 1
         # the kernel wrote the parameters behind autograd's back: invalidate cached weight packs (TactileSR._plan)
