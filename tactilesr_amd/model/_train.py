@@ -138,6 +138,12 @@ class TrainEngine:
         self.grad_sync = None
         self.n_buckets = 8
         self.profile = None      # bench.py: dict -> HIP-event brackets per launch family, on the launch stream
+        import os
+        # conv arithmetic of the train path: 0 = fp32 MFMA, 3 = split-bf16 (six products, fp32-equivalent),
+        # -2 = two scaled fp16 planes (three products; operand scales from device-side max|.| scalars),
+        # 1 = plain bf16 operands with fp32 accumulation (reduced precision: BASELINE's "bf16" configurations only)
+        self.nsplit = {"f32": 0, "bf16x6": 3, "fp16x3": -2, "bf16": 1}[os.environ.get("TSR_TRAIN_IMPL", "fp16x3")]
+        self.f16 = self.nsplit == -2
 
     def _timed(self, key):
         """Context manager: bracket the launches inside with two HIP events when profiling is on."""
@@ -156,12 +162,6 @@ class TrainEngine:
                     eng.profile.setdefault(key, []).append((self_.e0, self_.e1))
                 return False
         return _T()
-        import os
-        # conv arithmetic of the train path: 0 = fp32 MFMA, 3 = split-bf16 (six products, fp32-equivalent),
-        # -2 = two scaled fp16 planes (three products; operand scales from device-side max|.| scalars),
-        # 1 = plain bf16 operands with fp32 accumulation (reduced precision: BASELINE's "bf16" configurations only)
-        self.nsplit = {"f32": 0, "bf16x6": 3, "fp16x3": -2, "bf16": 1}[os.environ.get("TSR_TRAIN_IMPL", "fp16x3")]
-        self.f16 = self.nsplit == -2
 
     def _mfma_convs(self):
         m = self.m
