@@ -175,6 +175,11 @@ int tsr_conv2d_wgrad_bf16s(const float* a, int a_ctot, int a_coff, int cin,
                            const float* dz, int dz_ctot, int dz_coff, int cout, int ks, int planes,
                            const float* a_amax, const float* dz_amax,
                            float* slab, float* bias_slab, int nsplit, int B, int H, int W, void* stream);
+/* Batch splits to launch tsr_conv2d_wgrad_bf16s with (slab / bias_slab hold that many partials): one resident round
+ * of workgroups for this layer shape, never more than there are (image, 4x8 patch) work items; and the number of
+ * workgroups one split launches. */
+int tsr_conv2d_wgrad_splits(int cout, int cin, int ks, int planes, int B, int H, int W);
+int tsr_conv2d_wgrad_wgs_per_split(int cout, int cin, int ks, int planes);
 int tsr_reduce_splits(const float* slab, float* out, long long n, int nsplit, float alpha, void* stream);
 
 /* nn.BatchNorm2d train mode (model/tactileSR_model.py:38,42,48,169,175,181,187), from the

@@ -37,6 +37,8 @@ SIGNATURES = {
     "tsr_pack_conv_weight_dgrad_f16s": [_P, _P, _I, _I, _I, _I, _I, _F, _P],
     "tsr_conv2d_wgrad": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P],
     "tsr_conv2d_wgrad_bf16s": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "tsr_conv2d_wgrad_splits": [_I, _I, _I, _I, _I, _I, _I],
+    "tsr_conv2d_wgrad_wgs_per_split": [_I, _I, _I, _I],
     "tsr_reduce_splits": [_P, _P, _L, _I, _F, _P],
     "tsr_bn_stats_finalize": [_P, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P],
     "tsr_cb16_stats_entries": [_I, _I],

@@ -8,6 +8,7 @@
 // every fragment one aligned, bank-conflict-free ds_read_b128.  The transpose + bf16 split happens in
 // registers while staging (8 strided float4 loads per thread-item).
 #include "tsr_common.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -306,6 +307,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_bf16s_kernel(const WgradBAr
   }
 }
 
+int tsr_conv2d_wgrad_tr16(const float* a, int a_ctot, int a_coff, int cin, const float* a_scale, const float* a_shift,
+                          const float* dz, int dz_ctot, int dz_coff, int cout, int ks, int planes,
+                          const float* a_amax, const float* dz_amax, float* slab, float* bias_slab, int nsplit,
+                          int B, int H, int W, hipStream_t st);     // wgrad_mfma_tr16.hip
+
 extern "C" int tsr_conv2d_wgrad_bf16s(const float* a, int a_ctot, int a_coff, int cin,
                                       const float* a_scale, const float* a_shift,
                                       const float* dz, int dz_ctot, int dz_coff, int cout, int ks, int planes,
@@ -321,6 +327,12 @@ extern "C" int tsr_conv2d_wgrad_bf16s(const float* a, int a_ctot, int a_coff, in
       a_coff + cin > a_ctot || dz_coff + cout > dz_ctot || (ks != 1 && ks != 3 && ks != 5))
     return TSR_ERR_ARG;
   if ((a_scale != nullptr) != (a_shift != nullptr)) return TSR_ERR_ARG;
+  // default: the transposed-LDS-read GEMM form (wgrad_mfma_tr16.hip); TSR_WGRAD_OLD=1 keeps the register-transpose
+  // kernel below for A/B measurements
+  static const bool use_old = getenv("TSR_WGRAD_OLD") != nullptr;
+  if (!use_old)
+    return tsr_conv2d_wgrad_tr16(a, a_ctot, a_coff, cin, a_scale, a_shift, dz, dz_ctot, dz_coff, cout, ks, planes, a_amax,
+                                 dz_amax, slab, bias_slab, nsplit, B, H, W, (hipStream_t)stream);
   WgradBArgs g;
   g.a = a; g.a_ctot = a_ctot; g.a_coff = a_coff; g.cin = cin; g.a_scale = a_scale; g.a_shift = a_shift;
   g.dz = dz; g.dz_ctot = dz_ctot; g.dz_coff = dz_coff; g.cout = cout;

@@ -1,0 +1,526 @@
+// Weight gradient as a plain MFMA GEMM over pixels, fed by TRANSPOSED LDS reads (gfx950 ds_read_b64_tr_b16).
+//
+//   dW[co][ci][kh][kw] = sum over (image, y, x) of dz[co][y][x] * a[ci][y+kh-P][x+kw-P]
+//
+// GEMM view per tap: M = co, N = ci, K = pixels.  The 16-bit MFMA wants 8 consecutive K (pixels) of one channel per
+// lane, but activations live channel-minor in HBM (CB16: [pixel][16 ch]).  The previous kernel transposed in registers
+// while staging (8 strided loads per thread item) and had to re-stage a row-shifted input tile per kernel row; both made
+// it staging-bound (31 % of the f16 MFMA rate).  Here tiles are staged exactly as they sit in memory -- coalesced 16-B
+// loads of whole CB16 lines, split into 16-bit planes, written [plane][16-ch block][pixel][16 ch] -- and the MFMA
+// fragments come out of LDS already transposed: one ds_read_b64_tr_b16 hands each lane 4 pixels of its channel.  A tap
+// (kh, kw) is then only an LDS address offset of the B operand: kh is folded into which 4 input rows are staged, kw is
+// an immediate +32 B per column.
+//
+// Workgroup = CO x CI output channels x the KS taps of ONE kernel row (acc: KS tiles per 32x32 wave tile), sweeping
+// (image, 4-row x 8-column patch) work items of its batch split; per item two K = 16 steps (2 rows x 8 columns each).
+// LDS is double-buffered: the next item's global loads are issued before the MFMAs of the current one and converted /
+// written after them, one barrier per item.  128 x 128 tiles (8 waves, wave = 64 co x 32 ci) stage 2x fewer bytes per
+// MFMA than the 64 x 64 x one-row workgroups of the old kernel and at a fraction of the instruction cost.
+//
+// Bank conflicts: a 16-lane group reads 4 consecutive pixels x 32 B = 128 contiguous bytes; the two groups of a
+// 32-lane half read the two 16-channel blocks of the wave's 32 channels, whose LDS regions are an odd multiple of 128 B
+// apart (pixel counts padded to 4 mod 8), i.e. complementary halves of the 64-bank row for ANY start pixel: conflict
+// free for every tap.  Staging writes are 8 B per lane, 512 contiguous bytes per wave: conflict free.
+#include "tsr_common.h"
+#include <stdlib.h>
+
+typedef __bf16 tb16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 tb16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 th16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 th16x4 __attribute__((ext_vector_type(4)));
+typedef short tv4i16 __attribute__((__vector_size__(4 * sizeof(short))));
+
+template <bool F16> struct TPlane;
+template <> struct TPlane<false> {
+  typedef __bf16 T; typedef tb16x8 V8; typedef tb16x4 V4;
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct TPlane<true> {
+  typedef _Float16 T; typedef th16x8 V8; typedef th16x4 V4;
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+struct WgradTArgs {
+  const float* a;  int a_ctot; int a_coff; int cin;
+  const float* a_scale; const float* a_shift;
+  const float* dz; int dz_ctot; int dz_coff; int cout;
+  float* slab; float* bslab;
+  int B, H, W, nsplit;
+  int tiles_x, tiles_y;                        // 8-column x 4-row patches
+  const float* a_amax; const float* dz_amax;   // fp16 form: device scalars max|a| (raw), max|dz|
+};
+
+__device__ __forceinline__ float tr16_pow2_scale(float m) {   // power of two bringing m into [2^13, 2^14); 1 for 0
+  if (!(m > 0.f)) return 1.f;
+  int e = (int)((__float_as_uint(m) >> 23) & 0xFF) - 127;
+  int be = 13 - e + 127;
+  be = be < 1 ? 1 : (be > 254 ? 254 : be);
+  return __uint_as_float((unsigned)be << 23);
+}
+
+constexpr int tr16_pad_px(int n) {     // pixel count of a block region: == 4 (mod 8) -> region stride == 128 (mod 256) B
+  int p = n;
+  while ((p & 7) != 4) ++p;
+  return p;
+}
+
+template <int KS, int KHW, int CO, int CI, int WM, int NS, bool F16>
+struct WgradTGeom {
+  static constexpr int NWM = CO / WM, NWN = CI / 32, NWAVE = NWM * NWN, NT = 64 * NWAVE;
+  static constexpr int MT = WM / 32;
+  static constexpr int NKG = (KS + KHW - 1) / KHW;          // kernel-row groups (one workgroup each)
+  static constexpr int NTAP = KHW * KS;                     // taps (accumulator tiles per 32x32 wave tile) per workgroup
+  static constexpr int ACOLS = 8 + KS - 1, AROWS = 4 + KHW - 1;
+  static constexpr int DZ_PX = 32, A_PX = AROWS * ACOLS;
+  static constexpr int DZ_BLKB = tr16_pad_px(DZ_PX) * 32, A_BLKB = tr16_pad_px(A_PX) * 32;
+  static constexpr int DZ_PLANEB = (CO / 16) * DZ_BLKB, A_PLANEB = (CI / 16) * A_BLKB;
+  static constexpr int BUFB = NS * (DZ_PLANEB + A_PLANEB);
+  static constexpr int N_DZ = DZ_PX * (CO / 16) * 4, N_A = A_PX * (CI / 16) * 4;     // float4 staging items
+  static constexpr int NIT_DZ = (N_DZ + NT - 1) / NT, NIT_A = (N_A + NT - 1) / NT;
+  static constexpr int LDSB = (2 * BUFB > 32 * CO * 4 ? 2 * BUFB : 32 * CO * 4) + CI * 8;   // + (scale, shift) table
+};
+
+template <int KS, int KHW, int CO, int CI, int WM, int NS, bool F16, bool STAGGER = true>
+__global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_tr16_kernel(const WgradTArgs g) {
+  typedef WgradTGeom<KS, KHW, CO, CI, WM, NS, F16> G;
+  typedef typename TPlane<F16>::T PT;
+  typedef typename TPlane<F16>::V8 PV8;
+  typedef typename TPlane<F16>::V4 PV4;
+  typedef __attribute__((address_space(3))) tv4i16* lds_v4;
+  constexpr int P = KS / 2;
+  constexpr int NT = G::NT, MT = G::MT;
+  constexpr int NPROD = NS == 3 ? 6 : (NS == 2 ? 3 : 1);
+  // products ordered small -> large (plane 0 = most significant)
+  constexpr int PA[6] = {NS == 3 ? 2 : (NS == 2 ? 1 : 0), 0, NS == 3 ? 1 : 0, 1, 0, 0};
+  constexpr int PB[6] = {0, NS == 3 ? 2 : (NS == 2 ? 1 : 0), NS == 3 ? 1 : 0, 0, 1, 0};
+
+  __shared__ __attribute__((aligned(16))) char lds[G::LDSB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / G::NWN, wn = wave - wm * G::NWN;
+  const int h = lane >> 5, li = lane & 31;
+
+  const int nci = g.cin / CI, nco = g.cout / CO;
+  // XCD-aware block order (speed only): the dispatcher deals blocks round-robin over the 8 XCDs; remap so that each XCD
+  // runs a contiguous range of logical ids -- the KS kernel-row workgroups (and channel tiles) of one batch split read
+  // the same dz / input pixels at the same time and now share one L2 instead of fetching them into five.
+  int bid;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int cib = bid % nci; bid /= nci;
+  const int cob = bid % nco; bid /= nco;
+  const int kg = bid % G::NKG;          // kernel-row group: rows kh0 .. kh0 + KHW - 1 (the last group may be short)
+  const int sp = bid / G::NKG;
+  const int kh0 = kg * KHW;
+
+  const int HW = g.H * g.W;
+  const int a_blocks = g.a_ctot >> 4, dz_blocks = g.dz_ctot >> 4;
+  const int a_c0 = g.a_coff + cib * CI, dz_c0 = g.dz_coff + cob * CO;
+  const bool do_bias = g.bslab && cib == 0 && kg == 0;
+
+  // fp16 planes: power-of-two scales of both operands (input: bound of the fused transform), undone at the end
+  float s_a = 1.f, s_d = 1.f;
+  if (F16) {
+    float ma = g.a_amax ? *g.a_amax : 0.f;
+    if (g.a_scale) {
+      float* bnd = (float*)lds;
+      float ms = 0.f, mt = 0.f;
+      for (int c = tid; c < CI; c += NT) {
+        ms = fmaxf(ms, fabsf(g.a_scale[cib * CI + c]));
+        mt = fmaxf(mt, fabsf(g.a_shift[cib * CI + c]));
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        ms = fmaxf(ms, __shfl_xor(ms, o));
+        mt = fmaxf(mt, __shfl_xor(mt, o));
+      }
+      if (lane == 0) { bnd[wave * 2] = ms; bnd[wave * 2 + 1] = mt; }
+      __syncthreads();
+      ms = 0.f; mt = 0.f;
+      for (int w = 0; w < G::NWAVE; ++w) { ms = fmaxf(ms, bnd[w * 2]); mt = fmaxf(mt, bnd[w * 2 + 1]); }
+      __syncthreads();
+      ma = ma * ms + mt;
+    }
+    s_a = tr16_pow2_scale(ma);
+    s_d = tr16_pow2_scale(g.dz_amax ? *g.dz_amax : 0.f);
+  }
+
+  f32x16 acc[MT][G::NTAP];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int k = 0; k < G::NTAP; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][k][r] = 0.f;
+
+  // ---- staging roles: item i -> (quad = i & 3, pixel, block); consecutive threads walk a CB16 line, then the row
+  float bsum[G::NIT_DZ][4];
+#pragma unroll
+  for (int j = 0; j < G::NIT_DZ; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bsum[j][q] = 0.f;
+
+  // work items of this split: a contiguous range of (image, patch row, patch column), walked with counters (no
+  // division in the loop; the launcher guarantees B * patches < 2^31)
+  const int tpi = g.tiles_x * g.tiles_y;
+  const int total_items = g.B * tpi;
+  const int per = (total_items + g.nsplit - 1) / g.nsplit;
+  const int it0 = sp * per;
+  const int it1 = it0 + per < total_items ? it0 + per : total_items;
+  int nb = it0 / tpi, nty = (it0 - nb * tpi) / g.tiles_x, ntx = it0 - nb * tpi - nty * g.tiles_x;   // next item to LOAD
+
+  // Per-thread staging constants (invariant over work items): element offset of each slot relative to the item's
+  // (image, y0, x0) corner -- that corner is workgroup-uniform, so the per-item address is a scalar base + a 32-bit
+  // VGPR offset -- and its (row, column) for the bounds tests.  Loads are BRANCH-FREE: an out-of-image slot reads its
+  // block's corner pixel instead (always valid) and is zeroed by a select when it is stored (a conditional load makes
+  // hipcc branch around every load and drain vmcnt per slot).
+  int offd[G::NIT_DZ], safed[G::NIT_DZ], offa[G::NIT_A], safea[G::NIT_A], rcd[G::NIT_DZ], rca[G::NIT_A], ldsd[G::NIT_DZ], ldsa[G::NIT_A];
+#pragma unroll
+  for (int j = 0; j < G::NIT_DZ; ++j) {
+    const int i = (tid + j * NT) % G::N_DZ;          // (tail threads of a partial pass mirror an early item; masked)
+    const int q = i & 3, px = (i >> 2) & 31, blk = i >> 7;
+    safed[j] = blk * HW * 16 + q * 4;
+    offd[j] = safed[j] + ((px >> 3) * g.W + (px & 7)) * 16;
+    rcd[j] = ((px >> 3) << 8) | (px & 7);
+    ldsd[j] = blk * G::DZ_BLKB + px * 32 + q * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < G::NIT_A; ++j) {
+    const int i = (tid + j * NT) % G::N_A;
+    const int q = i & 3, pi = i >> 2;
+    const int px = pi % G::A_PX, blk = pi / G::A_PX;
+    const int r = px / G::ACOLS, cx = px - r * G::ACOLS;
+    safea[j] = blk * HW * 16 + q * 4;
+    offa[j] = safea[j] + ((r + kh0 - P) * g.W + cx - P) * 16;
+    rca[j] = (r << 8) | cx;
+    ldsa[j] = blk * G::A_BLKB + px * 32 + q * 8;
+  }
+  // the fused input transform's per-channel (scale, shift) of this workgroup's CI channels, kept in LDS
+  float* tsc = (float*)(lds + 2 * G::BUFB);
+  if (g.a_scale) {
+    for (int c = tid; c < CI; c += NT) {
+      tsc[c] = g.a_scale[cib * CI + c];
+      tsc[CI + c] = g.a_shift[cib * CI + c];
+    }
+  }
+
+  f32x4 hd[G::NIT_DZ], ha[G::NIT_A];
+  unsigned okd = 0, oka = 0;
+
+  auto load_item = [&]() {
+    const int b = nb, y0 = nty * 4, x0 = ntx * 8;
+    if (++ntx == g.tiles_x) {
+      ntx = 0;
+      if (++nty == g.tiles_y) { nty = 0; ++nb; }
+    }
+    const float* dzb = g.dz + (((size_t)b * dz_blocks + (dz_c0 >> 4)) * HW + y0 * g.W + x0) * 16;
+    const float* ab = g.a + (((size_t)b * a_blocks + (a_c0 >> 4)) * HW + y0 * g.W + x0) * 16;
+    okd = oka = 0;
+#pragma unroll
+    for (int j = 0; j < G::NIT_DZ; ++j) {
+      const bool ok = (y0 + (rcd[j] >> 8) < g.H) & (x0 + (rcd[j] & 255) < g.W);
+      hd[j] = *(const f32x4*)(dzb + (ok ? offd[j] : safed[j]));
+      okd |= (unsigned)ok << j;
+    }
+#pragma unroll
+    for (int j = 0; j < G::NIT_A; ++j) {
+      const int gy = y0 + (rca[j] >> 8) + kh0 - P, gx = x0 + (rca[j] & 255) - P;
+      const bool ok = (gy >= 0) & (gy < g.H) & (gx >= 0) & (gx < g.W);
+      ha[j] = *(const f32x4*)(ab + (ok ? offa[j] : safea[j]));
+      oka |= (unsigned)ok << j;
+    }
+  };
+
+  auto split_store = [&](f32x4 v, char* dst, int plane_stride, float sc) {
+    if (F16) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] *= sc;
+    }
+#pragma unroll
+    for (int p = 0; p < NS; ++p) {
+      PV4 qv;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        qv[c] = (PT)v[c];
+        v[c] -= (float)qv[c];
+      }
+      *(PV4*)(dst + p * plane_stride) = qv;
+    }
+  };
+
+  auto store_item = [&](int buf) {
+    char* dzt = lds + buf * G::BUFB;
+    char* at = dzt + NS * G::DZ_PLANEB;
+#pragma unroll
+    for (int j = 0; j < G::NIT_DZ; ++j) {
+      if ((j + 1) * NT <= G::N_DZ || tid + j * NT < G::N_DZ) {
+        f32x4 v = hd[j];
+        const float keep = ((okd >> j) & 1) ? 1.f : 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] *= keep;
+        if (do_bias) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) bsum[j][c] += v[c];
+        }
+        split_store(v, dzt + ldsd[j], G::DZ_PLANEB, s_d);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < G::NIT_A; ++j) {
+      if ((j + 1) * NT <= G::N_A || tid + j * NT < G::N_A) {
+        f32x4 v = ha[j];
+        if (g.a_scale) {      // producer's train-mode BN + ReLU, fused into the load (in-image pixels only)
+          const int cq = ((ldsa[j] / G::A_BLKB) * 16) + ((ldsa[j] >> 1) & 12);
+          const f32x4 sc = *(const f32x4*)(tsc + cq), sh = *(const f32x4*)(tsc + CI + cq);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = fmaxf(fmaf(v[c], sc[c], sh[c]), 0.f);
+        }
+        const float keep = ((oka >> j) & 1) ? 1.f : 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] *= keep;
+        split_store(v, at + ldsa[j], G::A_PLANEB, s_a);
+      }
+    }
+  };
+
+  // ---- fragment addressing (ds_read_b64_tr_b16): lane = 16*G4 + 4*q + p supplies the address of pixel-row q,
+  // channels 4p..4p+3 of its 16-channel block; it receives 4 pixels of channel (lane & 15) of that block
+  const int g4 = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  // dz (A operand), co tile m: blocks 2*(wm*MT+m) + (g4&1); K half h = g4>>1 -> patch row 2s+h; read rd -> cols 4rd..
+  const int a_lane = ((wm * MT) * 2 + (g4 & 1)) * G::DZ_BLKB + ((g4 >> 1) * 8 + tq) * 32 + tp * 8;
+  const int b_lane = (wn * 2 + (g4 & 1)) * G::A_BLKB + ((g4 >> 1) * G::ACOLS + tq) * 32 + tp * 8;   // + row, + kw
+
+  // One (K step, tap) = NPROD x MT MFMAs.  B fragments are ping-pong prefetched one tap ahead and the prefetch reads are
+  // interleaved with the running tap's MFMAs (left alone, hipcc hoists every tap's reads to the top of the item:
+  // 40 more live registers and spills at 128 x 128 x 5 taps).
+  auto mma_item = [&](int buf, auto&& between_steps) {
+    const char* dzt = lds + buf * G::BUFB;
+    const char* at = dzt + NS * G::DZ_PLANEB;
+    auto load_b = [&](PV8* bf, int s, int tap) {
+      const int khl = tap / KS, kw = tap - khl * KS;
+#pragma unroll
+      for (int p = 0; p < NS; ++p) {
+        const char* base = at + p * G::A_PLANEB + b_lane + (2 * s + khl) * (G::ACOLS * 32) + kw * 32;
+        const tv4i16 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base));
+        const tv4i16 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base + 4 * 32));
+        bf[p] = __builtin_shufflevector(__builtin_bit_cast(PV4, r0), __builtin_bit_cast(PV4, r1), 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    };
+    auto load_a = [&](PV8 (*af)[NS], int s) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int p = 0; p < NS; ++p) {
+          const char* base = dzt + p * G::DZ_PLANEB + a_lane + m * 2 * G::DZ_BLKB + s * (16 * 32);
+          const tv4i16 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base));
+          const tv4i16 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base + 4 * 32));
+          af[m][p] = __builtin_shufflevector(__builtin_bit_cast(PV4, r0), __builtin_bit_cast(PV4, r1), 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    };
+    PV8 af[MT][NS], bf[2][NS];
+    load_a(af, 0);
+    load_b(bf[0], 0, 0);
+    constexpr int NU = 2 * G::NTAP;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int s = u / G::NTAP, tap = u - s * G::NTAP;
+      const int cb = u & 1;
+      const bool seam = tap == G::NTAP - 1 && s == 0;       // the staging block sits between the two K steps
+#ifdef TSR_ABL_WG_NOBREAD
+      if (u == 0) load_b(bf[1], 0, 1);
+#else
+      if (u + 1 < NU && !seam) load_b(bf[cb ^ 1], (u + 1) / G::NTAP, (u + 1) % G::NTAP);
+#endif
+      // (a short last row group computes its missing rows on zero-weighted garbage-free data: the rows exist in the
+      // staged tile, their products are simply not written out)
+#pragma unroll
+      for (int t = 0; t < NPROD; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[m][tap] = TPlane<F16>::mfma(af[m][PA[6 - NPROD + t]], bf[cb][PB[6 - NPROD + t]], acc[m][tap]);
+#ifndef TSR_ABL_WG_NOFENCE
+      if (u + 1 < NU && !seam) {
+        constexpr int NRD = 2 * NS, NMF = NPROD * MT, PER = NMF / NRD > 0 ? NMF / NRD : 1;
+#pragma unroll
+        for (int i = 0; i < NRD; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      if (seam) {       // no fragment is prefetched across the staging block: its registers are needed there
+        between_steps();
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(af, 1);
+#ifndef TSR_ABL_WG_NOBREAD
+        load_b(bf[cb ^ 1], 1, 0);
+#endif
+      }
+    }
+  };
+
+  __syncthreads();                         // tsc published (and the scale-bound scratch is free)
+  // Per item: [issue next item's global loads | MFMAs of K step 0 | convert + write the next item into the other
+  // buffer | MFMAs of K step 1 | barrier].  The two waves of a SIMD (w and w + NWAVE/2) run the same code; the second
+  // half carries a static s_setprio 1, so it wins the matrix pipe whenever both want it and the pair falls half a
+  // phase apart: while one converts (VALU, LDS writes) its partner's MFMAs have the pipe, instead of both alternating
+  // between an MFMA-only and a VALU-only phase in lockstep.  (A role split with two code paths costs registers the
+  // 10-tile kernels do not have: 57 spills.)
+  if (STAGGER && __builtin_amdgcn_readfirstlane(wave) >= G::NWAVE / 2) __builtin_amdgcn_s_setprio(1);
+  if (it0 < it1) {
+    load_item();
+    store_item(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int item = it0; item < it1; ++item) {
+    const bool more = item + 1 < it1;
+#ifndef TSR_ABL_WG_NOLOAD
+    if (more) load_item();               // global loads fly under K step 0 (issuing them a whole item ahead: no gain)
+#endif
+#ifndef TSR_ABL_WG_NOMMA
+    mma_item(cur, [&]() {
+#endif
+#ifndef TSR_ABL_WG_NOSTORE
+      if (more) store_item(cur ^ 1);     // the other buffer: its last readers passed the previous barrier
+#else
+      asm volatile("" :: "v"(hd[0][0]), "v"(ha[0][0]), "v"(ha[G::NIT_A - 1][3]), "v"(hd[G::NIT_DZ - 1][3]));
+#endif
+#ifndef TSR_ABL_WG_NOMMA
+    });
+#endif
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- write this split's partial dW: slab[sp][co][ci][kh][kw]
+  constexpr int T = KS * KS;
+  float* sl = g.slab + (size_t)sp * g.cout * g.cin * T;
+  const float inv = F16 ? 1.f / (s_a * s_d) : 1.f;
+  const int ci = cib * CI + wn * 32 + li;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int tap = 0; tap < G::NTAP; ++tap) {
+      if (kh0 * KS + tap < T) {          // a short last row group holds rows beyond the kernel: not written
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = cob * CO + wm * WM + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          sl[((size_t)co * g.cin + ci) * T + kh0 * KS + tap] = acc[m][tap][r] * inv;
+        }
+      }
+    }
+  if (do_bias) {       // thread slot j holds the sums of 4 channels of (pixel, block): reduce the 32 pixels
+    float* bred = (float*)lds;                 // [32 px][CO]
+#pragma unroll
+    for (int j = 0; j < G::NIT_DZ; ++j) {
+      const int i = tid + j * NT;
+      if ((j + 1) * NT <= G::N_DZ || i < G::N_DZ) {
+        const int q = i & 3, px = (i >> 2) & 31, blk = i >> 7;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bred[px * CO + blk * 16 + q * 4 + c] = bsum[j][c];
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < CO; c += NT) {
+      float s = 0.f;
+#pragma unroll
+      for (int px = 0; px < 32; ++px) s += bred[px * CO + c];
+      g.bslab[(size_t)sp * g.cout + cob * CO + c] = s;
+    }
+  }
+}
+
+// Tile / row-group choice per layer shape (2-plane and 1-plane forms; the 3-plane bf16x6 cross-check path keeps one
+// row per workgroup).  The accumulators bound it: 32x32 wave tiles x taps x 16 registers.
+//   5x5 128->128 : 128 x 128, one row  (8 waves, wave = 64 co x 32 ci, 10 tiles)     1 workgroup / CU
+//   3x3 128->128 : 128 x  64, ALL rows (8 waves, wave = 32 x 32, 9 tiles)            1 workgroup / CU
+//   5x5  64-> 64 :  64 x  64, two rows (4 waves, 10 tiles; row groups {0,1},{2,3},{4}) 2 workgroups / CU
+//   3x3  64-> 64 :  64 x  64, ALL rows (4 waves, 9 tiles)                            2 workgroups / CU
+//   1x1          : 128 x 128 / 64 x 64
+template <int KS, int NS> struct WgradTCfg {
+  static constexpr bool wide = NS <= 2;
+  static constexpr int KHW_BIG = !wide ? 1 : (KS == 3 ? 3 : 1);
+  static constexpr int CI_BIG = !wide ? 64 : (KS == 3 ? 64 : 128);
+  static constexpr int WM_BIG = !wide ? 32 : (KS == 3 ? 32 : 64);
+  static constexpr int KHW_SMALL = !wide ? 1 : (KS == 5 ? 2 : (KS == 3 ? 3 : 1));
+};
+
+static bool tr16_big(int cout, int cin, int ci_big) { return (cout % 128) == 0 && (cin % ci_big) == 0; }
+
+template <int KS, int NS, bool F16>
+static int launch_tr16(const WgradTArgs& g, hipStream_t st) {
+  typedef WgradTCfg<KS, NS> C;
+  if (tr16_big(g.cout, g.cin, C::CI_BIG)) {
+    typedef WgradTGeom<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG, NS, F16> G;
+    const int grid = g.nsplit * G::NKG * (g.cout / 128) * (g.cin / C::CI_BIG);
+    static const bool nostag = getenv("TSR_WGRAD_NOSTAGGER") != nullptr;      // A/B switch (fp16x3 only)
+    if (F16 && nostag)
+      hipLaunchKernelGGL((wgrad_tr16_kernel<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG, NS, F16, false>), dim3(grid), dim3(G::NT), 0, st, g);
+    else
+      hipLaunchKernelGGL((wgrad_tr16_kernel<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG, NS, F16>), dim3(grid), dim3(G::NT), 0, st, g);
+    return tsr_check_launch();
+  }
+  typedef WgradTGeom<KS, C::KHW_SMALL, 64, 64, 32, NS, F16> G;
+  const int grid = g.nsplit * G::NKG * (g.cout / 64) * (g.cin / 64);
+  hipLaunchKernelGGL((wgrad_tr16_kernel<KS, C::KHW_SMALL, 64, 64, 32, NS, F16>), dim3(grid), dim3(G::NT), 0, st, g);
+  return tsr_check_launch();
+}
+
+template <int KS> static int tr16_wgs(int cout, int cin, int planes) {
+  if (planes == 3) {
+    typedef WgradTCfg<KS, 3> C;
+    if (tr16_big(cout, cin, C::CI_BIG)) return ((KS + C::KHW_BIG - 1) / C::KHW_BIG) * (cout / 128) * (cin / C::CI_BIG);
+    return ((KS + C::KHW_SMALL - 1) / C::KHW_SMALL) * (cout / 64) * (cin / 64);
+  }
+  typedef WgradTCfg<KS, 2> C;
+  if (tr16_big(cout, cin, C::CI_BIG)) return ((KS + C::KHW_BIG - 1) / C::KHW_BIG) * (cout / 128) * (cin / C::CI_BIG);
+  return ((KS + C::KHW_SMALL - 1) / C::KHW_SMALL) * (cout / 64) * (cin / 64);
+}
+
+// workgroups one batch split of this layer launches (the caller sizes nsplit so that splits x this fills the chip)
+extern "C" int tsr_conv2d_wgrad_wgs_per_split(int cout, int cin, int ks, int planes) {
+  return ks == 1 ? tr16_wgs<1>(cout, cin, planes) : (ks == 3 ? tr16_wgs<3>(cout, cin, planes) : tr16_wgs<5>(cout, cin, planes));
+}
+
+// recommended batch splits: one resident round of workgroups (1 per CU for the 512-thread tiles, 2 for the 256-thread
+// ones), never more than there are (image, patch) work items
+extern "C" int tsr_conv2d_wgrad_splits(int cout, int cin, int ks, int planes, int B, int H, int W) {
+  const int wgs = tsr_conv2d_wgrad_wgs_per_split(cout, cin, ks, planes);
+  const int ci_big = planes == 3 ? 64 : (ks == 3 ? 64 : 128);
+  const bool big = tr16_big(cout, cin, ci_big);
+  const long items = (long)B * ((H + 3) / 4) * ((W + 7) / 8);
+  long ns = (big ? 256 : 512) / wgs;
+  if (ns < 1) ns = 1;
+  if (ns > items) ns = items;
+  return (int)ns;
+}
+
+int tsr_conv2d_wgrad_tr16(const float* a, int a_ctot, int a_coff, int cin, const float* a_scale, const float* a_shift,
+                          const float* dz, int dz_ctot, int dz_coff, int cout, int ks, int planes,
+                          const float* a_amax, const float* dz_amax, float* slab, float* bias_slab, int nsplit,
+                          int B, int H, int W, hipStream_t st) {
+  WgradTArgs g;
+  g.a = a; g.a_ctot = a_ctot; g.a_coff = a_coff; g.cin = cin; g.a_scale = a_scale; g.a_shift = a_shift;
+  g.dz = dz; g.dz_ctot = dz_ctot; g.dz_coff = dz_coff; g.cout = cout;
+  g.slab = slab; g.bslab = bias_slab; g.B = B; g.H = H; g.W = W; g.nsplit = nsplit;
+  g.tiles_x = (W + 7) / 8; g.tiles_y = (H + 3) / 4;
+  g.a_amax = a_amax; g.dz_amax = dz_amax;
+  if (planes == 3) {
+    if (ks == 1) return launch_tr16<1, 3, false>(g, st);
+    if (ks == 3) return launch_tr16<3, 3, false>(g, st);
+    return launch_tr16<5, 3, false>(g, st);
+  }
+  if (planes == 1) {
+    if (ks == 1) return launch_tr16<1, 1, false>(g, st);
+    if (ks == 3) return launch_tr16<3, 1, false>(g, st);
+    return launch_tr16<5, 1, false>(g, st);
+  }
+  if (ks == 1) return launch_tr16<1, 2, true>(g, st);
+  if (ks == 3) return launch_tr16<3, 2, true>(g, st);
+  return launch_tr16<5, 2, true>(g, st);
+}

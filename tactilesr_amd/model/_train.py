@@ -408,7 +408,10 @@ class TrainEngine:
     def _wgrad(self, c, a: Act, dz: Act, conv, grads, name, with_bias):
         w = conv.weight
         cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
-        ns = self._nsplit(c.B, ((c.H + 7) // 8) * ((c.W + 7) // 8), ks, cout, cin)
+        if self.nsplit:       # 16-bit MFMA form: the library sizes the batch split for its tile shape
+            ns = _lib.load().tsr_conv2d_wgrad_splits(cout, cin, ks, self.nsplit, c.B, c.H, c.W)
+        else:
+            ns = self._nsplit(c.B, ((c.H + 7) // 8) * ((c.W + 7) // 8), ks, cout, cin)
         n = cout * cin * ks * ks
         slab = torch.empty(ns * n, dtype=torch.float32, device=w.device)
         bslab = torch.empty(ns * cout, dtype=torch.float32, device=w.device) if with_bias else None

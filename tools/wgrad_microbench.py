@@ -13,8 +13,14 @@ g = torch.Generator().manual_seed(0)
 a = torch.randn(B * cin * H * W, generator=g).cuda()
 dz = (torch.randn(B * cout * H * W, generator=g) * 1e-3).cuda()
 am = torch.tensor([6.0, 6e-3]).cuda()
-slices = ks * (cout // 64) * (cin // 64)
-ns = max(1, min(B * 25, 1024 // slices))
+from tactilesr_amd._lib import load  # noqa: E402
+if os.environ.get("TSR_WGRAD_OLD"):
+    slices = ks * (cout // 64) * (cin // 64)
+    ns = max(1, min(B * 25, 1024 // slices))
+else:
+    ns = load().tsr_conv2d_wgrad_splits(cout, cin, ks, planes, B, H, W)
+if len(sys.argv) > 6:
+    ns = int(sys.argv[6])
 slab = torch.empty(ns * cout * cin * ks * ks, device="cuda")
 bslab = torch.empty(ns * cout, device="cuda")
 
