@@ -80,7 +80,7 @@ struct WgradTGeom {
   static constexpr int LDSB = (2 * BUFB > 32 * CO * 4 ? 2 * BUFB : 32 * CO * 4) + CI * 8;   // + (scale, shift) table
 };
 
-template <int KS, int KHW, int CO, int CI, int WM, int NS, bool F16, bool STAGGER = true>
+template <int KS, int KHW, int CO, int CI, int WM, int NS, bool F16, bool STAGGER = false>
 __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_tr16_kernel(const WgradTArgs g) {
   typedef WgradTGeom<KS, KHW, CO, CI, WM, NS, F16> G;
   typedef typename TPlane<F16>::T PT;
@@ -364,13 +364,13 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_tr16_kern
   };
 
   __syncthreads();                         // tsc published (and the scale-bound scratch is free)
-  // Per item: [issue next item's global loads | MFMAs of K step 0 | convert + write the next item into the other
-  // buffer | MFMAs of K step 1 | barrier].  The two waves of a SIMD (w and w + NWAVE/2) run the same code; the second
-  // half carries a static s_setprio 1, so it wins the matrix pipe whenever both want it and the pair falls half a
-  // phase apart: while one converts (VALU, LDS writes) its partner's MFMAs have the pipe, instead of both alternating
-  // between an MFMA-only and a VALU-only phase in lockstep.  (A role split with two code paths costs registers the
-  // 10-tile kernels do not have: 57 spills.)
-  if (STAGGER && __builtin_amdgcn_readfirstlane(wave) >= G::NWAVE / 2) __builtin_amdgcn_s_setprio(1);
+  // Per item: [issue next item's global loads | MFMAs of K step 0 | S | MFMAs of K step 1 | S' | barrier] where the
+  // staging block (convert + write the next item into the other buffer) runs at S in the first half of the waves and
+  // at S' in the second.  Wave w and w + NWAVE/2 share a SIMD: while one converts (VALU, LDS writes) the other's MFMAs
+  // have the matrix pipe -- in lockstep both would alternate between an MFMA-only and a VALU-only phase.  (Measured:
+  // static s_setprio for one half does not pull the pair apart; two full loop bodies with different load placement
+  // cost 57 spilled registers in the 10-tile kernels.)
+  const bool late = STAGGER && __builtin_amdgcn_readfirstlane(wave) >= G::NWAVE / 2;
   if (it0 < it1) {
     load_item();
     store_item(0);
@@ -386,12 +386,15 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_tr16_kern
     mma_item(cur, [&]() {
 #endif
 #ifndef TSR_ABL_WG_NOSTORE
-      if (more) store_item(cur ^ 1);     // the other buffer: its last readers passed the previous barrier
+      if (more && !late) store_item(cur ^ 1);     // the other buffer: its last readers passed the previous barrier
 #else
       asm volatile("" :: "v"(hd[0][0]), "v"(ha[0][0]), "v"(ha[G::NIT_A - 1][3]), "v"(hd[G::NIT_DZ - 1][3]));
 #endif
 #ifndef TSR_ABL_WG_NOMMA
     });
+#endif
+#ifndef TSR_ABL_WG_NOSTORE
+    if (more && late) store_item(cur ^ 1);        // second half of the waves: after K step 1 (see above)
 #endif
     __syncthreads();
     cur ^= 1;
@@ -445,7 +448,11 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_tr16_kern
 template <int KS, int NS> struct WgradTCfg {
   static constexpr bool wide = NS <= 2;
   static constexpr int KHW_BIG = !wide ? 1 : (KS == 3 ? 3 : 1);
+#ifdef TSR_EXP_WG_5X5_2WG
+  static constexpr int CI_BIG = !wide ? 64 : (KS == 1 ? 128 : 64);
+#else
   static constexpr int CI_BIG = !wide ? 64 : (KS == 3 ? 64 : 128);
+#endif
   static constexpr int WM_BIG = !wide ? 32 : (KS == 3 ? 32 : 64);
   static constexpr int KHW_SMALL = !wide ? 1 : (KS == 5 ? 2 : (KS == 3 ? 3 : 1));
 };
@@ -458,9 +465,9 @@ static int launch_tr16(const WgradTArgs& g, hipStream_t st) {
   if (tr16_big(g.cout, g.cin, C::CI_BIG)) {
     typedef WgradTGeom<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG, NS, F16> G;
     const int grid = g.nsplit * G::NKG * (g.cout / 128) * (g.cin / C::CI_BIG);
-    static const bool nostag = getenv("TSR_WGRAD_NOSTAGGER") != nullptr;      // A/B switch (fp16x3 only)
-    if (F16 && nostag)
-      hipLaunchKernelGGL((wgrad_tr16_kernel<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG, NS, F16, false>), dim3(grid), dim3(G::NT), 0, st, g);
+    static const bool stag = getenv("TSR_WGRAD_STAGGER") != nullptr;      // A/B switch (fp16x3 only): measured slower
+    if (F16 && stag)
+      hipLaunchKernelGGL((wgrad_tr16_kernel<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG, NS, F16, true>), dim3(grid), dim3(G::NT), 0, st, g);
     else
       hipLaunchKernelGGL((wgrad_tr16_kernel<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG, NS, F16>), dim3(grid), dim3(G::NT), 0, st, g);
     return tsr_check_launch();
@@ -491,8 +498,13 @@ extern "C" int tsr_conv2d_wgrad_wgs_per_split(int cout, int cin, int ks, int pla
 // ones), never more than there are (image, patch) work items
 extern "C" int tsr_conv2d_wgrad_splits(int cout, int cin, int ks, int planes, int B, int H, int W) {
   const int wgs = tsr_conv2d_wgrad_wgs_per_split(cout, cin, ks, planes);
+#ifdef TSR_EXP_WG_5X5_2WG
+  const int ci_big = planes == 3 ? 64 : (ks == 1 ? 128 : 64);
+  const bool big = tr16_big(cout, cin, ci_big) && ks != 5;
+#else
   const int ci_big = planes == 3 ? 64 : (ks == 3 ? 64 : 128);
   const bool big = tr16_big(cout, cin, ci_big);
+#endif
   const long items = (long)B * ((H + 3) / 4) * ((W + 7) / 8);
   long ns = (big ? 256 : 512) / wgs;
   if (ns < 1) ns = 1;
