@@ -78,6 +78,11 @@ int tsr_conv2d_fwd_bf16s(const float* in, int in_ctot, int in_coff, int cin,
  * own fp32 CPU run against fp64 (tests).  Same remaining arguments as tsr_conv2d_fwd. */
 int tsr_pack_conv_weight_f16s(const float* w_oihw, void* w_packed, int cout, int cin, int ks, float wscale,
                               void* stream);
+/* Same with the scale derived ON THE DEVICE from w_amax[0] = max|w| (a device scalar the caller computed without a host
+ * round trip): wscale = 2^(13 - floor(log2 max|w|)).  The matching convolution takes the same scalar through
+ * tsr_conv_desc.w_amax. */
+int tsr_pack_conv_weight_f16s_dev(const float* w_oihw, void* w_packed, int cout, int cin, int ks, const float* w_amax,
+                                  void* stream);
 int tsr_conv2d_fwd_f16s(const float* in, int in_ctot, int in_coff, int cin,
                         const void* w_packed, int cout, int ks, float w_inv_scale,
                         const float* in_amax, float* out_amax,
@@ -138,6 +143,8 @@ typedef struct tsr_conv_desc {
   const float* in_amax;   /* device scalar max|in| (of the raw tensor; a fused input transform is bounded in-kernel) */
   float w_inv_scale;      /* 1 / wscale used at pack time */
   float* out_amax;        /* device scalar receiving max|out| (atomic max), any mode; NULL = off */
+  const float* w_amax;    /* nsplit == -2, optional: device scalar max|w| of a weight packed by ..._f16s_dev; replaces
+                             w_inv_scale (no host round trip for the weight scale) */
 } tsr_conv_desc;
 
 int tsr_conv2d_ex(const tsr_conv_desc* desc, void* stream);
@@ -157,6 +164,8 @@ int tsr_pack_conv_weight_dgrad_bf16s(const float* w_oihw, void* w_packed, int co
 
 int tsr_pack_conv_weight_dgrad_f16s(const float* w_oihw, void* w_packed, int cout, int cin, int ks,
                                     int ci0, int nprime, float wscale, void* stream);
+int tsr_pack_conv_weight_dgrad_f16s_dev(const float* w_oihw, void* w_packed, int cout, int cin, int ks,
+                                        int ci0, int nprime, const float* w_amax, void* stream);
 
 /* Weight (and bias) gradient partials: slab[s][cout][cin][k][k] (s < nsplit, OIHW) with
  * dW = sum_s slab[s] (tsr_reduce_splits), from a = conv input (CB16, optional relu(a*scale+shift)

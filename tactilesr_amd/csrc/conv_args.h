@@ -28,4 +28,5 @@ struct ConvArgs {
   const float* in_amax;   // device scalar: max |input activation| (written by the producer) -> input scale 2^k
   float w_inv_scale;      // 1 / (power-of-two weight scale applied at pack time); 0 = unused
   float* out_amax;        // device scalar: atomic max of |output| after the epilogue (for the consumer)
+  const float* w_amax;    // optional device scalar max|w|: the pack-time weight scale is re-derived from it (replaces w_inv_scale)
 };

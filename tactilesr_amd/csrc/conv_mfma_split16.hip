@@ -137,7 +137,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
       be = be < 1 ? 1 : (be > 254 ? 254 : be);
       sx = __uint_as_float((unsigned)be << 23);
     }
-    accmul = a.w_inv_scale / sx;
+    float w_inv = a.w_inv_scale;
+    if (a.w_amax) {            // same power of two the device-side pack derived from the same scalar
+      const float wm = *a.w_amax;
+      w_inv = 1.f;
+      if (wm > 0.f && wm < 3.0e38f) {
+        int be = 127 - (13 - ((int)((__float_as_uint(wm) >> 23) & 0xFF) - 127));
+        be = be < 1 ? 1 : (be > 254 ? 254 : be);
+        w_inv = __uint_as_float((unsigned)be << 23);
+      }
+    }
+    accmul = w_inv / sx;
   }
 
   int bid;
@@ -345,7 +355,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
 template <bool F16>
 __global__ void pack_conv_weight_bf16s_kernel(const float* __restrict__ w, typename Plane<F16>::T* __restrict__ wp,
                                               int cout, int cin, int ks, int ns, int tps, int ci0, int cin_f,
-                                              float wscale) {
+                                              float wscale, const float* __restrict__ w_amax) {
+  if (w_amax) {                // device-side scale: 2^(13 - floor(log2 max|w|)), 1 for a zero / non-finite maximum
+    const float wm = *w_amax;
+    wscale = 1.f;
+    if (wm > 0.f && wm < 3.0e38f) {
+      int be = 127 + 13 - ((int)((__float_as_uint(wm) >> 23) & 0xFF) - 127);
+      be = be < 1 ? 1 : (be > 254 ? 254 : be);
+      wscale = __uint_as_float((unsigned)be << 23);
+    }
+  }
   typedef typename Plane<F16>::T PT;
   const int T = ks * ks;
   const int nstep = (T + tps - 1) / tps;
@@ -387,7 +406,7 @@ extern "C" int tsr_pack_conv_weight_bf16s(const float* w_oihw, void* w_packed, i
   const size_t total = (size_t)cout * cin * (((ks * ks + tps - 1) / tps) * tps);
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel<false>, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
-                     (hipStream_t)stream, w_oihw, (__bf16*)w_packed, cout, cin, ks, nsplit, tps, -1, 0, 1.0f);
+                     (hipStream_t)stream, w_oihw, (__bf16*)w_packed, cout, cin, ks, nsplit, tps, -1, 0, 1.0f, nullptr);
   return tsr_check_launch();
 }
 
@@ -402,7 +421,32 @@ extern "C" int tsr_pack_conv_weight_f16s(const float* w_oihw, void* w_packed, in
   const size_t total = (size_t)cout * cin * (((ks * ks + tps - 1) / tps) * tps);
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel<true>, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
-                     (hipStream_t)stream, w_oihw, (_Float16*)w_packed, cout, cin, ks, 2, tps, -1, 0, wscale);
+                     (hipStream_t)stream, w_oihw, (_Float16*)w_packed, cout, cin, ks, 2, tps, -1, 0, wscale, nullptr);
+  return tsr_check_launch();
+}
+
+extern "C" int tsr_pack_conv_weight_f16s_dev(const float* w_oihw, void* w_packed, int cout, int cin, int ks,
+                                             const float* w_amax, void* stream) {
+  if (!w_oihw || !w_packed || !w_amax || (cin & 15) || (cout != 64 && cout != 128) || (ks != 1 && ks != 3 && ks != 5))
+    return TSR_ERR_ARG;
+  const int tps = taps_per_step(ks, cout, 2);
+  const size_t total = (size_t)cout * cin * (((ks * ks + tps - 1) / tps) * tps);
+  const int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel<true>, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
+                     (hipStream_t)stream, w_oihw, (_Float16*)w_packed, cout, cin, ks, 2, tps, -1, 0, 1.0f, w_amax);
+  return tsr_check_launch();
+}
+
+extern "C" int tsr_pack_conv_weight_dgrad_f16s_dev(const float* w_oihw, void* w_packed, int cout, int cin, int ks,
+                                                   int ci0, int nprime, const float* w_amax, void* stream) {
+  if (!w_oihw || !w_packed || !w_amax || (cout & 15) || (nprime != 64 && nprime != 128) || ci0 < 0 ||
+      ci0 + nprime > cin || (ks != 1 && ks != 3 && ks != 5))
+    return TSR_ERR_ARG;
+  const int tps = taps_per_step(ks, nprime, 2);
+  const size_t total = (size_t)nprime * cout * (((ks * ks + tps - 1) / tps) * tps);
+  const int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel<true>, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
+                     (hipStream_t)stream, w_oihw, (_Float16*)w_packed, nprime, cout, ks, 2, tps, ci0, cin, 1.0f, w_amax);
   return tsr_check_launch();
 }
 
@@ -415,7 +459,7 @@ extern "C" int tsr_pack_conv_weight_dgrad_bf16s(const float* w_oihw, void* w_pac
   const size_t total = (size_t)nprime * cout * (((ks * ks + tps - 1) / tps) * tps);
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel<false>, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
-                     (hipStream_t)stream, w_oihw, (__bf16*)w_packed, nprime, cout, ks, nsplit, tps, ci0, cin, 1.0f);
+                     (hipStream_t)stream, w_oihw, (__bf16*)w_packed, nprime, cout, ks, nsplit, tps, ci0, cin, 1.0f, nullptr);
   return tsr_check_launch();
 }
 
@@ -460,7 +504,7 @@ extern "C" int tsr_pack_conv_weight_dgrad_f16s(const float* w_oihw, void* w_pack
   const size_t total = (size_t)nprime * cout * (((ks * ks + tps - 1) / tps) * tps);
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel<true>, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
-                     (hipStream_t)stream, w_oihw, (_Float16*)w_packed, nprime, cout, ks, 2, tps, ci0, cin, wscale);
+                     (hipStream_t)stream, w_oihw, (_Float16*)w_packed, nprime, cout, ks, 2, tps, ci0, cin, wscale, nullptr);
   return tsr_check_launch();
 }
 

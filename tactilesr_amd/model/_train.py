@@ -40,7 +40,7 @@ class ConvDesc(ctypes.Structure):
         ("bn_a", c_void_p), ("bn_b", c_void_p),
         ("slab", c_void_p), ("slab_cnt", c_void_p),
         ("nsplit", c_int),
-        ("in_amax", c_void_p), ("w_inv_scale", c_float), ("out_amax", c_void_p),
+        ("in_amax", c_void_p), ("w_inv_scale", c_float), ("out_amax", c_void_p), ("w_amax", c_void_p),
     ]
 
 
@@ -60,10 +60,10 @@ class Act:
 
 def conv_ex(*, B, H, W, src: Act, w, cout, ks, out, out_ctot, out_coff, scale=None, shift=None, relu=0,
             res: Act = None, epi_mode=0, mask: Act = None, bn=False, slab=None, slab_cnt=None, nsplit=0,
-            w_inv_scale=1.0, out_amax=None):
+            w_inv_scale=1.0, out_amax=None, w_amax=None):
     d = ConvDesc()
     d.nsplit = nsplit
-    d.in_amax, d.w_inv_scale, d.out_amax = _p(src.amax), w_inv_scale, _p(out_amax)
+    d.in_amax, d.w_inv_scale, d.out_amax, d.w_amax = _p(src.amax), w_inv_scale, _p(out_amax), _p(w_amax)
     d.in_, d.in_ctot, d.in_coff, d.cin = _p(src.buf), src.ctot, src.coff, src.c
     d.w_packed, d.cout, d.ks = _p(w), cout, ks
     d.scale, d.shift = _p(scale), _p(shift)
@@ -85,11 +85,11 @@ def conv_ex(*, B, H, W, src: Act, w, cout, ks, out, out_ctot, out_coff, scale=No
         raise _lib.TactileSRHipError(f"tsr_conv2d_ex failed: status {st}")
 
 
-def _pack(w, cout, cin, ks, nsplit=0, wscale=1.0):
+def _pack(w, cout, cin, ks, nsplit=0, w_amax=None):
     if nsplit == -2:
         n = _lib.load().tsr_conv_weight_bf16s_elems(cout, cin, ks, 2)
         wp = torch.empty(n, dtype=torch.float16, device=w.device)
-        call("tsr_pack_conv_weight_f16s", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), _F(wscale), stream())
+        call("tsr_pack_conv_weight_f16s_dev", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), ptr(w_amax), stream())
         return wp
     if nsplit:
         n = _lib.load().tsr_conv_weight_bf16s_elems(cout, cin, ks, nsplit)
@@ -101,12 +101,12 @@ def _pack(w, cout, cin, ks, nsplit=0, wscale=1.0):
     return wp
 
 
-def _pack_dgrad(w, cout, cin, ks, ci0, nprime, nsplit=0, wscale=1.0):
+def _pack_dgrad(w, cout, cin, ks, ci0, nprime, nsplit=0, w_amax=None):
     if nsplit == -2:
         n = _lib.load().tsr_conv_weight_bf16s_elems(nprime, cout, ks, 2)
         wp = torch.empty(n, dtype=torch.float16, device=w.device)
-        call("tsr_pack_conv_weight_dgrad_f16s", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), _I(ci0), _I(nprime),
-             _F(wscale), stream())
+        call("tsr_pack_conv_weight_dgrad_f16s_dev", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), _I(ci0), _I(nprime),
+             ptr(w_amax), stream())
         return wp
     if nsplit:
         n = _lib.load().tsr_conv_weight_bf16s_elems(nprime, cout, ks, nsplit)
@@ -174,15 +174,15 @@ class TrainEngine:
         return cv
 
     def _weight_scales(self, c):
-        """fp16x3: power-of-two scale per conv weight (max|w|*wscale in [2^13, 2^14)); one host sync per step."""
-        c.wscale = {}
+        """fp16x3: max|w| per conv weight as DEVICE scalars (one batched launch, no host round trip); the pack kernels
+        and the convolutions derive the same power-of-two scale (max|w|*wscale in [2^13, 2^14)) from them."""
+        c.wamax = {}
         if not self.f16:
             return
-        import math
         cv = self._mfma_convs()
-        mx = torch.stack(torch._foreach_norm([k.weight.detach() for k in cv], float("inf"))).cpu().tolist()
-        for k, v in zip(cv, mx):
-            c.wscale[id(k)] = 2.0 ** (13 - math.floor(math.log2(v))) if v > 0 and math.isfinite(v) else 1.0
+        mx = torch.stack(torch._foreach_norm([k.weight.detach() for k in cv], float("inf")))
+        for i, k in enumerate(cv):
+            c.wamax[id(k)] = mx[i:i + 1]
 
     def _amax_pool(self, c, dev):
         n = 64 + 8 * (len(self.m.patternFeatureExtra_layer) + len(self.m.forceFeatureExtra_layer) + self.m.seqsCnt)
@@ -213,9 +213,10 @@ class TrainEngine:
         return _lib.load().tsr_conv2d_slab_entries_ex(c.B, c.H, c.W, cout, ks, self.nsplit)
 
     def _packw(self, c, conv):
+        """(packed weight, device scalar max|w| or None)"""
         w = conv.weight.detach().contiguous()
-        ws = c.wscale.get(id(conv), 1.0)
-        return _pack(w, w.shape[0], w.shape[1], w.shape[2], self.nsplit, ws), 1.0 / ws
+        wa = c.wamax.get(id(conv))
+        return _pack(w, w.shape[0], w.shape[1], w.shape[2], self.nsplit, wa), wa
 
     def _conv_bn(self, c: _Ctx, src: Act, conv, bn, out, out_ctot, out_coff, out_amax=None):
         """conv (bias-free raw output) + batch statistics; returns the 4xC BN vectors."""
@@ -225,7 +226,7 @@ class TrainEngine:
         with self._timed(("fwd", ks, cout, cin)):
             conv_ex(B=c.B, H=c.H, W=c.W, src=src, w=wp, cout=cout, ks=ks, out=out, out_ctot=out_ctot,
                     out_coff=out_coff, epi_mode=1, slab=c.slab, slab_cnt=c.slab_cnt, nsplit=self.nsplit,
-                    w_inv_scale=wis, out_amax=out_amax)
+                    w_amax=wis, out_amax=out_amax)
         return self._bn_finalize(c, conv.bias, bn, c.slab, c.slab_cnt, self._entries(c, cout, ks), cout)
 
     # ------------------------------------------------------------------ forward
@@ -302,7 +303,7 @@ class TrainEngine:
             else:
                 out, octot, ocoff, am_o = buf(64), 64, 0, new_amax()
             conv_ex(B=B, H=H, W=W, src=A2, w=wp, cout=64, ks=1, out=out, out_ctot=octot, out_coff=ocoff,
-                    shift=blk.confusion.bias.detach(), relu=1, res=X, nsplit=self.nsplit, w_inv_scale=wis,
+                    shift=blk.confusion.bias.detach(), relu=1, res=X, nsplit=self.nsplit, w_amax=wis,
                     out_amax=am_o)
             X = Act(out, octot, ocoff, 64, amax=am_o)
             s.Y = X
@@ -327,7 +328,7 @@ class TrainEngine:
             s.F1 = Act(s.f1, 64, 0, 64, amax=new_amax())
             w1, wis1 = self._packw(c, rb.conv1)
             conv_ex(B=B, H=H, W=W, src=F0, w=w1, cout=64, ks=3, out=s.f1, out_ctot=64, out_coff=0,
-                    shift=rb.conv1.bias.detach(), relu=1, nsplit=self.nsplit, w_inv_scale=wis1, out_amax=s.F1.amax)
+                    shift=rb.conv1.bias.detach(), relu=1, nsplit=self.nsplit, w_amax=wis1, out_amax=s.F1.amax)
             w2, wis2 = self._packw(c, rb.conv2)
             if i == n_res - 1:
                 out, octot, ocoff, am_o = c.hcat, 128, 0, c.am_hcat
@@ -335,7 +336,7 @@ class TrainEngine:
                 out, octot, ocoff, am_o = buf(64), 64, 0, new_amax()
             conv_ex(B=B, H=H, W=W, src=s.F1, w=w2, cout=64, ks=3, out=out, out_ctot=octot,
                     out_coff=ocoff, shift=rb.conv2.bias.detach(), relu=1, res=F0, nsplit=self.nsplit,
-                    w_inv_scale=wis2, out_amax=am_o)
+                    w_amax=wis2, out_amax=am_o)
             F0 = Act(out, octot, ocoff, 64, amax=am_o)
             s.Y = F0
             c.res.append(s)
@@ -343,7 +344,7 @@ class TrainEngine:
         c.h0 = buf(128)
         wh, wish = self._packw(c, m.output_layer[0])
         conv_ex(B=B, H=H, W=W, src=Act(c.hcat, 128, 0, 128, amax=c.am_hcat), w=wh, cout=128, ks=3, out=c.h0,
-                out_ctot=128, out_coff=0, relu=1, nsplit=self.nsplit, w_inv_scale=wish)
+                out_ctot=128, out_coff=0, relu=1, nsplit=self.nsplit, w_amax=wish)
         out = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
         call("tsr_head_fwd", ptr(c.h0), _I(128), _I(128), ptr(m.output_layer[2].weight.detach()), ptr(out), _I(1),
              _I(B), _I(H), _I(W), stream())
@@ -437,12 +438,12 @@ class TrainEngine:
         """d(input)[ci0:ci0+nprime] of conv given dz; optional + res, ReLU mask, BN-backward sums."""
         w = conv.weight.detach().contiguous()
         cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
-        ws = c.wscale.get(id(conv), 1.0)
-        wp = _pack_dgrad(w, cout, cin, ks, ci0, nprime, self.nsplit, ws)
+        wa = c.wamax.get(id(conv))
+        wp = _pack_dgrad(w, cout, cin, ks, ci0, nprime, self.nsplit, wa)
         with self._timed(("dgrad", ks, nprime, cout)):
             conv_ex(B=c.B, H=c.H, W=c.W, src=dz, w=wp, cout=nprime, ks=ks, out=out, out_ctot=out_ctot,
                     out_coff=out_coff, res=res, epi_mode=2 if mask is not None else 0, mask=mask, bn=bn,
-                    slab=c.slab if bn else None, slab_cnt=None, nsplit=self.nsplit, w_inv_scale=1.0 / ws,
+                    slab=c.slab if bn else None, slab_cnt=None, nsplit=self.nsplit, w_amax=wa,
                     out_amax=out_amax)
         c.last_entries = self._entries(c, nprime, ks)      # what a following _bn_bwd reduces
 
