@@ -234,11 +234,10 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_tr16_kern
     }
   };
 
-  auto split_store = [&](f32x4 v, char* dst, int plane_stride, float sc) {
-    if (F16) {
+  // `mult` carries both the power-of-two operand scale and the in-image mask (0 for a slot that read its safe pixel)
+  auto split_store = [&](f32x4 v, char* dst, int plane_stride, float mult) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] *= sc;
-    }
+    for (int c = 0; c < 4; ++c) v[c] *= mult;
 #pragma unroll
     for (int p = 0; p < NS; ++p) {
       PV4 qv;
@@ -257,15 +256,14 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_tr16_kern
 #pragma unroll
     for (int j = 0; j < G::NIT_DZ; ++j) {
       if ((j + 1) * NT <= G::N_DZ || tid + j * NT < G::N_DZ) {
-        f32x4 v = hd[j];
-        const float keep = ((okd >> j) & 1) ? 1.f : 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] *= keep;
+        const f32x4 v = hd[j];
+        const bool ok = (okd >> j) & 1;
         if (do_bias) {
+          const float keep = ok ? 1.f : 0.f;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) bsum[j][c] += v[c];
+          for (int c = 0; c < 4; ++c) bsum[j][c] = fmaf(v[c], keep, bsum[j][c]);
         }
-        split_store(v, dzt + ldsd[j], G::DZ_PLANEB, s_d);
+        split_store(v, dzt + ldsd[j], G::DZ_PLANEB, ok ? s_d : 0.f);
       }
     }
 #pragma unroll
@@ -278,10 +276,7 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_tr16_kern
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] = fmaxf(fmaf(v[c], sc[c], sh[c]), 0.f);
         }
-        const float keep = ((oka >> j) & 1) ? 1.f : 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] *= keep;
-        split_store(v, at + ldsa[j], G::A_PLANEB, s_a);
+        split_store(v, at + ldsa[j], G::A_PLANEB, ((oka >> j) & 1) ? s_a : 0.f);
       }
     }
   };
