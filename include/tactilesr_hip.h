@@ -90,6 +90,19 @@ int tsr_conv2d_fwd_f16s(const float* in, int in_ctot, int in_coff, int cin,
                         const float* res, int res_ctot, int res_coff,
                         float* out, int out_ctot, int out_coff, int relu,
                         int B, int H, int W, void* stream);
+/* bf16 ACTIVATION STORAGE (BASELINE's "bf16" configurations: reduced precision, tolerance 2e-2, never the parity path).
+ * Activations are bf16 CB16 tensors -- `in` / `res` / `out` address bf16 elements, same [B][C/16][H*W][16] order --
+ * weights the one-plane pack of tsr_pack_conv_weight_bf16s(nsplit = 1), fp32 accumulation and epilogue arithmetic
+ * (same y = relu(conv*scale + shift + res) as tsr_conv2d_fwd).  tsr_stem_fwd_b16 writes such a tensor, tsr_head_fwd_b16
+ * reads one (both otherwise identical to tsr_stem_fwd / tsr_head_fwd). */
+int tsr_conv2d_fwd_b16(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed, int cout, int ks,
+                       const float* scale, const float* shift, const void* res, int res_ctot, int res_coff,
+                       void* out, int out_ctot, int out_coff, int relu, int B, int H, int W, void* stream);
+int tsr_stem_fwd_b16(const float* lr, int lr_ctot, int lr_coff, int axis_cnt, int hin, int win, int sf,
+                     const float* w_oihw, const float* scale, const float* shift,
+                     void* out_bf16, int out_ctot, int out_coff, int relu, int B, void* stream);
+int tsr_head_fwd_b16(const void* in_bf16, int in_ctot, int cin, const float* w_oihw, float* out_nchw,
+                     int relu, int B, int H, int W, void* stream);
 
 /* nn.Upsample(scale_factor=sf, bilinear, align_corners=False) + Conv2d(3->64, 3x3, pad 1, no bias)
  * + scale/shift + optional ReLU: the pattern stem's first conv (model/tactileSR_model.py:34-39)

@@ -22,7 +22,8 @@ __device__ __forceinline__ void quad_transpose(float& t0, float& t1, float& t2, 
 
 // accmul: exact power-of-two factor undoing the operand scaling of the fp16-split path (1 otherwise).
 // WN = waves across C_out (2: each wave owns C_out/2 of one of 2 images; 1: each wave owns all C_out of one of 4).
-template <int COUT, bool EXT, int WN = 2>
+// IO16: output and residual tensors are bf16 CB16 (inference epilogue only).
+template <int COUT, bool EXT, int WN = 2, bool IO16 = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2][COUT / (32 * WN)], int bid, int b0,
                                               int y0, int x0, int wm, int wn, int h, int li, int HW,
                                               float accmul = 1.f) {
@@ -58,12 +59,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
       if (a.scale) sc4 = *(const f32x4*)(a.scale + nq);
       if (a.shift) sh4 = *(const f32x4*)(a.shift + nq);
       if (EXT && a.res_scale) { rsc4 = *(const f32x4*)(a.res_scale + nq); rsh4 = *(const f32x4*)(a.res_shift + nq); }
-      float* ob4 = a.out + (((size_t)bsafe * out_blocks + (oq >> 4)) * HW) * 16 + (oq & 15);
+      const size_t oidx4 = (((size_t)bsafe * out_blocks + (oq >> 4)) * HW) * 16 + (oq & 15);
+      float* ob4 = a.out + oidx4;
       const float* rb4 = nullptr;
+      size_t ridx4 = 0;
       if (a.res) {
         const int rq = a.res_coff + nq;
-        rb4 = a.res + (((size_t)bsafe * res_blocks + (rq >> 4)) * HW) * 16 + (rq & 15);
+        ridx4 = (((size_t)bsafe * res_blocks + (rq >> 4)) * HW) * 16 + (rq & 15);
+        rb4 = a.res + ridx4;
       }
+      typedef __bf16 ep_bf16x4 __attribute__((ext_vector_type(4)));
       const int gx = x0 + j + 4 * h;
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
@@ -79,7 +84,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = (v[c] * accmul) * sc4[c] + sh4[c];
             if (rb4) {
-              f32x4 rv = *(const f32x4*)(rb4 + po);
+              f32x4 rv;
+              if (IO16) {
+                const ep_bf16x4 r16 = *(const ep_bf16x4*)((const __bf16*)a.res + ridx4 + po);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rv[c] = (float)r16[c];
+              } else {
+                rv = *(const f32x4*)(rb4 + po);
+              }
               if (EXT && a.res_scale) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) rv[c] = fmaxf(fmaf(rv[c], rsc4[c], rsh4[c]), 0.f);
@@ -92,7 +104,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
               if (a.relu) v[c] = fmaxf(v[c], 0.f);
               amax = fmaxf(amax, fabsf(v[c]));
             }
-            *(f32x4*)(ob4 + po) = v;
+            if (IO16) {
+              ep_bf16x4 o16;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) o16[c] = (__bf16)v[c];
+              *(ep_bf16x4*)((__bf16*)a.out + oidx4 + po) = o16;
+            } else {
+              *(f32x4*)(ob4 + po) = v;
+            }
           }
         }
       }

@@ -52,7 +52,9 @@ template <> struct SplitGeom<3> { static constexpr int PIXS = 7, RMOD = 8; };
 // taps per barrier step: enough MFMA work between two barriers (>= 24 MFMAs per wave where LDS allows)
 __host__ __device__ constexpr int taps_per_step(int ks, int cout, int ns) {
   const int t = ks * ks;
-  const int want = ns == 3 ? 1 : (ns == 2 ? 2 : ks);   // measured: ns = 3 is fastest at 1 (occupancy), 2 and 1 gain from grouping
+  // measured: ns = 3 is fastest at 1 (occupancy), 2 and 1 gain from grouping; one plane x 128 channels: 2 taps keep
+  // the 4-image workgroups of the bf16-storage path at two per CU
+  const int want = ns == 3 ? 1 : (ns == 2 ? 2 : (cout == 128 ? 2 : ks));
   return want < t ? want : t;
 }
 
@@ -68,8 +70,11 @@ constexpr int row_slots(int hh, int pixs, int rmod) {
 // halo buffer in the middle of the current block (loads at its first step, conversion + LDS writes at its
 // second-to-last), so a block boundary costs no extra barrier pair and the first tap's fragments are prefetched
 // like any other tap's.  Blocks are processed in pairs: buffer and fragment-set parity stay compile-time.
-template <int KS, int COUT, int NS, bool EXT, bool F16, int WN, bool DBH = false>
+// IO16 (NS = 1 only, inference): activations live in HBM as bf16 CB16 -- the halo slab is COPIED into LDS (8 B per
+// (pixel, channel quad), no conversion), the epilogue rounds to bf16 on store.  BASELINE's "bf16" configurations.
+template <int KS, int COUT, int NS, bool EXT, bool F16, int WN, bool DBH = false, bool IO16 = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArgs a) {
+  static_assert(!IO16 || (NS == 1 && !F16 && !EXT), "bf16 activation storage: plain bf16 operands, inference epilogue");
   typedef typename Plane<F16>::T PT;
   typedef typename Plane<F16>::V8 PV8;
   typedef typename Plane<F16>::V4 PV4;
@@ -180,7 +185,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
         st_src[k] = ((img * in_blocks) * HW + gy * a.W + gx) * 16 + qd * 4;
     }
   }
-  const float* in_base = a.in + ((size_t)b0 * in_blocks + (a.in_coff >> 4)) * HW * 16;
+  const size_t in_base_idx = ((size_t)b0 * in_blocks + (a.in_coff >> 4)) * HW * 16;
+  const float* in_base = a.in + in_base_idx;
+  const __bf16* in_base16 = (const __bf16*)a.in + in_base_idx;
 
   const int laneA = wm * IMGB + (li >> 3) * ROWB + (li & 7) * PIXB + h * 16;
   const int laneB = (h * COUT + wn * (COUT / WN) + li) * 16;
@@ -199,6 +206,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
 
   // ---- helpers (all loops fully unrolled: fragment registers are plain SSA values)
   auto load_halo = [&](int c, f32x4* hv) {
+    if (IO16) {     // 4 bf16 = 8 B per item, carried in the low half of the f32x4 slot
+      const __bf16* inc = in_base16 + (size_t)c * HW * 16;
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        hv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (st_src[k] >= 0) {
+          const float2 t = *(const float2*)(inc + st_src[k]);
+          hv[k][0] = t.x;
+          hv[k][1] = t.y;
+        }
+      }
+      return;
+    }
     const float* inc = in_base + (size_t)c * HW * 16;
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
@@ -207,6 +227,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
     }
   };
   auto store_halo = [&](const f32x4* hv, int c, int hb) {
+    if (IO16) {
+#pragma unroll
+      for (int k = 0; k < NIT; ++k)
+        if (st_dst[k] >= 0) *(float2*)(halo + hb * HALO_B + st_dst[k]) = make_float2(hv[k][0], hv[k][1]);
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       if (st_dst[k] >= 0) {
@@ -345,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
 #undef STORE_W
 #undef LOAD_FRAGS
 
-  conv_epilogue<COUT, EXT, WN>(a, acc, bid, b0, y0, x0, wm, wn, h, li, HW, accmul);
+  conv_epilogue<COUT, EXT, WN, IO16>(a, acc, bid, b0, y0, x0, wm, wn, h, li, HW, accmul);
 }
 
 // OIHW fp32 -> [C_in/16][step][tap in step][plane][2 (k half)][C_out][8] bf16 split planes; taps are
@@ -539,6 +565,62 @@ extern "C" int tsr_conv2d_fwd_bf16s(const float* in, int in_ctot, int in_coff, i
   if (nsplit == 3) return dispatch_bf16s<3, false>(a, cout, ks, st);
   if (nsplit == 2) return dispatch_bf16s<2, false>(a, cout, ks, st);
   return dispatch_bf16s<1, false>(a, cout, ks, st);
+}
+
+// bf16 activation storage (BASELINE's "bf16" configurations; reduced precision, never the parity path): `in`, `res`
+// and `out` are bf16 CB16 tensors, weights the one-plane pack of tsr_pack_conv_weight_bf16s(nsplit = 1), fp32
+// accumulation and epilogue arithmetic.
+template <int KS, int COUT>
+static int launch_b16(const ConvArgs& a, hipStream_t st) {
+  if constexpr (KS > 1) {
+    // 4 images per workgroup, wave = image x all C_out: the weight slab of a step serves 256 pixels instead of 128 --
+    // with one product per MAC the weight stream through L2 / LDS is what bounds the 2-image form (measured at
+    // B = 4096: 5x5 128->128 31.7 -> 25.1 ms per 6 launches, 3x3 64->64 9.0 -> 6.9 ms; whole forward 53.9 k -> 64.2 k/s)
+    const int grid4 = ((a.B + 3) / 4) * a.tiles_x * a.tiles_y;
+    // (a double-buffered halo for the 3x3 form of this variant measured slower: 3x3 64->64 6.9 -> 8.5 ms)
+    hipLaunchKernelGGL((conv_mfma_split16_kernel<KS, COUT, 1, false, false, 1, false, true>), dim3(grid4), dim3(256), 0, st, a);
+    return tsr_check_launch();
+  }
+  const int grid = ((a.B + 1) / 2) * a.tiles_x * a.tiles_y;
+  if constexpr (KS == 3) {
+    if (((a.cin >> 4) & 1) == 0) {
+      hipLaunchKernelGGL((conv_mfma_split16_kernel<KS, COUT, 1, false, false, 2, true, true>), dim3(grid), dim3(256), 0, st, a);
+      return tsr_check_launch();
+    }
+  }
+  hipLaunchKernelGGL((conv_mfma_split16_kernel<KS, COUT, 1, false, false, 2, false, true>), dim3(grid), dim3(256), 0, st, a);
+  return tsr_check_launch();
+}
+
+extern "C" int tsr_conv2d_fwd_b16(const void* in, int in_ctot, int in_coff, int cin,
+                                  const void* w_packed, int cout, int ks,
+                                  const float* scale, const float* shift,
+                                  const void* res, int res_ctot, int res_coff,
+                                  void* out, int out_ctot, int out_coff, int relu,
+                                  int B, int H, int W, void* stream) {
+  if (!in || !w_packed || !out || B <= 0 || H <= 0 || W <= 0) return TSR_ERR_ARG;
+  if ((cin & 15) || (in_ctot & 15) || (in_coff & 15) || (out_ctot & 15) || (out_coff & 15) || cin <= 0 ||
+      in_coff + cin > in_ctot || out_coff + cout > out_ctot)
+    return TSR_ERR_ARG;
+  if (res && ((res_ctot & 15) || (res_coff & 15) || res_coff + cout > res_ctot)) return TSR_ERR_ARG;
+  ConvArgs a = {};
+  a.in = (const float*)in; a.in_ctot = in_ctot; a.in_coff = in_coff; a.cin = cin;
+  a.wp = (const float*)w_packed; a.scale = scale; a.shift = shift;
+  a.res = (const float*)res; a.res_ctot = res_ctot; a.res_coff = res_coff;
+  a.out = (float*)out; a.out_ctot = out_ctot; a.out_coff = out_coff; a.relu = relu;
+  a.B = B; a.H = H; a.W = W;
+  a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8;
+  hipStream_t st = (hipStream_t)stream;
+  if (cout == 64) {
+    if (ks == 1) return launch_b16<1, 64>(a, st);
+    if (ks == 3) return launch_b16<3, 64>(a, st);
+    if (ks == 5) return launch_b16<5, 64>(a, st);
+  } else if (cout == 128) {
+    if (ks == 1) return launch_b16<1, 128>(a, st);
+    if (ks == 3) return launch_b16<3, 128>(a, st);
+    if (ks == 5) return launch_b16<5, 128>(a, st);
+  }
+  return TSR_ERR_ARG;
 }
 
 // fp16 two-plane variant ("fp16x3": x*sx = h1+h2, w*sw = g1+g2, products h1g1 + h1g2 + h2g1, fp32 accumulate).

@@ -24,7 +24,11 @@ __device__ __forceinline__ void bilin_src(int dst, float scale, int n_in, int& i
 // One workgroup = a band of RB output rows of one image.  A thread item = 4 consecutive pixels of a row x one
 // 16-channel block: per (input channel, kernel row) it reads 6 upsampled values and per tap the 16 weights, i.e.
 // 162 LDS reads for 1728 FMAs (a pixel-per-thread mapping needs 4x the weight reads and is LDS/issue bound).
-template <int CIN>
+typedef __bf16 sh_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 sh_bf16x4 __attribute__((ext_vector_type(4)));
+
+// OUT16: the output tensor is bf16 CB16 (the "bf16" activation-storage path); same arithmetic, rounded on store.
+template <int CIN, bool OUT16 = false>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ lr, int lr_ctot, int lr_coff,
                                                    int hin, int win, int sf,
                                                    const float* __restrict__ w,      // OIHW (64,CIN,3,3)
@@ -108,7 +112,9 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ lr,
         }
     }
     const int oc = out_coff + blk * 16;
-    float* o = out + (((size_t)b * out_blocks + (oc >> 4)) * HW + (size_t)(y0 + y) * W + x0) * 16;
+    const size_t oidx = (((size_t)b * out_blocks + (oc >> 4)) * HW + (size_t)(y0 + y) * W + x0) * 16;
+    float* o = out + oidx;
+    __bf16* o16 = (__bf16*)out + oidx;
     f32x4 scv[4], shv[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -127,7 +133,14 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ lr,
             v[j] = relu ? fmaxf(t, 0.f) : t;
             amax = fmaxf(amax, fabsf(v[j]));
           }
-          ((f32x4*)(o + px * 16))[q] = v;
+          if (OUT16) {
+            sh_bf16x4 hvv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hvv[j] = (__bf16)v[j];
+            ((sh_bf16x4*)(o16 + px * 16))[q] = hvv;
+          } else {
+            ((f32x4*)(o + px * 16))[q] = v;
+          }
         }
       }
     }
@@ -139,9 +152,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ lr,
   }
 }
 
-extern "C" int tsr_stem_fwd(const float* lr, int lr_ctot, int lr_coff, int axis_cnt, int hin, int win, int sf,
-                            const float* w_oihw, const float* scale, const float* shift,
-                            float* out, int out_ctot, int out_coff, int relu, int B, float* out_amax, void* stream) {
+static int stem_fwd_impl(const float* lr, int lr_ctot, int lr_coff, int axis_cnt, int hin, int win, int sf,
+                         const float* w_oihw, const float* scale, const float* shift,
+                         float* out, int out_ctot, int out_coff, int relu, int B, float* out_amax, void* stream,
+                         bool out16) {
   if (!lr || !w_oihw || !out || B <= 0 || axis_cnt != 3 || hin <= 0 || win <= 0 || sf <= 0) return TSR_ERR_ARG;
   if ((out_ctot & 15) || (out_coff & 15) || out_coff + 64 > out_ctot || lr_coff + axis_cnt > lr_ctot)
     return TSR_ERR_ARG;
@@ -166,15 +180,35 @@ extern "C" int tsr_stem_fwd(const float* lr, int lr_ctot, int lr_coff, int axis_
   if (RB == 0) return TSR_ERR_ARG;
   const size_t smem = fixed + (size_t)3 * (RB + 2) * WP * 4;
   dim3 grid((H + RB - 1) / RB, B);
-  hipLaunchKernelGGL((stem_kernel<3>), grid, dim3(256), smem, (hipStream_t)stream, lr, lr_ctot, lr_coff, hin,
-                     win, sf, w_oihw, scale, shift, out, out_ctot, out_coff, relu, B, RB, out_amax);
+  if (out16)
+    hipLaunchKernelGGL((stem_kernel<3, true>), grid, dim3(256), smem, (hipStream_t)stream, lr, lr_ctot, lr_coff, hin,
+                       win, sf, w_oihw, scale, shift, out, out_ctot, out_coff, relu, B, RB, out_amax);
+  else
+    hipLaunchKernelGGL((stem_kernel<3, false>), grid, dim3(256), smem, (hipStream_t)stream, lr, lr_ctot, lr_coff, hin,
+                       win, sf, w_oihw, scale, shift, out, out_ctot, out_coff, relu, B, RB, out_amax);
   return tsr_check_launch();
+}
+
+extern "C" int tsr_stem_fwd(const float* lr, int lr_ctot, int lr_coff, int axis_cnt, int hin, int win, int sf,
+                            const float* w_oihw, const float* scale, const float* shift,
+                            float* out, int out_ctot, int out_coff, int relu, int B, float* out_amax, void* stream) {
+  return stem_fwd_impl(lr, lr_ctot, lr_coff, axis_cnt, hin, win, sf, w_oihw, scale, shift, out, out_ctot, out_coff, relu,
+                       B, out_amax, stream, false);
+}
+
+// bf16 activation storage: the output is bf16 CB16 (`out` addresses bf16 elements)
+extern "C" int tsr_stem_fwd_b16(const float* lr, int lr_ctot, int lr_coff, int axis_cnt, int hin, int win, int sf,
+                                const float* w_oihw, const float* scale, const float* shift,
+                                void* out_bf16, int out_ctot, int out_coff, int relu, int B, void* stream) {
+  return stem_fwd_impl(lr, lr_ctot, lr_coff, axis_cnt, hin, win, sf, w_oihw, scale, shift, (float*)out_bf16, out_ctot,
+                       out_coff, relu, B, nullptr, stream, true);
 }
 
 // ---------------------------------------------------------------------------------------
 // Thread = (pixel, channel quad): the four lanes of a pixel read the four 16-B quarters of each 64-B CB16 line, so a
 // load instruction consumes whole lines (a lane per pixel reads every line in four instructions: 4x the L1 tag
 // work on an HBM-read-bound kernel); the partial dot products meet through two DPP adds.
+template <bool IN16>
 __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ in, int in_ctot, int cin,
                                                    const float* __restrict__ w,   // OIHW (1,cin,3,3)
                                                    float* __restrict__ out, int relu, int B, int H, int W) {
@@ -209,7 +243,9 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ in,
   const int in_blocks = in_ctot >> 4;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f;            // one accumulator per kernel row: three independent FMA chains
   for (int blk = 0; blk < nblk; ++blk) {
-    const float* plane = in + ((size_t)b * in_blocks + blk) * HW * 16 + 4 * q;
+    const size_t pidx = ((size_t)b * in_blocks + blk) * HW * 16 + 4 * q;
+    const float* plane = in + pidx;
+    const __bf16* plane16 = (const __bf16*)in + pidx;
     const float* wb = wl + blk * 9 * 16 + 4 * q;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
@@ -220,7 +256,14 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ in,
       for (int kw = 0; kw < 3; ++kw) {
         const int gx = x + kw - 1;
         if (gx < 0 || gx >= W) continue;
-        const f32x4 v = *(const f32x4*)(plane + (size_t)(gy * W + gx) * 16);
+        f32x4 v;
+        if (IN16) {
+          const sh_bf16x4 hvv = *(const sh_bf16x4*)(plane16 + (size_t)(gy * W + gx) * 16);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = (float)hvv[c];
+        } else {
+          v = *(const f32x4*)(plane + (size_t)(gy * W + gx) * 16);
+        }
         const f32x4 wv = *(const f32x4*)(wb + (kh * 3 + kw) * 16);
         s = fmaf(v[0], wv[0], fmaf(v[1], wv[1], fmaf(v[2], wv[2], fmaf(v[3], wv[3], s))));
       }
@@ -240,8 +283,20 @@ extern "C" int tsr_head_fwd(const float* in, int in_ctot, int cin, const float* 
     return TSR_ERR_ARG;
   dim3 grid((H * W + 63) / 64, B);
   const size_t smem = (size_t)cin * 9 * 4;
-  hipLaunchKernelGGL(head_kernel, grid, dim3(256), smem, (hipStream_t)stream, in, in_ctot, cin, w_oihw,
+  hipLaunchKernelGGL(head_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, in, in_ctot, cin, w_oihw,
                      out_nchw, relu, B, H, W);
+  return tsr_check_launch();
+}
+
+// bf16 activation storage: `in` is bf16 CB16; the image comes out fp32 NCHW as always
+extern "C" int tsr_head_fwd_b16(const void* in_bf16, int in_ctot, int cin, const float* w_oihw, float* out_nchw,
+                                int relu, int B, int H, int W, void* stream) {
+  if (!in_bf16 || !w_oihw || !out_nchw || B <= 0 || (cin & 15) || (in_ctot & 15) || cin > in_ctot || cin <= 0)
+    return TSR_ERR_ARG;
+  dim3 grid((H * W + 63) / 64, B);
+  const size_t smem = (size_t)cin * 9 * 4;
+  hipLaunchKernelGGL(head_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, (const float*)in_bf16, in_ctot, cin,
+                     w_oihw, out_nchw, relu, B, H, W);
   return tsr_check_launch();
 }
 

@@ -157,7 +157,9 @@ class TactileSR(nn.Module):
         #   "fp16x3" (default) 2 power-of-two-scaled fp16 planes, 3 f16-MFMA products: fp32-grade at 3/16 the fp32-MFMA cost
         #   "bf16x6"           3 bf16 planes, 6 bf16-MFMA products: fp32-equivalent, no scaling needed
         #   "f32"              fp32 MFMA (exact fp32 fma chain)
-        #   "bf16x3" / "bf16"  reduced precision (never the parity path)
+        #   "bf16x3"           reduced precision (never the parity path)
+        #   "bf16"             BASELINE's "bf16" configurations: bf16 ACTIVATION STORAGE in HBM + plain bf16 MFMA operands,
+        #                      fp32 accumulate (tolerance 2e-2; never the parity path)
         import os
         self.conv_impl = os.environ.get("TSR_CONV_IMPL", "fp16x3")
         assert self.conv_impl in CONV_IMPLS, self.conv_impl
@@ -211,7 +213,11 @@ class TactileSR(nn.Module):
         if prof is not None:     # bench.py: HIP-event bracket on the launch stream, per kernel instantiation
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if pc.nsplit == -2:
+        if pc.nsplit == 1 and src.dtype == torch.bfloat16:      # bf16 activation storage
+            call("tsr_conv2d_fwd_b16", ptr(src), _I(s_ctot), _I(s_coff), _I(pc.cin), ptr(pc.w), _I(pc.cout), _I(pc.ks),
+                 ptr(pc.scale), ptr(pc.shift), ptr(res), _I(r_ctot), _I(r_coff), ptr(dst), _I(d_ctot), _I(d_coff),
+                 _I(1 if relu else 0), _I(B), _I(H), _I(W), stream())
+        elif pc.nsplit == -2:
             call("tsr_conv2d_fwd_f16s", ptr(src), _I(s_ctot), _I(s_coff), _I(pc.cin), ptr(pc.w), _I(pc.cout),
                  _I(pc.ks), _lib.c_float(pc.w_inv_scale), ptr(amax_in), ptr(amax_out), ptr(pc.scale), ptr(pc.shift),
                  ptr(res), _I(r_ctot), _I(r_coff), ptr(dst), _I(d_ctot), _I(d_coff), _I(1 if relu else 0),
@@ -237,8 +243,20 @@ class TactileSR(nn.Module):
         HW = H * W
         dev = x.device
 
+        io16 = self.conv_impl == "bf16"       # activations stored as bf16 CB16 between the kernels
+        if io16 and (len(plan["msrb"]) == 0 or len(plan["res"]) == 0):
+            raise _lib.TactileSRHipError("the bf16-storage path needs at least one MSRB and one ResBlock")
+
         def buf(c):
-            return torch.empty(B * c * HW, dtype=torch.float32, device=dev)
+            return torch.empty(B * c * HW, dtype=torch.bfloat16 if io16 else torch.float32, device=dev)
+
+        def stem(coff, w1, s1, sh1, dst, slot_):
+            if io16:
+                call("tsr_stem_fwd_b16", ptr(x), _I(ctot), _I(coff), _I(A), _I(hin), _I(win), _I(sf), ptr(w1), ptr(s1),
+                     ptr(sh1), ptr(dst), _I(64), _I(0), _I(1), _I(B), stream())
+            else:
+                call("tsr_stem_fwd", ptr(x), _I(ctot), _I(coff), _I(A), _I(hin), _I(win), _I(sf), ptr(w1), ptr(s1),
+                     ptr(sh1), ptr(dst), _I(64), _I(0), _I(1), _I(B), ptr(slot_), stream())
 
         ctot = x.shape[1]
         # fp16-split path: one device scalar per logical activation tensor holds max|x| (atomic max by the
@@ -259,8 +277,7 @@ class TactileSR(nn.Module):
         s_catT = slot()
         for t, (w1, s1, sh1, pc2) in enumerate(plan["stems"]):
             s_stem = slot()
-            call("tsr_stem_fwd", ptr(x), _I(ctot), _I(A * t), _I(A), _I(hin), _I(win), _I(sf), ptr(w1), ptr(s1),
-                 ptr(sh1), ptr(stemA), _I(64), _I(0), _I(1), _I(B), ptr(s_stem), stream())
+            stem(A * t, w1, s1, sh1, stemA, s_stem)
             self._conv(pc2, stemA, 64, 0, catT, 64 * T, 64 * t, True, B, H, W, amax_in=s_stem, amax_out=s_catT)
         xa, xb = buf(64), buf(64)
         s_x = slot()
@@ -299,8 +316,7 @@ class TactileSR(nn.Module):
         # force branch
         f0, f1 = buf(64), buf(64)
         s_f = slot()
-        call("tsr_stem_fwd", ptr(x), _I(ctot), _I(0), _I(A), _I(hin), _I(win), _I(sf), ptr(plan["force_w"]),
-             ptr(None), ptr(None), ptr(f0), _I(64), _I(0), _I(1), _I(B), ptr(s_f), stream())
+        stem(0, plan["force_w"], None, None, f0, s_f)
         if stages is not None:
             stages["force_in"] = (f0.clone(), 64, 0)
         n_res = len(plan["res"])
@@ -327,8 +343,8 @@ class TactileSR(nn.Module):
         if stages is not None:
             stages["force"] = (hcat, 128, 0)
             stages["head0"] = (h0, 128, 0)
-        call("tsr_head_fwd", ptr(h0), _I(128), _I(128), ptr(plan["head_w"]), ptr(out), _I(1), _I(B), _I(H), _I(W),
-             stream())
+        call("tsr_head_fwd_b16" if io16 else "tsr_head_fwd", ptr(h0), _I(128), _I(128), ptr(plan["head_w"]), ptr(out),
+             _I(1), _I(B), _I(H), _I(W), stream())
 
     def forward(self, x):
         assert x.shape[1] == self.seqsCnt * self.axisCnt, "input channel should be same with seqsCnt x axisCnt!"
@@ -386,6 +402,9 @@ class TactileSR(nn.Module):
 
 
 def _to_nchw(t, B, C, HW, ctot, coff):
+    if t.dtype == torch.bfloat16:      # bf16-storage probes: plain tensor ops (test plumbing only)
+        v = t.view(B, ctot // 16, HW, 16)[:, coff // 16:(coff + C) // 16]
+        return v.permute(0, 1, 3, 2).reshape(B * C * HW).float()
     dst = torch.empty(B * C * HW, dtype=torch.float32, device=t.device)
     call("tsr_cb16_to_nchw", ptr(t), ptr(dst), _I(B), _I(C), _I(HW), _I(ctot), _I(coff), stream())
     return dst
