@@ -94,13 +94,14 @@ def host_cores():
     return max(1, min(16, avail))
 
 
-def pmc_traffic(kernel_substr):
+def pmc_traffic(kernel_substr, mode="eval"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/rNN_pmc_summary.json, made by tools/summarize_prof.py: separate --pmc
+    (profiles/rNN[_train]_pmc_summary.json, made by tools/collect_profiles.sh + tools/summarize_prof.py: separate --pmc
     FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 FETCH x2 correction).  PMC
     counters cannot be read from inside the process, so bench.py cites the latest pass."""
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_summary.json")))
+    pat = "r[0-9][0-9]_pmc_summary.json" if mode == "eval" else f"r[0-9][0-9]_{mode}_pmc_summary.json"
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", pat)))
     if not files:
         return None, None
     d = json.load(open(files[-1]))
@@ -224,7 +225,8 @@ def main():
         traffic, traffic_src = pmc_traffic(kname) if B == 4096 else (None, None)
         dtype = {"fp16x3": "f32 as 2 power-of-two-scaled fp16 planes x 3 MFMA products, fp32 accumulate (fp32-grade)",
                  "bf16x6": "f32 as 3 bf16 planes x 6 MFMA products, fp32 accumulate (fp32-equivalent)",
-                 "f32": "f32", "bf16x3": "bf16x3 (reduced: ~16 significand bits)", "bf16": "bf16"}[args.impl]
+                 "f32": "f32", "bf16x3": "bf16x3 (reduced: ~16 significand bits)",
+                 "bf16": "bf16 activation storage + bf16 MFMA operands, fp32 accumulate (reduced precision: 3e-2)"}[args.impl]
         res = {
             "metric": "SR samples/sec (4x4->%dx%d)" % (side, side), "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -246,7 +248,7 @@ def main():
                          "mfma_pipe_util": round(executed / peak, 4) if executed else None,
                          "algorithmic_vs_f32_mfma_peak": round(alg / PEAK_F32_MFMA, 4) if alg else None,
                          "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": B * (2 * 128 * side * side * 4) + 128 * 128 * 25 * 4,
+                         "algorithmic_bytes_per_launch": B * (2 * 128 * side * side * (2 if args.impl == "bf16" else 4)) + 128 * 128 * 25 * 4,
                          "avg_launch_ms": round(c5_ms, 3), "launches_timed": len(ev)},
             "whole_step": {"algorithmic_tflops": round(value / world * fwd_flop / 1e12, 2),
                            "frac_of_peak": round(value / world * fwd_flop / peak, 4),
@@ -331,8 +333,8 @@ def main_train(args):
         for k, v in prof.items():
             fam.setdefault(k[0], 0.0)
             fam[k[0]] += sum(a.elapsed_time(b) for a, b in v) / args.steps
-        wname = "wgrad_mfma_bf16s_kernel<5" if impl != "f32" else "wgrad_mfma_f32_kernel<5"
-        traffic, traffic_src = pmc_traffic(wname) if B == 2048 and not args.seqs else (None, None)
+        wname = "wgrad_tr16_kernel<5, 1, 128, 128" if impl != "f32" else "wgrad_mfma_f32_kernel<5"
+        traffic, traffic_src = pmc_traffic(wname, "train") if B == 2048 and not args.seqs else (None, None)
         res = {
             "metric": "SR train samples/sec (4x4->%dx%d)" % (side, side), "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -343,8 +345,8 @@ def main_train(args):
             "data": "synthetic",
             "config": {"workload": ("tactileSRSeqs (T=8, 100x100) " if args.seqs else "TactileSR ") +
                        "train step (train_cal_loss + backward + Adam L2), fp32 params/activations, batch/GPU=%d "
-                       "(BASELINE configs[%s])" % (B, "4] shape" if args.seqs else
-                                                   ("3] per-GPU batch" if B == 8192 else "3] is 8192/GPU: pass --batch 8192")),
+                       "(BASELINE configs[%s" % (B, "4] shape)" if args.seqs else
+                                                   ("3] per-GPU batch)" if B == 8192 else "3] is 8192/GPU: pass --batch 8192)")),
                        "batch_per_gpu": B, "parallelism": f"dp{world}",
                        "grad_allreduce_MB": round(sum(p.numel() for p in model.parameters()) * 4 / 1e6, 2),
                        "grad_buckets": len(eng.arena.buckets) if eng.arena is not None else None,
@@ -364,7 +366,7 @@ def main_train(args):
                            "mfma_pipe_util": round(value / world * train_flop * nprod / peak, 4),
                            "algorithmic_vs_f32_mfma_peak": round(value / world * train_flop / PEAK_F32_MFMA, 4),
                            "ms_per_step_by_family": {k: round(v, 2) for k, v in sorted(fam.items())}},
-            "loss": float(ld["total_loss"]),
+            "loss": float(ld["total_loss"].detach()),
         }
         if world == 1 and not args.no_cpu_baseline and not args.seqs:
             res["cpu_baseline"] = cpu_train_baseline()
