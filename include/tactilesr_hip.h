@@ -90,6 +90,19 @@ int tsr_conv2d_fwd_f16s(const float* in, int in_ctot, int in_coff, int cin,
                         const float* res, int res_ctot, int res_coff,
                         float* out, int out_ctot, int out_coff, int relu,
                         int B, int H, int W, void* stream);
+/* MSRB stage-2 convolution with its half of the 1x1 `confusion` conv fused (model/tactileSR_model.py:196-206; no
+ * `cat2` tensor in HBM).  W_c = [W_a | W_b]:  P = W_a.relu(bn(conv3(x1))) + b_c + x  (3x3 launch: w2 = W_a, shift2 = b_c,
+ * res = x, relu2 = 0), out = relu(W_b.relu(bn(conv5(x1))) + P)  (5x5 launch: w2 = W_b, res = P, relu2 = 1).
+ * fp16x3 arithmetic; the conv has C_out = 128; w2_packed = tsr_pack_conv_weight_f16s of the 64x128x1x1 half;
+ * `out` / `res` / `out_amax` describe the 64-channel result. */
+int tsr_conv2d_fwd_f16s_fuse1x1(const float* in, int in_ctot, int in_coff, int cin,
+                                const void* w_packed, int ks, float w_inv_scale,
+                                const float* in_amax, float* out_amax,
+                                const float* scale, const float* shift, int relu,
+                                const void* w2_packed, float w2_inv_scale, const float* shift2,
+                                const float* res, int res_ctot, int res_coff,
+                                float* out, int out_ctot, int out_coff, int relu2,
+                                int B, int H, int W, void* stream);
 /* bf16 ACTIVATION STORAGE (BASELINE's "bf16" configurations: reduced precision, tolerance 2e-2, never the parity path).
  * Activations are bf16 CB16 tensors -- `in` / `res` / `out` address bf16 elements, same [B][C/16][H*W][16] order --
  * weights the one-plane pack of tsr_pack_conv_weight_bf16s(nsplit = 1), fp32 accumulation and epilogue arithmetic

@@ -28,5 +28,10 @@ struct ConvArgs {
   const float* in_amax;   // device scalar: max |input activation| (written by the producer) -> input scale 2^k
   float w_inv_scale;      // 1 / (power-of-two weight scale applied at pack time); 0 = unused
   float* out_amax;        // device scalar: atomic max of |output| after the epilogue (for the consumer)
+  // ---- fused second GEMM (conv_fuse1x1.h; inference, fp16x3, C_out = 128): out = act2(W2 . act(bn(conv)) + shift2 + res)
+  const void* w2;         // 64 x 128 x 1 x 1 weight packed by tsr_pack_conv_weight_f16s; out / res then describe 64 channels
+  float w2_inv_scale;     // 1 / (its pack-time power-of-two scale)
+  const float* shift2;    // optional per-channel bias of the second GEMM
+  int relu2;
   const float* w_amax;    // optional device scalar max|w|: the pack-time weight scale is re-derived from it (replaces w_inv_scale)
 };

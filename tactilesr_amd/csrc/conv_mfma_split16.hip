@@ -23,6 +23,7 @@
 #include "tsr_common.h"
 #include "conv_args.h"
 #include "conv_epilogue.h"
+#include "conv_fuse1x1.h"
 #include "tactilesr_hip.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -72,9 +73,12 @@ constexpr int row_slots(int hh, int pixs, int rmod) {
 // like any other tap's.  Blocks are processed in pairs: buffer and fragment-set parity stay compile-time.
 // IO16 (NS = 1 only, inference): activations live in HBM as bf16 CB16 -- the halo slab is COPIED into LDS (8 B per
 // (pixel, channel quad), no conversion), the epilogue rounds to bf16 on store.  BASELINE's "bf16" configurations.
-template <int KS, int COUT, int NS, bool EXT, bool F16, int WN, bool DBH = false, bool IO16 = false>
+// FUSE2 (fp16x3, C_out = 128, inference): the MSRB's 1x1 `confusion` half is applied to the tile before it leaves the
+// workgroup (conv_fuse1x1.h); out / res then describe the 64-channel result.
+template <int KS, int COUT, int NS, bool EXT, bool F16, int WN, bool DBH = false, bool IO16 = false, bool FUSE2 = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArgs a) {
   static_assert(!IO16 || (NS == 1 && !F16 && !EXT), "bf16 activation storage: plain bf16 operands, inference epilogue");
+  static_assert(!FUSE2 || (NS == 2 && F16 && !EXT && COUT == 128 && WN == 2), "fused 1x1: fp16x3, 128 channels, inference");
   typedef typename Plane<F16>::T PT;
   typedef typename Plane<F16>::V8 PV8;
   typedef typename Plane<F16>::V4 PV4;
@@ -102,7 +106,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
 
   static_assert(!DBH || (NSTEP >= 3 && (T & 1)), "double-buffered halo needs >= 3 steps per block and an odd tap count");
   constexpr int NHB = DBH ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) char lds[NHB * HALO_B + 3 * WSLAB_B];
+  constexpr int MAIN_LDS = NHB * HALO_B + 3 * WSLAB_B;
+  constexpr int FUSE_LDS = FUSE2 ? Fuse1x1Geom::BYTES + 64 : 0;
+  __shared__ __attribute__((aligned(16))) char lds[MAIN_LDS > FUSE_LDS ? MAIN_LDS : FUSE_LDS];
   char* halo = lds;
   char* wbuf = lds + NHB * HALO_B;  // 3-slot ring: slab s lives in slot s % 3
 
@@ -371,7 +377,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
 #undef STORE_W
 #undef LOAD_FRAGS
 
-  conv_epilogue<COUT, EXT, WN, IO16>(a, acc, bid, b0, y0, x0, wm, wn, h, li, HW, accmul);
+  if constexpr (FUSE2) conv_fuse1x1_epilogue(a, acc, lds, b0, y0, x0, wm, wn, h, li, HW, accmul);
+  else conv_epilogue<COUT, EXT, WN, IO16>(a, acc, bid, b0, y0, x0, wm, wn, h, li, HW, accmul);
 }
 
 // OIHW fp32 -> [C_in/16][step][tap in step][plane][2 (k half)][C_out][8] bf16 split planes; taps are
@@ -565,6 +572,44 @@ extern "C" int tsr_conv2d_fwd_bf16s(const float* in, int in_ctot, int in_coff, i
   if (nsplit == 3) return dispatch_bf16s<3, false>(a, cout, ks, st);
   if (nsplit == 2) return dispatch_bf16s<2, false>(a, cout, ks, st);
   return dispatch_bf16s<1, false>(a, cout, ks, st);
+}
+
+// Stage-2 convolution of an MSRB with its half of the 1x1 `confusion` fused (conv_fuse1x1.h): fp16x3 arithmetic,
+// C_out = 128, ks = 3 or 5; out / res describe the 64-channel result of the fused second GEMM.
+extern "C" int tsr_conv2d_fwd_f16s_fuse1x1(const float* in, int in_ctot, int in_coff, int cin,
+                                           const void* w_packed, int ks, float w_inv_scale,
+                                           const float* in_amax, float* out_amax,
+                                           const float* scale, const float* shift, int relu,
+                                           const void* w2_packed, float w2_inv_scale, const float* shift2,
+                                           const float* res, int res_ctot, int res_coff,
+                                           float* out, int out_ctot, int out_coff, int relu2,
+                                           int B, int H, int W, void* stream) {
+  if (!in || !w_packed || !w2_packed || !out || !in_amax || B <= 0 || H <= 0 || W <= 0 || !(w_inv_scale > 0.f) ||
+      !(w2_inv_scale > 0.f) || (ks != 3 && ks != 5))
+    return TSR_ERR_ARG;
+  if ((cin & 15) || (in_ctot & 15) || (in_coff & 15) || (out_ctot & 15) || (out_coff & 15) || cin <= 0 ||
+      in_coff + cin > in_ctot || out_coff + 64 > out_ctot)
+    return TSR_ERR_ARG;
+  if (res && ((res_ctot & 15) || (res_coff & 15) || res_coff + 64 > res_ctot)) return TSR_ERR_ARG;
+  ConvArgs a = {};
+  a.in = in; a.in_ctot = in_ctot; a.in_coff = in_coff; a.cin = cin;
+  a.wp = (const float*)w_packed; a.scale = scale; a.shift = shift; a.relu = relu;
+  a.res = res; a.res_ctot = res_ctot; a.res_coff = res_coff;
+  a.out = out; a.out_ctot = out_ctot; a.out_coff = out_coff;
+  a.B = B; a.H = H; a.W = W;
+  a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8;
+  a.in_amax = in_amax; a.w_inv_scale = w_inv_scale; a.out_amax = out_amax;
+  a.w2 = w2_packed; a.w2_inv_scale = w2_inv_scale; a.shift2 = shift2; a.relu2 = relu2;
+  const int grid = ((B + 1) / 2) * a.tiles_x * a.tiles_y;
+  hipStream_t st = (hipStream_t)stream;
+  if (ks == 5) {
+    hipLaunchKernelGGL((conv_mfma_split16_kernel<5, 128, 2, false, true, 2, false, false, true>), dim3(grid), dim3(256), 0, st, a);
+  } else if (((cin >> 4) & 1) == 0) {
+    hipLaunchKernelGGL((conv_mfma_split16_kernel<3, 128, 2, false, true, 2, true, false, true>), dim3(grid), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((conv_mfma_split16_kernel<3, 128, 2, false, true, 2, false, false, true>), dim3(grid), dim3(256), 0, st, a);
+  }
+  return tsr_check_launch();
 }
 
 // bf16 activation storage (BASELINE's "bf16" configurations; reduced precision, never the parity path): `in`, `res`

@@ -102,6 +102,21 @@ class _PackedConv:
         self.scale, self.shift = _fold(conv.bias, bn, self.cout, w.device)
 
 
+class _PackedHalf:
+    """One 64x128x1x1 half of an MSRB's `confusion` weight in the fp16 two-plane pack (fused 1x1 epilogue)."""
+    __slots__ = ("w", "w_inv_scale")
+
+    def __init__(self, w: torch.Tensor):
+        import math
+        w = w.float().contiguous()
+        m = float(w.abs().max())
+        wscale = 2.0 ** (13 - math.floor(math.log2(m))) if m > 0 else 1.0
+        self.w_inv_scale = 1.0 / wscale
+        n = _lib.load().tsr_conv_weight_bf16s_elems(64, 128, 1, 2)
+        self.w = torch.empty(n, dtype=torch.float16, device=w.device)
+        call("tsr_pack_conv_weight_f16s", ptr(w), ptr(self.w), _I(64), _I(128), _I(1), _lib.c_float(wscale), stream())
+
+
 def _fold(bias, bn: Optional[nn.BatchNorm2d], cout: int, device):
     """Eval-mode BatchNorm2d folded onto the conv output: y = conv*scale + shift with
     scale = gamma/sqrt(var+eps), shift = (bias-mean)*scale + beta."""
@@ -165,6 +180,9 @@ class TactileSR(nn.Module):
         assert self.conv_impl in CONV_IMPLS, self.conv_impl
         # arithmetic of output_layer.0 (the 128->128 conv in front of the cancellation-heavy 128->1 head); None = conv_impl
         self.head_impl = os.environ.get("TSR_HEAD_IMPL") or None
+        # fp16x3 eval: apply each half of an MSRB's 1x1 `confusion` inside the stage-2 conv that produced its input
+        # (csrc/conv_fuse1x1.h): `cat2` never exists in HBM.  TSR_FUSE1X1=0 keeps the separate 1x1 launches (A/B).
+        self.fuse_1x1 = os.environ.get("TSR_FUSE1X1", "1") != "0"
         self.max_images_per_pass = 4096   # workspace bound: ~6.6 MB of CB16 activations per image
 
     def make_layer(self, block, num_of_layer):
@@ -175,7 +193,7 @@ class TactileSR(nn.Module):
 
     # ------------------------------------------------------------------ engine
     def _param_key(self):
-        return (self.conv_impl, self.head_impl, _lib.param_epoch()) + tuple((t.data_ptr(), t._version)
+        return (self.conv_impl, self.head_impl, self.fuse_1x1, _lib.param_epoch()) + tuple((t.data_ptr(), t._version)
                                          for t in list(self.parameters()) + list(self.buffers()))
 
     def _build_plan(self):
@@ -190,9 +208,12 @@ class TactileSR(nn.Module):
         plan["fuse"] = _PackedConv(self.inputContact_layer[0], self.inputContact_layer[1], ns)
         msrbs = []
         for blk in self.patternFeatureExtra_layer:
+            halves = None
+            if ns == -2 and self.fuse_1x1:      # the two 64x128 halves of the 1x1, each packed like a 1x1 conv weight
+                halves = tuple(_PackedHalf(blk.confusion.weight.detach()[:, o:o + 128]) for o in (0, 128))
             msrbs.append((_PackedConv(blk.conv_3_1[0], blk.conv_3_1[1], ns), _PackedConv(blk.conv_5_1[0], blk.conv_5_1[1], ns),
                           _PackedConv(blk.conv_3_2[0], blk.conv_3_2[1], ns), _PackedConv(blk.conv_5_2[0], blk.conv_5_2[1], ns),
-                          _PackedConv(blk.confusion, None, ns)))
+                          _PackedConv(blk.confusion, None, ns), halves))
         plan["msrb"] = msrbs
         plan["force_w"] = self.input_layer_force[1].weight.detach().float().contiguous()
         plan["res"] = [(_PackedConv(b.conv1, None, ns), _PackedConv(b.conv2, None, ns)) for b in self.forceFeatureExtra_layer]
@@ -230,6 +251,21 @@ class TactileSR(nn.Module):
             call("tsr_conv2d_fwd_bf16s", ptr(src), _I(s_ctot), _I(s_coff), _I(pc.cin), ptr(pc.w), _I(pc.cout),
                  _I(pc.ks), _I(pc.nsplit), ptr(pc.scale), ptr(pc.shift), ptr(res), _I(r_ctot), _I(r_coff),
                  ptr(dst), _I(d_ctot), _I(d_coff), _I(1 if relu else 0), _I(B), _I(H), _I(W), stream())
+        if prof is not None:
+            e1.record()
+            prof.setdefault((pc.ks, pc.cout), []).append((e0, e1))
+
+    def _conv_fused(self, pc: _PackedConv, half: "_PackedHalf", shift2, src, dst, d_ctot, d_coff, res, r_ctot, r_coff,
+                    relu2, amax_out, amax_in, B, H, W):
+        """Stage-2 conv (128 -> 128, BN + ReLU) + its half of the 1x1 confusion + residual (+ ReLU), one launch."""
+        prof = self._profile
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        call("tsr_conv2d_fwd_f16s_fuse1x1", ptr(src), _I(128), _I(0), _I(128), ptr(pc.w), _I(pc.ks),
+             _lib.c_float(pc.w_inv_scale), ptr(amax_in), ptr(amax_out), ptr(pc.scale), ptr(pc.shift), _I(1),
+             ptr(half.w), _lib.c_float(half.w_inv_scale), ptr(shift2), ptr(res), _I(r_ctot), _I(r_coff),
+             ptr(dst), _I(d_ctot), _I(d_coff), _I(1 if relu2 else 0), _I(B), _I(H), _I(W), stream())
         if prof is not None:
             e1.record()
             prof.setdefault((pc.ks, pc.cout), []).append((e0, e1))
@@ -288,20 +324,39 @@ class TactileSR(nn.Module):
         del stemA
         hcat = buf(128)
         s_hcat = slot()
-        cat1, cat2 = buf(128), buf(256)
         n_msrb = len(plan["msrb"])
+        fused = n_msrb > 0 and plan["msrb"][0][5] is not None
+        cat1, cat2 = buf(128), (None if fused else buf(256))
         cur = xa
         if n_msrb == 0:
             call("tsr_cb16_to_nchw", ptr(xa), ptr(xb), _I(B), _I(64), _I(HW), _I(64), _I(0), stream())
             call("tsr_nchw_to_cb16", ptr(xb), ptr(hcat), _I(B), _I(64), _I(HW), _I(128), _I(64), stream())
-        for i, (c31, c51, c32, c52, conf) in enumerate(plan["msrb"]):
+        p1 = None
+        for i, (c31, c51, c32, c52, conf, halves) in enumerate(plan["msrb"]):
             last = i == n_msrb - 1
             s_c1, s_c2 = slot(), slot()
             self._conv(c31, cur, 64, 0, cat1, 128, 0, True, B, H, W, amax_in=s_x, amax_out=s_c1)
             self._conv(c51, cur, 64, 0, cat1, 128, 64, True, B, H, W, amax_in=s_x, amax_out=s_c1)
+            nxt = xb if cur is xa else xa
+            if halves is not None:
+                # stage 2 with the 1x1 fused: P = W_a.relu(bn(conv3)) + b + x ; out = relu(W_b.relu(bn(conv5)) + P)
+                if p1 is None:
+                    p1 = buf(64)
+                if last:
+                    dst, d_ctot, d_coff, s_out = hcat, 128, 64, s_hcat
+                else:
+                    s_x_new = slot()
+                    dst, d_ctot, d_coff, s_out = nxt, 64, 0, s_x_new
+                self._conv_fused(c32, halves[0], conf.shift, cat1, p1, 64, 0, cur, 64, 0, False, None, s_c1, B, H, W)
+                self._conv_fused(c52, halves[1], None, cat1, dst, d_ctot, d_coff, p1, 64, 0, True, s_out, s_c1, B, H, W)
+                if not last:
+                    s_x = s_x_new
+                    cur = nxt
+                if stages is not None:
+                    stages[f"msrb{i}"] = (hcat.clone(), 128, 64) if last else (cur.clone(), 64, 0)
+                continue
             self._conv(c32, cat1, 128, 0, cat2, 256, 0, True, B, H, W, amax_in=s_c1, amax_out=s_c2)
             self._conv(c52, cat1, 128, 0, cat2, 256, 128, True, B, H, W, amax_in=s_c1, amax_out=s_c2)
-            nxt = xb if cur is xa else xa
             if last:   # pattern feature lands in channels [64,128) of the head input (cat: force first)
                 self._conv(conf, cat2, 256, 0, hcat, 128, 64, True, B, H, W, res=cur, r_ctot=64, r_coff=0,
                            amax_in=s_c2, amax_out=s_hcat)

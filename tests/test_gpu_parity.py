@@ -421,3 +421,70 @@ def test_bf16_storage_batch4096_tiling_invariance(T):
     e = relerr(y[0], ref)
     print(f"[bf16 storage] B=4096: {e:.2e}")
     assert e < 3e-2
+
+
+@pytest.mark.parametrize("ks,cin,B,H,W,relu2,with_res,with_bias", [
+    (3, 128, 2, 40, 40, False, True, True), (5, 128, 3, 40, 40, True, True, False), (5, 128, 1, 13, 21, True, False, True),
+    (3, 128, 5, 100, 100, True, True, True), (3, 48, 2, 16, 24, False, False, False)])
+def test_conv2d_fused_1x1_epilogue(T, ks, cin, B, H, W, relu2, with_res, with_bias):
+    """tsr_conv2d_fwd_f16s_fuse1x1: stage-2 conv (-> 128 ch, BN fold + ReLU) with a 64x128 1x1 GEMM, bias, residual and
+    optional ReLU applied before the tile leaves the workgroup -- against fp64, fp32-grade bar, ragged tiles and odd
+    batches (out-of-image pixels of a partial tile must not leak into the tile-local operand scale or the output)."""
+    import math
+    from tactilesr_amd._lib import call, ptr, stream, load, c_int as I, c_float as Fl
+    g = torch.Generator().manual_seed(ks * 31 + cin + B + H)
+    x = torch.randn(B, cin, H, W, generator=g) * 2
+    w = torch.randn(128, cin, ks, ks, generator=g) * (2.0 / (128 * ks * ks)) ** 0.5
+    scale, shift = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.3
+    w2 = torch.randn(64, 128, 1, 1, generator=g) * (2.0 / 64) ** 0.5
+    b2 = torch.randn(64, generator=g) * 0.2 if with_bias else None
+    res = torch.randn(B, 64, H, W, generator=g) if with_res else None
+    a = F.relu(F.conv2d(x.double(), w.double(), padding=ks // 2) * scale.double().view(1, -1, 1, 1)
+               + shift.double().view(1, -1, 1, 1))
+    ref = F.conv2d(a, w2.double(), b2.double() if with_bias else None)
+    if with_res:
+        ref = ref + res.double()
+    if relu2:
+        ref = F.relu(ref)
+    lib = load()
+
+    def pack(wt, cout, cin_, k):
+        ws = 2.0 ** (13 - math.floor(math.log2(float(wt.abs().max()))))
+        wp = torch.empty(lib.tsr_conv_weight_bf16s_elems(cout, cin_, k, 2), dtype=torch.float16, device="cuda")
+        wd = wt.cuda().contiguous()
+        call("tsr_pack_conv_weight_f16s", ptr(wd), ptr(wp), I(cout), I(cin_), I(k), Fl(ws), stream())
+        return wp, 1.0 / ws
+
+    wp, wis = pack(w, 128, cin, ks)
+    w2p, w2is = pack(w2, 64, 128, 1)
+    xin = T.to_cb16(x.cuda(), cin + 16, 16)
+    rbuf = T.to_cb16(res.cuda(), 80, 16) if with_res else None
+    amax_in, amax_out = x.abs().max().reshape(1).cuda(), torch.zeros(1, device="cuda")
+    out = torch.full((B * 96 * H * W,), float("nan"), device="cuda")
+    sc, sh = scale.cuda(), shift.cuda()
+    b2d = b2.cuda() if with_bias else None
+    call("tsr_conv2d_fwd_f16s_fuse1x1", ptr(xin), I(cin + 16), I(16), I(cin), ptr(wp), I(ks), Fl(wis), ptr(amax_in),
+         ptr(amax_out), ptr(sc), ptr(sh), I(1), ptr(w2p), Fl(w2is), ptr(b2d), ptr(rbuf), I(80 if with_res else 0),
+         I(16 if with_res else 0), ptr(out), I(96), I(16), I(int(relu2)), I(B), I(H), I(W), stream())
+    got = T.from_cb16(out, B, 64, H, W, 96, 16)
+    err = relerr(got, ref)
+    print(f"[fused 1x1] k{ks} cin{cin} B{B} {H}x{W}: {err:.2e}")
+    assert err < TOL
+    assert float(amax_out) == float(got.abs().max())
+    assert torch.isnan(T.from_cb16(out, B, 16, H, W, 96, 0)).all() and torch.isnan(T.from_cb16(out, B, 16, H, W, 96, 80)).all()
+
+
+def test_fused_and_unfused_1x1_paths_agree(T, golden):
+    """model.fuse_1x1 on/off: two fp32-grade evaluations of the same MSRB arithmetic (the fused form splits the tile with
+    a tile-local scale instead of the tensor-wide one): within the sum of their 1e-5 bars."""
+    g = golden("eval")
+    sd = O.random_state_dict(O.tactilesr_state_shapes(), int(g["t1/seed"]))
+    m = T.TactileSR()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    LR = torch.rand(5, 3, 4, 4, device="cuda") * 8
+    m.fuse_1x1 = True
+    y1 = m(LR)
+    m.fuse_1x1 = False
+    y0 = m(LR)
+    assert not torch.equal(y0, y1) and relerr(y1, y0) < 2 * TOL
