@@ -1,0 +1,93 @@
+"""Two data-parallel ranks of the REAL HIP engine on one MI355X (two processes sharing the card, gloo backend -- it
+moves CUDA tensors through the host; RCCL cannot put two ranks on one device and the pool leases one GPU).  What it
+pins: the gradient arena + in-backward bucket all-reduce of tactilesr_amd.ddp on the engine's own backward, across real
+process boundaries: synced gradient = mean of the per-rank gradients (rank-local BatchNorm statistics, SURVEY.md
+section 5), every bucket enqueued before backward returns from the second step on, identical weights on both ranks after
+the fused Adam step, parameter AND buffer broadcast at start."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import tactilesr_amd
+    from tactilesr_amd import ddp, optim
+    ddp.init_distributed("gloo")
+    torch.cuda.set_device(0)
+    cfg = dict(patternFeatureExtraLayerCnt=1)
+    torch.manual_seed(1000 + rank)                        # replicas start different on purpose
+    m = tactilesr_amd.TactileSR(**cfg).cuda().train()
+    with torch.no_grad():
+        for bn in [mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm2d)]:
+            bn.running_mean.fill_(0.25 * (rank + 1))
+    sync = ddp.GradSync(m)
+    sync.broadcast_parameters(0)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    LR, HR = torch.rand(6, 3, 4, 4, generator=g) * 8, torch.rand(6, 1, 40, 40, generator=g) * 25
+    a, b = ddp.shard_batch(6, rank, world)
+    x, y = LR[a:b].cuda(), HR[a:b].cuda()
+    # this rank's un-synced gradient on its shard (fresh replica, same weights)
+    ref = tactilesr_amd.TactileSR(**cfg).cuda().train()
+    ref.load_state_dict(sd0)
+    F.mse_loss(ref(x), y).backward()
+    local = torch.cat([p.grad.flatten() for p in ref.parameters()])
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    expect = sum(gathered) / world
+    opt = optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-2)
+    res = {"rank": rank, "bn_mean": float(next(iter(sd0[k] for k in sd0 if k.endswith("running_mean")))[0]),
+           "w0": float(torch.cat([v.flatten().double() for k, v in sd0.items() if v.is_floating_point()]).sum())}
+    ok, events = [], []
+    for step in range(2):
+        m.load_state_dict(sd0)                            # same weights and BN statistics every step
+        opt.zero_grad()
+        sync.events.clear()
+        F.mse_loss(m(x), y).backward()
+        events.append(list(sync.events))
+        sync.finish()
+        got = torch.cat([p.grad.flatten() for p in m.parameters()])
+        ok.append(bool(torch.allclose(got, expect, rtol=0, atol=1e-6 * float(expect.abs().max()))))
+    opt.step()
+    torch.cuda.synchronize()
+    w1 = torch.cat([p.detach().flatten() for p in m.parameters()])
+    both = [torch.zeros_like(w1) for _ in range(world)]
+    dist.all_gather(both, w1)
+    res.update(ok=ok, events=events, nb=len(m.train_engine().arena.buckets),
+               same_weights=bool(torch.equal(both[0], both[1])), moved=bool(not torch.equal(w1, torch.cat(
+                   [sd0[k].flatten() for k, _ in m.named_parameters()]))))
+    q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_engine_gradsync_on_one_gpu():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda r: r["rank"])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0]["w0"] == res[1]["w0"] and res[1]["bn_mean"] == 0.25            # params + buffers = rank 0's
+    for r in res:
+        assert r["ok"] == [True, True], r
+        nb = r["nb"]
+        assert r["events"][0] == []                                              # first step: arena laid out at its end
+        assert r["events"][1] == [("enqueue", k) for k in range(nb)], r["events"] # then: all buckets from inside backward
+        assert r["same_weights"] and r["moved"]
