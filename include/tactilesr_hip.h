@@ -111,6 +111,14 @@ int tsr_conv2d_fwd_f16s_fuse1x1(const float* in, int in_ctot, int in_coff, int c
 int tsr_conv2d_fwd_b16(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed, int cout, int ks,
                        const float* scale, const float* shift, const void* res, int res_ctot, int res_coff,
                        void* out, int out_ctot, int out_coff, int relu, int B, int H, int W, void* stream);
+/* ... and its stage-2 form with half of the 1x1 `confusion` fused (see tsr_conv2d_fwd_f16s_fuse1x1; w2_packed =
+ * tsr_pack_conv_weight_bf16s(nsplit = 1) of the 64x128x1x1 half; res / out are 64-channel bf16 tensors). */
+int tsr_conv2d_fwd_b16_fuse1x1(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed, int ks,
+                               const float* scale, const float* shift, int relu,
+                               const void* w2_packed, const float* shift2,
+                               const void* res, int res_ctot, int res_coff,
+                               void* out, int out_ctot, int out_coff, int relu2,
+                               int B, int H, int W, void* stream);
 int tsr_stem_fwd_b16(const float* lr, int lr_ctot, int lr_coff, int axis_cnt, int hin, int win, int sf,
                      const float* w_oihw, const float* scale, const float* shift,
                      void* out_bf16, int out_ctot, int out_coff, int relu, int B, void* stream);

@@ -106,9 +106,15 @@ class _PackedHalf:
     """One 64x128x1x1 half of an MSRB's `confusion` weight in the fp16 two-plane pack (fused 1x1 epilogue)."""
     __slots__ = ("w", "w_inv_scale")
 
-    def __init__(self, w: torch.Tensor):
+    def __init__(self, w: torch.Tensor, ns: int = -2):
         import math
         w = w.float().contiguous()
+        if ns != -2:        # bf16-storage path: one bf16 plane, no scaling
+            self.w_inv_scale = 1.0
+            n = _lib.load().tsr_conv_weight_bf16s_elems(64, 128, 1, 1)
+            self.w = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+            call("tsr_pack_conv_weight_bf16s", ptr(w), ptr(self.w), _I(64), _I(128), _I(1), _I(1), stream())
+            return
         m = float(w.abs().max())
         wscale = 2.0 ** (13 - math.floor(math.log2(m))) if m > 0 else 1.0
         self.w_inv_scale = 1.0 / wscale
@@ -209,8 +215,9 @@ class TactileSR(nn.Module):
         msrbs = []
         for blk in self.patternFeatureExtra_layer:
             halves = None
-            if ns == -2 and self.fuse_1x1:      # the two 64x128 halves of the 1x1, each packed like a 1x1 conv weight
-                halves = tuple(_PackedHalf(blk.confusion.weight.detach()[:, o:o + 128]) for o in (0, 128))
+            if self.fuse_1x1 and (ns == -2 or self.conv_impl == "bf16"):
+                # the two 64x128 halves of the 1x1, each packed like a 1x1 conv weight
+                halves = tuple(_PackedHalf(blk.confusion.weight.detach()[:, o:o + 128], ns) for o in (0, 128))
             msrbs.append((_PackedConv(blk.conv_3_1[0], blk.conv_3_1[1], ns), _PackedConv(blk.conv_5_1[0], blk.conv_5_1[1], ns),
                           _PackedConv(blk.conv_3_2[0], blk.conv_3_2[1], ns), _PackedConv(blk.conv_5_2[0], blk.conv_5_2[1], ns),
                           _PackedConv(blk.confusion, None, ns), halves))
@@ -262,10 +269,15 @@ class TactileSR(nn.Module):
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        call("tsr_conv2d_fwd_f16s_fuse1x1", ptr(src), _I(128), _I(0), _I(128), ptr(pc.w), _I(pc.ks),
-             _lib.c_float(pc.w_inv_scale), ptr(amax_in), ptr(amax_out), ptr(pc.scale), ptr(pc.shift), _I(1),
-             ptr(half.w), _lib.c_float(half.w_inv_scale), ptr(shift2), ptr(res), _I(r_ctot), _I(r_coff),
-             ptr(dst), _I(d_ctot), _I(d_coff), _I(1 if relu2 else 0), _I(B), _I(H), _I(W), stream())
+        if src.dtype == torch.bfloat16:
+            call("tsr_conv2d_fwd_b16_fuse1x1", ptr(src), _I(128), _I(0), _I(128), ptr(pc.w), _I(pc.ks), ptr(pc.scale),
+                 ptr(pc.shift), _I(1), ptr(half.w), ptr(shift2), ptr(res), _I(r_ctot), _I(r_coff), ptr(dst), _I(d_ctot),
+                 _I(d_coff), _I(1 if relu2 else 0), _I(B), _I(H), _I(W), stream())
+        else:
+            call("tsr_conv2d_fwd_f16s_fuse1x1", ptr(src), _I(128), _I(0), _I(128), ptr(pc.w), _I(pc.ks),
+                 _lib.c_float(pc.w_inv_scale), ptr(amax_in), ptr(amax_out), ptr(pc.scale), ptr(pc.shift), _I(1),
+                 ptr(half.w), _lib.c_float(half.w_inv_scale), ptr(shift2), ptr(res), _I(r_ctot), _I(r_coff),
+                 ptr(dst), _I(d_ctot), _I(d_coff), _I(1 if relu2 else 0), _I(B), _I(H), _I(W), stream())
         if prof is not None:
             e1.record()
             prof.setdefault((pc.ks, pc.cout), []).append((e0, e1))
