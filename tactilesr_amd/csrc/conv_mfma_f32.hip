@@ -309,9 +309,10 @@ extern "C" int tsr_conv2d_slab_entries(int B, int H, int W) {
 }
 
 // Slab entries a tsr_conv2d_ex launch with these parameters writes: one per (workgroup, image slot).  The fp16-split
-// 3x3 / 5x5 kernels with 64 output channels put 4 images in a workgroup, everything else 2.
+// 3x3 / 5x5 kernels with 64 output channels and every one-plane (plain bf16) 3x3 / 5x5 kernel put 4 images in a
+// workgroup, everything else 2 (must match launch_bf16s in conv_mfma_split16.hip).
 extern "C" int tsr_conv2d_slab_entries_ex(int B, int H, int W, int cout, int ks, int nsplit) {
-  const int img = (nsplit == -2 && cout == 64 && ks > 1) ? 4 : 2;
+  const int img = (ks > 1 && ((nsplit == -2 && cout == 64) || nsplit == 1)) ? 4 : 2;
   return ((B + img - 1) / img) * ((W + 7) / 8) * ((H + 7) / 8) * img;
 }
 

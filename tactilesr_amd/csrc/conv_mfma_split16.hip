@@ -503,10 +503,12 @@ static int launch_bf16s(const ConvArgs& a, hipStream_t st) {
   // C_out = 64, fp16 3x3 / 5x5: 4 images per workgroup, every wave owns all 64 channels of one image (measured: the
   // 1x1 and the 3-plane bf16 forms are faster as pairs).  The training epilogues index their statistics slabs by
   // (workgroup, image slot): tsr_conv2d_slab_entries_ex tells the caller how many entries this form writes.
-  constexpr int WN = (COUT == 64 && F16 && KS > 1) ? 1 : 2;
+  // One plane (plain bf16, the reduced-precision train mode): 4 images for both channel counts -- with one product
+  // per MAC the weight stream per MFMA is what bounds the 2-image form (see launch_b16).
+  constexpr int WN = (KS > 1 && ((COUT == 64 && F16) || NS == 1)) ? 1 : 2;
   constexpr int IMG = 4 / WN;
   const int grid = ((a.B + IMG - 1) / IMG) * a.tiles_x * a.tiles_y;
-  if constexpr (KS == 3 && !(COUT == 64 && WN == 1)) {      // (4-image workgroups: two slabs would not leave 2 per CU)
+  if constexpr (KS == 3 && WN == 2) {      // (4-image workgroups: a second slab costs occupancy; measured slower)
     if (((a.cin >> 4) & 1) == 0) {     // double-buffered halo (needs the channel blocks in pairs)
       hipLaunchKernelGGL((conv_mfma_split16_kernel<KS, COUT, NS, EXT, F16, WN, true>), dim3(grid), dim3(256), 0, st, a);
       return tsr_check_launch();

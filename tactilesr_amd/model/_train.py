@@ -242,9 +242,12 @@ class TrainEngine:
         lib = _lib.load()
         c.entries = lib.tsr_conv2d_slab_entries(B, H, W)
         st_entries = lib.tsr_cb16_stats_entries(B, HW)
+        # statistics slabs are indexed by (workgroup, image slot): the entry count depends on how many images the
+        # kernel variant of (C_out, k, arithmetic) puts in a workgroup -- ask the library for every shape in use
         e64 = max(lib.tsr_conv2d_slab_entries_ex(B, H, W, 64, k, self.nsplit) for k in (1, 3, 5))
-        c.slab = torch.empty(max(c.entries * 128 * 2, e64 * 64 * 2, st_entries * 64 * 2), dtype=torch.float32, device=dev)
-        c.slab_cnt = torch.empty(max(c.entries, e64, st_entries), dtype=torch.float32, device=dev)
+        e128 = max(c.entries, max(lib.tsr_conv2d_slab_entries_ex(B, H, W, 128, k, self.nsplit) for k in (1, 3, 5)))
+        c.slab = torch.empty(max(e128 * 128 * 2, e64 * 64 * 2, st_entries * 64 * 2), dtype=torch.float32, device=dev)
+        c.slab_cnt = torch.empty(max(e128, e64, st_entries), dtype=torch.float32, device=dev)
         c.work = torch.empty(512 * 128 * 3, dtype=torch.float64, device=dev)
 
         def buf(ch):
