@@ -80,15 +80,20 @@ struct WgradTGeom {
   static constexpr int LDSB = (2 * BUFB > 32 * CO * 4 ? 2 * BUFB : 32 * CO * 4) + CI * 8;   // + (scale, shift) table
 };
 
-template <int KS, int KHW, int CO, int CI, int WM, int NS, bool F16, bool STAGGER = false>
-__global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_tr16_kernel(const WgradTArgs g) {
+// SPEC: role-specialised workgroup of 2 x NWAVE waves -- waves [0, NWAVE) only run the MFMA loop (one per SIMD for the
+// 4-wave tiles: the matrix pipe is theirs alone), waves [NWAVE, 2 NWAVE) only stage (global loads, fp32 -> fp16-plane
+// conversion, LDS writes) one item ahead.  In the symmetric form the two waves of a SIMD run the same code in
+// lockstep and its VALU time (32 %) adds to its MFMA time (59 %); with different programs they overlap.
+template <int KS, int KHW, int CO, int CI, int WM, int NS, bool F16, bool SPEC = false>
+__global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) void wgrad_tr16_kernel(const WgradTArgs g) {
   typedef WgradTGeom<KS, KHW, CO, CI, WM, NS, F16> G;
   typedef typename TPlane<F16>::T PT;
   typedef typename TPlane<F16>::V8 PV8;
   typedef typename TPlane<F16>::V4 PV4;
   typedef __attribute__((address_space(3))) tv4i16* lds_v4;
   constexpr int P = KS / 2;
-  constexpr int NT = G::NT, MT = G::MT;
+  constexpr int NT = G::NT, MT = G::MT;            // NT = staging threads (= MFMA threads)
+  constexpr int NTT = SPEC ? 2 * NT : NT;            // threads of the workgroup
   constexpr int NPROD = NS == 3 ? 6 : (NS == 2 ? 3 : 1);
   // products ordered small -> large (plane 0 = most significant)
   constexpr int PA[6] = {NS == 3 ? 2 : (NS == 2 ? 1 : 0), 0, NS == 3 ? 1 : 0, 1, 0, 0};
@@ -96,8 +101,12 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_tr16_kern
 
   __shared__ __attribute__((aligned(16))) char lds[G::LDSB];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / G::NWN, wn = wave - wm * G::NWN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool stager = !SPEC || __builtin_amdgcn_readfirstlane(wave) >= G::NWAVE;     // this wave stages tiles
+  const bool mmaer = !SPEC || !stager;                                               // this wave runs the MFMAs
+  const int tid = SPEC ? (threadIdx.x & (NT - 1)) : threadIdx.x;                      // index within its role
+  const int wrole = SPEC ? (wave % G::NWAVE) : wave;
+  const int wm = wrole / G::NWN, wn = wrole - wm * G::NWN;
   const int h = lane >> 5, li = lane & 31;
 
   const int nci = g.cin / CI, nco = g.cout / CO;
@@ -128,7 +137,7 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_tr16_kern
     if (g.a_scale) {
       float* bnd = (float*)lds;
       float ms = 0.f, mt = 0.f;
-      for (int c = tid; c < CI; c += NT) {
+      for (int c = threadIdx.x; c < CI; c += NTT) {
         ms = fmaxf(ms, fabsf(g.a_scale[cib * CI + c]));
         mt = fmaxf(mt, fabsf(g.a_shift[cib * CI + c]));
       }
@@ -140,7 +149,7 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_tr16_kern
       if (lane == 0) { bnd[wave * 2] = ms; bnd[wave * 2 + 1] = mt; }
       __syncthreads();
       ms = 0.f; mt = 0.f;
-      for (int w = 0; w < G::NWAVE; ++w) { ms = fmaxf(ms, bnd[w * 2]); mt = fmaxf(mt, bnd[w * 2 + 1]); }
+      for (int w = 0; w < NTT / 64; ++w) { ms = fmaxf(ms, bnd[w * 2]); mt = fmaxf(mt, bnd[w * 2 + 1]); }
       __syncthreads();
       ma = ma * ms + mt;
     }
@@ -148,13 +157,17 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_tr16_kern
     s_d = tr16_pow2_scale(g.dz_amax ? *g.dz_amax : 0.f);
   }
 
+  // (in the role-specialised form the accumulators must be live in the MFMA role's branch ONLY -- zeroed, used and
+  // written out there -- or the register allocator keeps 160 of them alive through the staging role's loop)
   f32x16 acc[MT][G::NTAP];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int k = 0; k < G::NTAP; ++k)
+      for (int k = 0; k < G::NTAP; ++k)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][k][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[m][k][r] = 0.f;
+  };
 
   // ---- staging roles: item i -> (quad = i & 3, pixel, block); consecutive threads walk a CB16 line, then the row
   float bsum[G::NIT_DZ][4];
@@ -201,7 +214,7 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_tr16_kern
   // the fused input transform's per-channel (scale, shift) of this workgroup's CI channels, kept in LDS
   float* tsc = (float*)(lds + 2 * G::BUFB);
   if (g.a_scale) {
-    for (int c = tid; c < CI; c += NT) {
+    for (int c = threadIdx.x; c < CI; c += NTT) {
       tsc[c] = g.a_scale[cib * CI + c];
       tsc[CI + c] = g.a_shift[cib * CI + c];
     }
@@ -359,72 +372,87 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_tr16_kern
   };
 
   __syncthreads();                         // tsc published (and the scale-bound scratch is free)
-  // Per item: [issue next item's global loads | MFMAs of K step 0 | S | MFMAs of K step 1 | S' | barrier] where the
-  // staging block (convert + write the next item into the other buffer) runs at S in the first half of the waves and
-  // at S' in the second.  Wave w and w + NWAVE/2 share a SIMD: while one converts (VALU, LDS writes) the other's MFMAs
-  // have the matrix pipe -- in lockstep both would alternate between an MFMA-only and a VALU-only phase.  (Measured:
-  // static s_setprio for one half does not pull the pair apart; two full loop bodies with different load placement
-  // cost 57 spilled registers in the 10-tile kernels.)
-  const bool late = STAGGER && __builtin_amdgcn_readfirstlane(wave) >= G::NWAVE / 2;
-  if (it0 < it1) {
+  // ---- this split's partial dW: slab[sp][co][ci][kh][kw]
+  auto write_slab = [&]() {
+    constexpr int T = KS * KS;
+    float* sl = g.slab + (size_t)sp * g.cout * g.cin * T;
+    const float inv = F16 ? 1.f / (s_a * s_d) : 1.f;
+    const int ci = cib * CI + wn * 32 + li;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int tap = 0; tap < G::NTAP; ++tap) {
+        if (kh0 * KS + tap < T) {          // a short last row group holds rows beyond the kernel: not written
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = cob * CO + wm * WM + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            sl[((size_t)co * g.cin + ci) * T + kh0 * KS + tap] = acc[m][tap][r] * inv;
+          }
+        }
+      }
+  };
+
+  if (it0 < it1 && stager) {
     load_item();
     store_item(0);
+    if (SPEC && it0 + 1 < it1) load_item();          // specialised stagers run one item ahead with the loads in flight
   }
   __syncthreads();
   int cur = 0;
-  for (int item = it0; item < it1; ++item) {
-    const bool more = item + 1 < it1;
+  if (!SPEC) {
+    zero_acc();
+    for (int item = it0; item < it1; ++item) {
+      const bool more = item + 1 < it1;
 #ifndef TSR_ABL_WG_NOLOAD
-    if (more) load_item();               // global loads fly under K step 0 (issuing them a whole item ahead: no gain)
+      if (more) load_item();               // global loads fly under K step 0 (issuing them a whole item ahead: no gain)
 #endif
 #ifndef TSR_ABL_WG_NOMMA
-    mma_item(cur, [&]() {
+      mma_item(cur, [&]() {
 #endif
 #ifndef TSR_ABL_WG_NOSTORE
-      if (more && !late) store_item(cur ^ 1);     // the other buffer: its last readers passed the previous barrier
+        if (more) store_item(cur ^ 1);     // the other buffer: its last readers passed the previous barrier
 #else
-      asm volatile("" :: "v"(hd[0][0]), "v"(ha[0][0]), "v"(ha[G::NIT_A - 1][3]), "v"(hd[G::NIT_DZ - 1][3]));
+        asm volatile("" :: "v"(hd[0][0]), "v"(ha[0][0]), "v"(ha[G::NIT_A - 1][3]), "v"(hd[G::NIT_DZ - 1][3]));
 #endif
 #ifndef TSR_ABL_WG_NOMMA
-    });
+      });
 #endif
-#ifndef TSR_ABL_WG_NOSTORE
-    if (more && late) store_item(cur ^ 1);        // second half of the waves: after K step 1 (see above)
-#endif
-    __syncthreads();
-    cur ^= 1;
+      __syncthreads();
+      cur ^= 1;
+    }
+    write_slab();
+  } else if (stager) {
+    for (int item = it0; item < it1; ++item) {
+      if (item + 1 < it1) {
+        store_item(cur ^ 1);               // item + 1: loaded during the previous iteration
+        if (item + 2 < it1) load_item();   // item + 2: in flight for a whole item
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    zero_acc();
+    for (int item = it0; item < it1; ++item) {
+      mma_item(cur, [&]() {});
+      __syncthreads();
+      cur ^= 1;
+    }
+    write_slab();
   }
 
-  // ---- write this split's partial dW: slab[sp][co][ci][kh][kw]
-  constexpr int T = KS * KS;
-  float* sl = g.slab + (size_t)sp * g.cout * g.cin * T;
-  const float inv = F16 ? 1.f / (s_a * s_d) : 1.f;
-  const int ci = cib * CI + wn * 32 + li;
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int tap = 0; tap < G::NTAP; ++tap) {
-      if (kh0 * KS + tap < T) {          // a short last row group holds rows beyond the kernel: not written
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = cob * CO + wm * WM + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          sl[((size_t)co * g.cin + ci) * T + kh0 * KS + tap] = acc[m][tap][r] * inv;
-        }
-      }
-    }
   if (do_bias) {       // thread slot j holds the sums of 4 channels of (pixel, block): reduce the 32 pixels
     float* bred = (float*)lds;                 // [32 px][CO]
 #pragma unroll
     for (int j = 0; j < G::NIT_DZ; ++j) {
       const int i = tid + j * NT;
-      if ((j + 1) * NT <= G::N_DZ || i < G::N_DZ) {
+      if (stager && ((j + 1) * NT <= G::N_DZ || i < G::N_DZ)) {
         const int q = i & 3, px = (i >> 2) & 31, blk = i >> 7;
 #pragma unroll
         for (int c = 0; c < 4; ++c) bred[px * CO + blk * 16 + q * 4 + c] = bsum[j][c];
       }
     }
     __syncthreads();
-    for (int c = tid; c < CO; c += NT) {
+    for (int c = threadIdx.x; c < CO; c += NTT) {
       float s = 0.f;
 #pragma unroll
       for (int px = 0; px < 32; ++px) s += bred[px * CO + c];
@@ -454,17 +482,26 @@ template <int KS, int NS> struct WgradTCfg {
 
 static bool tr16_big(int cout, int cin, int ci_big) { return (cout % 128) == 0 && (cin % ci_big) == 0; }
 
+static bool tr16_spec() {
+  static const bool on = getenv("TSR_WGRAD_SPEC") != nullptr;
+  return on;
+}
+
 template <int KS, int NS, bool F16>
 static int launch_tr16(const WgradTArgs& g, hipStream_t st) {
   typedef WgradTCfg<KS, NS> C;
+  if constexpr (KS == 5 && F16) {
+    if (tr16_spec() && (g.cout % 128) == 0 && (g.cin % 64) == 0) {      // role-specialised 128 x 64 tile (4 + 4 waves)
+      typedef WgradTGeom<KS, 1, 128, 64, 64, NS, F16> G;
+      const int grid = g.nsplit * G::NKG * (g.cout / 128) * (g.cin / 64);
+      hipLaunchKernelGGL((wgrad_tr16_kernel<KS, 1, 128, 64, 64, NS, F16, true>), dim3(grid), dim3(2 * G::NT), 0, st, g);
+      return tsr_check_launch();
+    }
+  }
   if (tr16_big(g.cout, g.cin, C::CI_BIG)) {
     typedef WgradTGeom<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG, NS, F16> G;
     const int grid = g.nsplit * G::NKG * (g.cout / 128) * (g.cin / C::CI_BIG);
-    static const bool stag = getenv("TSR_WGRAD_STAGGER") != nullptr;      // A/B switch (fp16x3 only): measured slower
-    if (F16 && stag)
-      hipLaunchKernelGGL((wgrad_tr16_kernel<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG, NS, F16, true>), dim3(grid), dim3(G::NT), 0, st, g);
-    else
-      hipLaunchKernelGGL((wgrad_tr16_kernel<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG, NS, F16>), dim3(grid), dim3(G::NT), 0, st, g);
+    hipLaunchKernelGGL((wgrad_tr16_kernel<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG, NS, F16>), dim3(grid), dim3(G::NT), 0, st, g);
     return tsr_check_launch();
   }
   typedef WgradTGeom<KS, C::KHW_SMALL, 64, 64, 32, NS, F16> G;
@@ -486,6 +523,7 @@ template <int KS> static int tr16_wgs(int cout, int cin, int planes) {
 
 // workgroups one batch split of this layer launches (the caller sizes nsplit so that splits x this fills the chip)
 extern "C" int tsr_conv2d_wgrad_wgs_per_split(int cout, int cin, int ks, int planes) {
+  if (ks == 5 && planes == -2 && tr16_spec() && (cout % 128) == 0 && (cin % 64) == 0) return 5 * (cout / 128) * (cin / 64);
   return ks == 1 ? tr16_wgs<1>(cout, cin, planes) : (ks == 3 ? tr16_wgs<3>(cout, cin, planes) : tr16_wgs<5>(cout, cin, planes));
 }
 
