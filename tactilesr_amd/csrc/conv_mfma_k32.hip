@@ -1,0 +1,356 @@
+// fp16x3 implicit-GEMM convolution on v_mfma_f32_16x16x32_f16 (K = 32 per instruction), the default form of the
+// 3x3 / 5x5 convolutions.  Same arithmetic as conv_mfma_split16.hip (fp32 operands as two power-of-two-scaled fp16
+// planes, products h2g1 + h1g1 + h1g2 accumulated in fp32), same staging (halo slab split on the fly, weight slabs
+// through a 3-slot LDS ring), same epilogues -- a different matrix instruction:
+//
+//   * Why: under an MFMA-dense loop the MI355X lowers its clock, and it holds a HIGHER clock on the 16x16x32 shape than
+//     on 32x32x16 at equal cycles per FLOP (MI355X_MICROARCH.md, DVFS give-back item 7).  Measured on this kernel's
+//     predecessor with the instruction swapped in place (wrong results, same FLOPs, same LDS traffic): 1.77 -> 2.02 GHz
+//     (GRBM_GUI_ACTIVE / 8 / wall), 5x5 128->128 at B = 4096 12.8 -> 11.7 ms.
+//   * K = 32 = two taps x 16 channels.  The LDS images are the 32x32x16 kernel's ([pixel][plane][16 ch] halo,
+//     [tap][plane][k half][C_out][8] weights); only the lane -> address maps differ: lane = (m = lane & 15, g = lane >> 4),
+//     g = (tap of the pair, 8-channel half).  A rows: 16 pixels = 2 rows x 8 columns of the wave's 8x8 patch; the
+//     two taps of a pair differ by a per-lane byte delta that takes two values (next column / next row), so two
+//     precomputed address registers and compile-time immediates cover every step.
+//   * 9 and 25 are odd: the last tap of an even channel block is paired with the last tap of the following odd block
+//     (zero padding would cost 4 % / 11 % of the MFMA work).  The even block's 8x8 window of that tap is copied
+//     LDS -> LDS into a small side buffer while its slab is still resident; the odd block ends with the cross step
+//     [side buffer | halo].  tsr_pack_conv_weight_f16s lays the weight stream out in exactly that step order.
+//   * Fragment registers are single-buffered and refilled one product phase ahead: per step the phases are
+//     P0 = A1 x B0 (h2 g1), P1 = A0 x B0 (h1 g1), P2 = A0 x B1 (h1 g2); A1 is dead after P0 and reloaded (next step) during
+//     P1, B0 after P1 during P2, A0 / B1 of the step itself arrive under P0.  64 accumulator + 64 fragment registers.
+//
+// Workgroup = 256 threads, 8x8 patch: WN = 2 -> 2 images x 2 C_out halves (C_out = 128), WN = 1 -> 4 images x all
+// C_out (C_out = 64); every wave owns 64 pixels x 64 channels = 4 x 4 accumulator tiles.
+#include "tsr_common.h"
+#include "conv_args.h"
+#include "conv_epilogue16.h"
+#include "conv_fuse1x1_16.h"
+#include "tactilesr_hip.h"
+#include <type_traits>
+
+typedef _Float16 kf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 kf16x4 __attribute__((ext_vector_type(4)));
+
+// halo / side-buffer row stride in 16-B slots: == 2 (mod 4), which makes the ds_read_b128 A fragments of this lane map
+// bank-conflict free (lane groups {0-3,12-15,20-27}, ...: pixel slots 4*col + {0, stride} + k-half {0, 1} all distinct)
+constexpr int k32_row_slots(int px) {
+  int rs = px * 4;
+  while ((rs & 3) != 2) ++rs;
+  return rs;
+}
+
+template <int KS, int COUT, int WN> struct K32Geom {
+  static constexpr int IMG = 4 / WN;
+  static constexpr int HH = 8 + KS - 1;
+  static constexpr int T = KS * KS;
+  static constexpr int HS = (T - 1) / 2;                       // tap pairs per block; + the cross step per block pair
+  static constexpr int PIXB = 64;
+  static constexpr int ROWB = k32_row_slots(HH) * 16;
+  static constexpr int IMGB = HH * ROWB;
+  static constexpr int HALO_B = IMG * IMGB;
+  static constexpr int SROWB = k32_row_slots(8) * 16;
+  static constexpr int SIMGB = 8 * SROWB;
+  static constexpr int SIDE_B = IMG * SIMGB;
+  static constexpr int WTAP_B = 2 * 16 * COUT * 2;             // [plane 2][k half 2][C_out][8] fp16
+  static constexpr int WSLAB_B = 2 * WTAP_B;                   // one step = one pair of taps
+  static constexpr int MAIN_LDS = HALO_B + SIDE_B + 3 * WSLAB_B;
+};
+
+template <int KS, int COUT, bool EXT, int WN, bool FUSE2 = false>
+__global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
+  static_assert(COUT == 64 * WN, "every wave owns 64 channels");
+  static_assert(!FUSE2 || (!EXT && COUT == 128), "fused 1x1: 128 channels, inference");
+  typedef K32Geom<KS, COUT, WN> G;
+  constexpr int IMG = G::IMG, P = KS / 2, HH = G::HH, T = G::T, HS = G::HS, NT = 4;
+  constexpr int PIXB = G::PIXB, ROWB = G::ROWB, IMGB = G::IMGB, HALO_B = G::HALO_B;
+  constexpr int SROWB = G::SROWB, SIMGB = G::SIMGB, SIDE_B = G::SIDE_B;
+  constexpr int WTAP_B = G::WTAP_B, WSLAB_B = G::WSLAB_B;
+  constexpr int WITEMS = WSLAB_B / 16, WV = (WITEMS + 255) / 256;
+  constexpr int NITEM = IMG * HH * HH * 4, NIT = (NITEM + 255) / 256;
+  constexpr int FUSE_LDS = FUSE2 ? Fuse1x1Geom16::BYTES + 64 : 0;
+  __shared__ __attribute__((aligned(16))) char lds[G::MAIN_LDS > FUSE_LDS ? G::MAIN_LDS : FUSE_LDS];
+  char* halo = lds;
+  char* wbuf = lds + HALO_B + SIDE_B;     // 3-slot ring: slab s lives in slot s % 3
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
+  const int m = lane & 15, g = lane >> 4, khalf = g & 1, tsel = g >> 1;
+
+  // power-of-two operand scales (see conv_mfma_split16.hip)
+  float sx = 1.f, accmul = 1.f;
+  {
+    float mx = a.in_amax ? *a.in_amax : 0.f;
+    if (EXT && a.in_scale) {
+      __shared__ float bnd[8];
+      float ms = 0.f, mt = 0.f;
+      for (int c = threadIdx.x; c < a.cin; c += 256) {
+        ms = fmaxf(ms, fabsf(a.in_scale[c]));
+        mt = fmaxf(mt, fabsf(a.in_shift[c]));
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        ms = fmaxf(ms, __shfl_xor(ms, o));
+        mt = fmaxf(mt, __shfl_xor(mt, o));
+      }
+      if (lane == 0) { bnd[wave * 2] = ms; bnd[wave * 2 + 1] = mt; }
+      __syncthreads();
+      ms = fmaxf(fmaxf(bnd[0], bnd[2]), fmaxf(bnd[4], bnd[6]));
+      mt = fmaxf(fmaxf(bnd[1], bnd[3]), fmaxf(bnd[5], bnd[7]));
+      mx = mx * ms + mt;
+    }
+    if (mx > 0.f) {
+      int e = (int)((__float_as_uint(mx) >> 23) & 0xFF) - 127;
+      int be = 13 - e + 127;
+      be = be < 1 ? 1 : (be > 254 ? 254 : be);
+      sx = __uint_as_float((unsigned)be << 23);
+    }
+    float w_inv = a.w_inv_scale;
+    if (a.w_amax) {
+      const float wmx = *a.w_amax;
+      w_inv = 1.f;
+      if (wmx > 0.f && wmx < 3.0e38f) {
+        int be = 127 - (13 - ((int)((__float_as_uint(wmx) >> 23) & 0xFF) - 127));
+        be = be < 1 ? 1 : (be > 254 ? 254 : be);
+        w_inv = __uint_as_float((unsigned)be << 23);
+      }
+    }
+    accmul = w_inv / sx;
+  }
+
+  int bid;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tpi = a.tiles_x * a.tiles_y;
+  const int ig = bid / tpi;
+  const int trem = bid - ig * tpi;
+  const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+  const int y0 = ty * 8, x0 = tx * 8, b0 = ig * IMG;
+  const int HW = a.H * a.W;
+  const int in_blocks = a.in_ctot >> 4;
+
+  int st_src[NIT], st_dst[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int it = tid + k * 256;
+    st_src[k] = -1;
+    st_dst[k] = -1;
+    if (it < NITEM) {
+      const int qd = it & 3, px = it >> 2;
+      const int img = px / (HH * HH), rem = px - img * (HH * HH);
+      const int hy = rem / HH, hx = rem - hy * HH;
+      const int gy = y0 - P + hy, gx = x0 - P + hx, b = b0 + img;
+      st_dst[k] = img * IMGB + hy * ROWB + hx * PIXB + qd * 8;
+      if (b < a.B && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+        st_src[k] = ((img * in_blocks) * HW + gy * a.W + gx) * 16 + qd * 4;
+    }
+  }
+  const float* in_base = a.in + ((size_t)b0 * in_blocks + (a.in_coff >> 4)) * HW * 16;
+
+  // A-fragment lane bases (bytes from `lds`): lx = pair in one row (second tap one pixel to the right), lw = pair that
+  // wraps to the next row, lc / lcs = cross step (first tap from the side buffer, second from the halo)
+  const int laneA0 = wm * IMGB + (m >> 3) * ROWB + (m & 7) * PIXB + khalf * 16;
+  const int lx = laneA0 + tsel * PIXB;
+  const int lw = laneA0 + tsel * (ROWB - (KS - 1) * PIXB);
+  const int lc = tsel ? laneA0 + (KS - 1) * ROWB + (KS - 1) * PIXB
+                      : HALO_B + wm * SIMGB + (m >> 3) * SROWB + (m & 7) * PIXB + khalf * 16;
+  const int lcs = tsel ? 2 * ROWB : 2 * SROWB;
+  const int laneB = tsel * WTAP_B + (khalf * COUT + wn * (COUT / WN) + m) * 16;
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nchunk = a.cin >> 4;              // even (launch check)
+  const int S = (nchunk >> 1) * T;            // steps: HS per even block, HS + 1 per odd block
+  const char* wsrc = (const char*)a.wp;
+
+  auto load_halo = [&](int c, f32x4* hv) {
+    const float* inc = in_base + (size_t)c * HW * 16;
+    // branch-free: out-of-image items read a valid dummy address (offset 0) and are zeroed by their scale in store_halo
+    // (hipcc otherwise wraps every load in its own exec-masked branch with a wait in front)
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) hv[k] = *(const f32x4*)(inc + (unsigned)(st_src[k] < 0 ? 0 : st_src[k]));
+  };
+  auto store_halo = [&](const f32x4* hv, int c) {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      if (st_dst[k] >= 0) {
+        f32x4 v = hv[k];
+        if (EXT && a.in_scale) {   // producer's train-mode BN+ReLU, fused into the load
+          const int cq = c * 16 + ((tid + k * 256) & 3) * 4;
+          const f32x4 sc = *(const f32x4*)(a.in_scale + cq);
+          const f32x4 sh = *(const f32x4*)(a.in_shift + cq);
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) v[jj] = fmaxf(fmaf(v[jj], sc[jj], sh[jj]), 0.f);
+        }
+        const float mk = st_src[k] >= 0 ? sx : 0.f;       // zero padding outside the image
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) v[jj] *= mk;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          kf16x4 bq;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            bq[jj] = (_Float16)v[jj];
+            v[jj] -= (float)bq[jj];
+          }
+          *(kf16x4*)(halo + st_dst[k] + p * 32) = bq;
+        }
+      }
+    }
+  };
+#define LOAD_W(sidx)                                                                     \
+  {                                                                                      \
+    const f32x4* src_ = (const f32x4*)(wsrc + (size_t)(sidx) * WSLAB_B);                  \
+    _Pragma("unroll") for (int v = 0; v < WV; ++v) wreg[v] = src_[tid + v * 256];        \
+  }
+#define STORE_W(slot)                                                                    \
+  {                                                                                      \
+    char* wb_ = wbuf + (slot) * WSLAB_B;                                                 \
+    _Pragma("unroll") for (int v = 0; v < WV; ++v) ((f32x4*)wb_)[tid + v * 256] = wreg[v]; \
+  }
+  // fragments of pair step st_ (taps 2 st_, 2 st_ + 1 of the resident block), plane p_
+#define LOAD_A(dst, p_, st_)                                                             \
+  {                                                                                      \
+    const int kh_ = (2 * (st_)) / KS, kw_ = (2 * (st_)) - kh_ * KS;                      \
+    const char* ab_ = lds + (kw_ < KS - 1 ? lx : lw) + kh_ * ROWB + kw_ * PIXB + (p_) * 32; \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) dst[mt] = *(const kf16x8*)(ab_ + mt * 2 * ROWB); \
+  }
+#define LOAD_A_CROSS(dst, p_)                                                            \
+  {                                                                                      \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) dst[mt] = *(const kf16x8*)(lds + lc + mt * lcs + (p_) * 32); \
+  }
+#define LOAD_B(dst, p_, slot_)                                                           \
+  {                                                                                      \
+    const char* wb_ = wbuf + (slot_) * WSLAB_B + laneB + (p_) * (2 * COUT * 16);         \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) dst[nt] = *(const kf16x8*)(wb_ + nt * 256); \
+  }
+#define MFMA_PHASE(A_, B_)                                                               \
+  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                       \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                    \
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_[mt], B_[nt], acc[mt][nt], 0, 0, 0);
+  // interleave hint: n_ groups of (per_ MFMAs, 1 LDS read)
+#define INTERLEAVE(n_, per_)                                                             \
+  _Pragma("unroll") for (int i_ = 0; i_ < (n_); ++i_) {                                  \
+    __builtin_amdgcn_sched_group_barrier(0x008, (per_), 0);                              \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                   \
+  }
+
+  // ---- prologue: halo(0), W(0), W(1) in LDS; W(2) in flight
+  f32x4 hv[NIT], wreg[WV];
+  load_halo(0, hv);
+  LOAD_W(0);
+  STORE_W(0);
+  if (S > 1) { LOAD_W(1); STORE_W(1); }
+  store_halo(hv, 0);
+  if (S > 2) LOAD_W(2);
+  __syncthreads();
+
+  kf16x8 A0[4], A1[4], B0[NT], B1[NT];
+  LOAD_A(A1, 1, 0);
+  LOAD_B(B0, 0, 0);
+
+  // side-buffer copy of the last tap's 8x8 window (even blocks): IMG 16-B items per thread, item k = image k
+  const int sc_src = ((tid >> 5) + KS - 1) * ROWB + (((tid >> 2) & 7) + KS - 1) * PIXB + (tid & 3) * 16;
+  const int sc_dst = HALO_B + (tid >> 5) * SROWB + ((tid >> 2) & 7) * PIXB + (tid & 3) * 16;
+
+  int s = 0;
+  int slot = 0;                            // s % 3, kept incrementally
+  auto block = [&](int c, auto oddc) {
+    constexpr int ODD = decltype(oddc)::value;
+    constexpr int NST = HS + ODD;
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const int slot1 = slot == 2 ? 0 : slot + 1;
+      const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
+      const bool cross = ODD && st == HS;
+      f32x4 sidev[IMG];
+      // this step's second-phase operands
+      if (cross) { LOAD_A_CROSS(A0, 0); } else { LOAD_A(A0, 0, st); }
+      LOAD_B(B1, 1, slot);
+      if (!ODD && st == 0) {
+#pragma unroll
+        for (int k = 0; k < IMG; ++k) sidev[k] = *(const f32x4*)(lds + sc_src + k * IMGB);
+      }
+      if (st == NST - 2 && c + 1 < nchunk) load_halo(c + 1, hv);   // next block's slab: in flight for a step and a half
+      MFMA_PHASE(A1, B0);                                          // P0: h2 g1
+      if (!ODD && st == 0) { INTERLEAVE(8 + IMG, 1); } else { INTERLEAVE(8, 2); }
+      if (st + 1 < NST) {                                          // next step's A1 (same block: the slab is resident)
+        if (ODD && st + 1 == HS) { LOAD_A_CROSS(A1, 1); } else { LOAD_A(A1, 1, st + 1); }
+      }
+      MFMA_PHASE(A0, B0);                                          // P1: h1 g1
+      if (st + 1 < NST) { INTERLEAVE(4, 4); }
+      LOAD_B(B0, 0, slot1);        // next step's B0: published one barrier ago (after the last step: stale, unused)
+      MFMA_PHASE(A0, B1);                                          // P2: h1 g2
+      INTERLEAVE(4, 4);
+      if (!ODD && st == 0) {
+#pragma unroll
+        for (int k = 0; k < IMG; ++k) *(f32x4*)(lds + sc_dst + k * SIMGB) = sidev[k];
+      }
+      if (s + 2 < S) STORE_W(slot2);           // slot (s+2)%3 was last read one barrier ago
+      if (s + 3 < S) LOAD_W(s + 3);
+      __syncthreads();
+      if (st + 1 == NST && c + 1 < nchunk) {
+        store_halo(hv, c + 1);     // every wave is past its last read of the old slab (barrier above)
+        __syncthreads();
+        LOAD_A(A1, 1, 0);
+      }
+      ++s;
+      slot = slot1;
+    }
+  };
+  for (int c = 0; c < nchunk; c += 2) {
+    block(c, std::integral_constant<int, 0>());
+    block(c + 1, std::integral_constant<int, 1>());
+  }
+#undef LOAD_W
+#undef STORE_W
+#undef LOAD_A
+#undef LOAD_A_CROSS
+#undef LOAD_B
+#undef MFMA_PHASE
+#undef INTERLEAVE
+
+  if constexpr (FUSE2) conv_fuse1x1_epilogue16(a, acc, lds, b0, y0, x0, wm, wn, lane, HW, accmul);
+  else conv_epilogue16<COUT, EXT, WN>(a, acc, bid, b0, y0, x0, wm, wn, lane, HW, accmul);
+}
+
+// ---- launchers (called from conv_mfma_split16.hip's dispatchers; argument checks were done there) -------------------
+template <int KS, int COUT, bool EXT>
+static int launch_k32(const ConvArgs& a, hipStream_t st) {
+  constexpr int WN = COUT / 64;
+  constexpr int IMG = 4 / WN;
+  const int grid = ((a.B + IMG - 1) / IMG) * a.tiles_x * a.tiles_y;
+  hipLaunchKernelGGL((conv_k32_kernel<KS, COUT, EXT, WN, false>), dim3(grid), dim3(256), 0, st, a);
+  return tsr_check_launch();
+}
+
+int tsr_conv_k32(const ConvArgs& a, int cout, int ks, bool ext, hipStream_t st) {
+  if (ext) {
+    if (cout == 64 && ks == 3) return launch_k32<3, 64, true>(a, st);
+    if (cout == 64 && ks == 5) return launch_k32<5, 64, true>(a, st);
+    if (cout == 128 && ks == 3) return launch_k32<3, 128, true>(a, st);
+    if (cout == 128 && ks == 5) return launch_k32<5, 128, true>(a, st);
+  } else {
+    if (cout == 64 && ks == 3) return launch_k32<3, 64, false>(a, st);
+    if (cout == 64 && ks == 5) return launch_k32<5, 64, false>(a, st);
+    if (cout == 128 && ks == 3) return launch_k32<3, 128, false>(a, st);
+    if (cout == 128 && ks == 5) return launch_k32<5, 128, false>(a, st);
+  }
+  return TSR_ERR_ARG;
+}
+
+int tsr_conv_k32_fuse1x1(const ConvArgs& a, int ks, hipStream_t st) {
+  const int grid = ((a.B + 1) / 2) * a.tiles_x * a.tiles_y;
+  if (ks == 5) hipLaunchKernelGGL((conv_k32_kernel<5, 128, false, 2, true>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_k32_kernel<3, 128, false, 2, true>), dim3(grid), dim3(256), 0, st, a);
+  return tsr_check_launch();
+}

@@ -42,7 +42,18 @@ template <> struct Plane<false> {
 };
 template <> struct Plane<true> {
   typedef _Float16 T; typedef f16x8 V8; typedef f16x4 V4;
-  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
+#ifdef TSR_EXP_MFMA16   // timing experiment only (wrong results): the same FLOPs as two 16x16x32 instructions
+    f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+    c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
+    c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+  }
 };
 
 template <int NS> struct SplitGeom;
@@ -216,22 +227,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
     if (IO16) {     // 4 bf16 = 8 B per item, carried in the low half of the f32x4 slot
       const __bf16* inc = in_base16 + (size_t)c * HW * 16;
 #pragma unroll
-      for (int k = 0; k < NIT; ++k) {
-        hv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (st_src[k] >= 0) {
-          const float2 t = *(const float2*)(inc + st_src[k]);
-          hv[k][0] = t.x;
-          hv[k][1] = t.y;
-        }
+      for (int k = 0; k < NIT; ++k) {   // branch-free (see below): dummy address, zeroed by a select
+        float2 t = *(const float2*)(inc + (unsigned)(st_src[k] < 0 ? 0 : st_src[k]));
+        if (st_src[k] < 0) t = make_float2(0.f, 0.f);
+        hv[k] = (f32x4){t.x, t.y, 0.f, 0.f};
       }
       return;
     }
     const float* inc = in_base + (size_t)c * HW * 16;
+    // branch-free: out-of-image items read a valid dummy address (offset 0) and are zeroed in store_halo (hipcc otherwise
+    // wraps every load in its own exec-masked branch)
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-      hv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (st_src[k] >= 0) hv[k] = *(const f32x4*)(inc + st_src[k]);
-    }
+    for (int k = 0; k < NIT; ++k) hv[k] = *(const f32x4*)(inc + (unsigned)(st_src[k] < 0 ? 0 : st_src[k]));
   };
   auto store_halo = [&](const f32x4* hv, int c, int hb) {
     if (IO16) {
@@ -244,16 +251,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
     for (int k = 0; k < NIT; ++k) {
       if (st_dst[k] >= 0) {
         f32x4 v = hv[k];
-        if (EXT && a.in_scale && st_src[k] >= 0) {   // producer's train-mode BN+ReLU, fused into the load
+        if (EXT && a.in_scale) {   // producer's train-mode BN+ReLU, fused into the load
           const int cq = c * 16 + ((tid + k * 256) & 3) * 4;
           const f32x4 sc = *(const f32x4*)(a.in_scale + cq);
           const f32x4 sh = *(const f32x4*)(a.in_shift + cq);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), 0.f);
         }
-        if (F16) {
+        {   // operand scale of the fp16 planes; zero padding outside the image
+          const float mk = st_src[k] >= 0 ? (F16 ? sx : 1.f) : 0.f;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] *= sx;
+          for (int j = 0; j < 4; ++j) v[j] *= mk;
         }
 #pragma unroll
         for (int p = 0; p < NS; ++p) {
@@ -344,7 +352,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
           if (PF && (t + 1 < T || DBH)) {
             // interleave the next tap's fragment reads with this tap's MFMAs (hipcc otherwise sinks all ds_reads
             // below the MFMA block, exposing their latency in front of the barrier's lgkmcnt(0) every step)
-            constexpr int NRD = NS * (2 + NB), NMF = NPROD * 2 * NB, PER = NMF / NRD > 0 ? NMF / NRD : 1;
+            #ifdef TSR_EXP_MFMA16
+            constexpr int MFX = F16 ? 2 : 1;
+#else
+            constexpr int MFX = 1;
+#endif
+            constexpr int NRD = NS * (2 + NB), NMF = NPROD * 2 * NB, PER = (NMF / NRD > 0 ? NMF / NRD : 1) * MFX;
 #pragma unroll
             for (int i = 0; i < NRD; ++i) {
               __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
 template <bool F16>
 __global__ void pack_conv_weight_bf16s_kernel(const float* __restrict__ w, typename Plane<F16>::T* __restrict__ wp,
                                               int cout, int cin, int ks, int ns, int tps, int ci0, int cin_f,
-                                              float wscale, const float* __restrict__ w_amax) {
+                                              float wscale, const float* __restrict__ w_amax, int k32) {
   if (w_amax) {                // device-side scale: 2^(13 - floor(log2 max|w|)), 1 for a zero / non-finite maximum
     const float wm = *w_amax;
     wscale = 1.f;
@@ -417,12 +430,31 @@ __global__ void pack_conv_weight_bf16s_kernel(const float* __restrict__ w, typen
     if (tap < T) v = ci0 < 0 ? w[((size_t)n * cin + ci) * T + tap]
                              : w[((size_t)ci * cin_f + ci0 + n) * T + (T - 1 - tap)];
     v *= wscale;
+    // position of this (block, tap) slab in the stream.  k32 (conv_mfma_k32.hip; tps = 1, blocks in pairs): the even
+    // block's taps 0..T-2, the odd block's taps 0..T-2, then the cross pair (last tap of the even, of the odd block)
+    size_t pos = (size_t)chunk * TP + tap;
+    if (k32) {
+      const int odd = chunk & 1;
+      pos = (size_t)(chunk >> 1) * 2 * T + (tap < T - 1 ? odd * (T - 1) + tap : 2 * T - 2 + odd);
+    }
     for (int p = 0; p < ns; ++p) {
       const PT bq = (PT)v;
       v -= (float)bq;
-      wp[((((size_t)(chunk * TP + tap) * ns + p) * 2 + kh) * cout + n) * 8 + j] = bq;
+      wp[(((pos * ns + p) * 2 + kh) * cout + n) * 8 + j] = bq;
     }
   }
+}
+
+// fp16x3 3x3 / 5x5 convolutions run on conv_mfma_k32.hip (16x16x32 MFMA, tap pairs) when the channel blocks come in
+// pairs; TSR_CONV_M32=1 keeps the 32x32x16 kernel of this file (A/B measurements).  Pack and launch ask the same question.
+int tsr_conv_k32(const ConvArgs& a, int cout, int ks, bool ext, hipStream_t st);      // conv_mfma_k32.hip
+int tsr_conv_k32_fuse1x1(const ConvArgs& a, int ks, hipStream_t st);
+// C_out = 64 stays on the 32x32x16 kernel for now (its 4-image form of the K = 32 kernel spills at the block boundaries
+// and measured 0-7 % slower; TSR_CONV_K32_ALL=1 routes it there as well).
+static bool use_k32(int ks, int kdim, int cout) {
+  static const bool off = getenv("TSR_CONV_M32") != nullptr;
+  static const bool all = getenv("TSR_CONV_K32_ALL") != nullptr;
+  return !off && ks > 1 && ((kdim >> 4) & 1) == 0 && (cout == 128 || all);
 }
 
 // bf16 elements a packed weight needs (taps padded to a multiple of the step size)
@@ -441,7 +473,7 @@ extern "C" int tsr_pack_conv_weight_bf16s(const float* w_oihw, void* w_packed, i
   const size_t total = (size_t)cout * cin * (((ks * ks + tps - 1) / tps) * tps);
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel<false>, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
-                     (hipStream_t)stream, w_oihw, (__bf16*)w_packed, cout, cin, ks, nsplit, tps, -1, 0, 1.0f, nullptr);
+                     (hipStream_t)stream, w_oihw, (__bf16*)w_packed, cout, cin, ks, nsplit, tps, -1, 0, 1.0f, nullptr, 0);
   return tsr_check_launch();
 }
 
@@ -452,11 +484,12 @@ extern "C" int tsr_pack_conv_weight_f16s(const float* w_oihw, void* w_packed, in
   if (!w_oihw || !w_packed || (cin & 15) || (cout != 64 && cout != 128) || (ks != 1 && ks != 3 && ks != 5) ||
       !(wscale > 0.f))
     return TSR_ERR_ARG;
-  const int tps = taps_per_step(ks, cout, 2);
+  const int k32 = use_k32(ks, cin, cout);
+  const int tps = k32 ? 1 : taps_per_step(ks, cout, 2);
   const size_t total = (size_t)cout * cin * (((ks * ks + tps - 1) / tps) * tps);
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel<true>, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
-                     (hipStream_t)stream, w_oihw, (_Float16*)w_packed, cout, cin, ks, 2, tps, -1, 0, wscale, nullptr);
+                     (hipStream_t)stream, w_oihw, (_Float16*)w_packed, cout, cin, ks, 2, tps, -1, 0, wscale, nullptr, k32);
   return tsr_check_launch();
 }
 
@@ -464,11 +497,12 @@ extern "C" int tsr_pack_conv_weight_f16s_dev(const float* w_oihw, void* w_packed
                                              const float* w_amax, void* stream) {
   if (!w_oihw || !w_packed || !w_amax || (cin & 15) || (cout != 64 && cout != 128) || (ks != 1 && ks != 3 && ks != 5))
     return TSR_ERR_ARG;
-  const int tps = taps_per_step(ks, cout, 2);
+  const int k32 = use_k32(ks, cin, cout);
+  const int tps = k32 ? 1 : taps_per_step(ks, cout, 2);
   const size_t total = (size_t)cout * cin * (((ks * ks + tps - 1) / tps) * tps);
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel<true>, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
-                     (hipStream_t)stream, w_oihw, (_Float16*)w_packed, cout, cin, ks, 2, tps, -1, 0, 1.0f, w_amax);
+                     (hipStream_t)stream, w_oihw, (_Float16*)w_packed, cout, cin, ks, 2, tps, -1, 0, 1.0f, w_amax, k32);
   return tsr_check_launch();
 }
 
@@ -477,11 +511,12 @@ extern "C" int tsr_pack_conv_weight_dgrad_f16s_dev(const float* w_oihw, void* w_
   if (!w_oihw || !w_packed || !w_amax || (cout & 15) || (nprime != 64 && nprime != 128) || ci0 < 0 ||
       ci0 + nprime > cin || (ks != 1 && ks != 3 && ks != 5))
     return TSR_ERR_ARG;
-  const int tps = taps_per_step(ks, nprime, 2);
+  const int k32 = use_k32(ks, cout, nprime);
+  const int tps = k32 ? 1 : taps_per_step(ks, nprime, 2);
   const size_t total = (size_t)nprime * cout * (((ks * ks + tps - 1) / tps) * tps);
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel<true>, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
-                     (hipStream_t)stream, w_oihw, (_Float16*)w_packed, nprime, cout, ks, 2, tps, ci0, cin, 1.0f, w_amax);
+                     (hipStream_t)stream, w_oihw, (_Float16*)w_packed, nprime, cout, ks, 2, tps, ci0, cin, 1.0f, w_amax, k32);
   return tsr_check_launch();
 }
 
@@ -494,7 +529,7 @@ extern "C" int tsr_pack_conv_weight_dgrad_bf16s(const float* w_oihw, void* w_pac
   const size_t total = (size_t)nprime * cout * (((ks * ks + tps - 1) / tps) * tps);
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel<false>, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
-                     (hipStream_t)stream, w_oihw, (__bf16*)w_packed, nprime, cout, ks, nsplit, tps, ci0, cin, 1.0f, nullptr);
+                     (hipStream_t)stream, w_oihw, (__bf16*)w_packed, nprime, cout, ks, nsplit, tps, ci0, cin, 1.0f, nullptr, 0);
   return tsr_check_launch();
 }
 
@@ -505,6 +540,9 @@ static int launch_bf16s(const ConvArgs& a, hipStream_t st) {
   // (workgroup, image slot): tsr_conv2d_slab_entries_ex tells the caller how many entries this form writes.
   // One plane (plain bf16, the reduced-precision train mode): 4 images for both channel counts -- with one product
   // per MAC the weight stream per MFMA is what bounds the 2-image form (see launch_b16).
+  if constexpr (F16 && NS == 2 && KS > 1) {
+    if (use_k32(KS, a.cin, COUT)) return tsr_conv_k32(a, COUT, KS, EXT, st);
+  }
   constexpr int WN = (KS > 1 && ((COUT == 64 && F16) || NS == 1)) ? 1 : 2;
   constexpr int IMG = 4 / WN;
   const int grid = ((a.B + IMG - 1) / IMG) * a.tiles_x * a.tiles_y;
@@ -537,11 +575,12 @@ extern "C" int tsr_pack_conv_weight_dgrad_f16s(const float* w_oihw, void* w_pack
   if (!w_oihw || !w_packed || (cout & 15) || (nprime != 64 && nprime != 128) || ci0 < 0 || ci0 + nprime > cin ||
       (ks != 1 && ks != 3 && ks != 5) || !(wscale > 0.f))
     return TSR_ERR_ARG;
-  const int tps = taps_per_step(ks, nprime, 2);
+  const int k32 = use_k32(ks, cout, nprime);
+  const int tps = k32 ? 1 : taps_per_step(ks, nprime, 2);
   const size_t total = (size_t)nprime * cout * (((ks * ks + tps - 1) / tps) * tps);
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(pack_conv_weight_bf16s_kernel<true>, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0,
-                     (hipStream_t)stream, w_oihw, (_Float16*)w_packed, nprime, cout, ks, 2, tps, ci0, cin, wscale, nullptr);
+                     (hipStream_t)stream, w_oihw, (_Float16*)w_packed, nprime, cout, ks, 2, tps, ci0, cin, wscale, nullptr, k32);
   return tsr_check_launch();
 }
 
@@ -606,6 +645,7 @@ extern "C" int tsr_conv2d_fwd_f16s_fuse1x1(const float* in, int in_ctot, int in_
   a.w2 = w2_packed; a.w2_inv_scale = w2_inv_scale; a.shift2 = shift2; a.relu2 = relu2;
   const int grid = ((B + 1) / 2) * a.tiles_x * a.tiles_y;
   hipStream_t st = (hipStream_t)stream;
+  if (use_k32(ks, cin, 128)) return tsr_conv_k32_fuse1x1(a, ks, st);
   if (ks == 5) {
     hipLaunchKernelGGL((conv_mfma_split16_kernel<5, 128, 2, false, true, 2, false, false, true>), dim3(grid), dim3(256), 0, st, a);
   } else if (((cin >> 4) & 1) == 0) {

@@ -26,7 +26,14 @@ os.makedirs(dst, exist_ok=True)
 
 
 def files(run, suffix):
-    return glob.glob(os.path.join(src, run, "**", "*" + suffix), recursive=True)
+    """Files of the NEWEST process of a run only: gpurun merges gpurun_out/ into the local copy, so an earlier
+    collection's <pid>_*.csv files are still lying next to the new ones."""
+    fs = glob.glob(os.path.join(src, run, "**", "*" + suffix), recursive=True)
+    if not fs:
+        return fs
+    newest = max(fs, key=os.path.getmtime)
+    pid = os.path.basename(newest).split("_")[0]
+    return [f for f in fs if os.path.basename(f).split("_")[0] == pid]
 
 
 for run in sorted(os.listdir(src)):
