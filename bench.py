@@ -220,7 +220,9 @@ def main():
         peak = PEAK_F32_MFMA if args.impl == "f32" else PEAK_BF16_MFMA
         alg = B * c5_flop / (c5_ms * 1e-3) if ev else None       # algorithmic FLOP/s of the launch
         executed = alg * nprod if ev else None                               # MFMA FLOP/s actually executed
+        k32 = args.impl == "fp16x3" and not os.environ.get("TSR_CONV_M32")      # conv_mfma_k32.hip (16x16x32 MFMA)
         kname = ("conv_mfma_f32_kernel<5, 128" if args.impl == "f32" else
+                 ("conv_k32_kernel<5, 128, false, 2, %s" % ("true" if fused else "false")) if k32 else
                  "conv_mfma_split16_kernel<5, 128, %d, false, %s" % ({"fp16x3": 2, "bf16x6": 3, "bf16x3": 2, "bf16": 1}[args.impl],
                                                                      "true" if args.impl == "fp16x3" else "false"))
         per_kernel = {f"conv{k[0]}x{k[0]}_c{k[1]}": round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 3)
@@ -337,7 +339,9 @@ def main_train(args):
         for k, v in prof.items():
             fam.setdefault(k[0], 0.0)
             fam[k[0]] += sum(a.elapsed_time(b) for a, b in v) / args.steps
-        wname = "wgrad_tr16_kernel<5, 1, 128, 128" if impl != "f32" else "wgrad_mfma_f32_kernel<5"
+        wname = ("wgrad_mfma_f32_kernel<5" if impl == "f32" else
+                 "wgrad_k32_kernel<5, 1, 128, 128" if impl == "fp16x3" and not os.environ.get("TSR_WGRAD_M32") else
+                 "wgrad_tr16_kernel<5, 1, 128, 128")
         traffic, traffic_src = pmc_traffic(wname, "train") if B == 2048 and not args.seqs else (None, None)
         res = {
             "metric": "SR train samples/sec (4x4->%dx%d)" % (side, side), "value": round(value, 2), "unit": "samples/s",

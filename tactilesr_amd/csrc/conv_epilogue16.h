@@ -13,10 +13,9 @@
 #include "conv_epilogue.h"
 
 template <int COUT, bool EXT, int WN = 2, bool IO16 = false>
-__device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[4][COUT / (16 * WN)], int bid, int b0,
+__device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[4][COUT / (16 * WN)], int ebase, int b0,
                                                 int y0, int x0, int wm, int wn, int lane, int HW, float accmul = 1.f) {
   constexpr int NT = COUT / (16 * WN);
-  constexpr int IMG = 4 / WN;
   const int cl = lane & 15, ph = lane >> 4;
   const int k4 = cl >> 2, j = cl & 3;
   const int dyl = ph >> 1, dxl = 4 * (ph & 1);            // this lane's pixel row within a tile / first pixel column
@@ -130,7 +129,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[
         cnt = tot; mean = meanm; m2 = m2m;
       }
       if (ph == 0) {
-        const size_t e = (size_t)bid * IMG + wm;
+        const size_t e = (size_t)ebase + wm;      // (workgroup, image slot) entry
         float* sl = a.slab + (e * COUT + n) * 2;
         sl[0] = mean;
         sl[1] = m2;
@@ -187,7 +186,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[
           s1[c] += __shfl_xor(s1[c], 32); s2[c] += __shfl_xor(s2[c], 32);
         }
         if (ph == 0 && j == 0) {
-          const size_t e = (size_t)bid * IMG + wm;
+          const size_t e = (size_t)ebase + wm;      // (workgroup, image slot) entry
           float* sl = a.slab + (e * COUT + nq) * 2;
 #pragma unroll
           for (int c = 0; c < 4; ++c) { sl[2 * c] = s1[c]; sl[2 * c + 1] = s2[c]; }

@@ -27,6 +27,7 @@
 #include "conv_epilogue16.h"
 #include "conv_fuse1x1_16.h"
 #include "tactilesr_hip.h"
+#include <stdlib.h>
 #include <type_traits>
 
 typedef _Float16 kf16x8 __attribute__((ext_vector_type(8)));
@@ -40,7 +41,7 @@ constexpr int k32_row_slots(int px) {
   return rs;
 }
 
-template <int KS, int COUT, int WN> struct K32Geom {
+template <int KS, int COUT, int WN, bool DBH = false> struct K32Geom {
   static constexpr int IMG = 4 / WN;
   static constexpr int HH = 8 + KS - 1;
   static constexpr int T = KS * KS;
@@ -51,18 +52,24 @@ template <int KS, int COUT, int WN> struct K32Geom {
   static constexpr int HALO_B = IMG * IMGB;
   static constexpr int SROWB = k32_row_slots(8) * 16;
   static constexpr int SIMGB = 8 * SROWB;
-  static constexpr int SIDE_B = IMG * SIMGB;
+  static constexpr int SIDE_B = DBH ? 0 : IMG * SIMGB;         // (two resident slabs need no side buffer)
   static constexpr int WTAP_B = 2 * 16 * COUT * 2;             // [plane 2][k half 2][C_out][8] fp16
   static constexpr int WSLAB_B = 2 * WTAP_B;                   // one step = one pair of taps
-  static constexpr int MAIN_LDS = HALO_B + SIDE_B + 3 * WSLAB_B;
+  static constexpr int NHB = DBH ? 2 : 1;
+  static constexpr int MAIN_LDS = NHB * HALO_B + SIDE_B + 3 * WSLAB_B;
 };
 
-template <int KS, int COUT, bool EXT, int WN, bool FUSE2 = false>
+// DBH (3x3): double-buffered halo.  Both blocks of a pair are resident, so the cross step reads its two taps straight
+// from the two slabs (no side buffer) and sits BETWEEN the blocks: even block taps 0..7, cross (tap 8 | tap 8), odd block
+// taps 0..7.  The odd block's slab is staged under the even block's steps and the next even block's under the odd
+// block's: no block boundary is left in the loop (a 3x3 block is only 4.5 steps long; the boundary's barrier pair,
+// conversion burst and exposed first fragment read cost 15 % there).
+template <int KS, int COUT, bool EXT, int WN, bool FUSE2 = false, bool DBH = false>
 __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
   static_assert(COUT == 64 * WN, "every wave owns 64 channels");
   static_assert(!FUSE2 || (!EXT && COUT == 128), "fused 1x1: 128 channels, inference");
-  typedef K32Geom<KS, COUT, WN> G;
-  constexpr int IMG = G::IMG, P = KS / 2, HH = G::HH, T = G::T, HS = G::HS, NT = 4;
+  typedef K32Geom<KS, COUT, WN, DBH> G;
+  constexpr int IMG = G::IMG, P = KS / 2, HH = G::HH, T = G::T, HS = G::HS, NT = COUT / (16 * WN);
   constexpr int PIXB = G::PIXB, ROWB = G::ROWB, IMGB = G::IMGB, HALO_B = G::HALO_B;
   constexpr int SROWB = G::SROWB, SIMGB = G::SIMGB, SIDE_B = G::SIDE_B;
   constexpr int WTAP_B = G::WTAP_B, WSLAB_B = G::WSLAB_B;
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
   constexpr int FUSE_LDS = FUSE2 ? Fuse1x1Geom16::BYTES + 64 : 0;
   __shared__ __attribute__((aligned(16))) char lds[G::MAIN_LDS > FUSE_LDS ? G::MAIN_LDS : FUSE_LDS];
   char* halo = lds;
-  char* wbuf = lds + HALO_B + SIDE_B;     // 3-slot ring: slab s lives in slot s % 3
+  char* wbuf = lds + G::NHB * HALO_B + SIDE_B;     // 3-slot ring: slab s lives in slot s % 3
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -129,6 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
   const int tpi = a.tiles_x * a.tiles_y;
   const int ig = bid / tpi;
   const int trem = bid - ig * tpi;
+  const int ebase = bid * IMG;       // first statistics-slab entry of this workgroup (train epilogues)
   const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
   const int y0 = ty * 8, x0 = tx * 8, b0 = ig * IMG;
   const int HW = a.H * a.W;
@@ -160,6 +168,7 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
   const int lc = tsel ? laneA0 + (KS - 1) * ROWB + (KS - 1) * PIXB
                       : HALO_B + wm * SIMGB + (m >> 3) * SROWB + (m & 7) * PIXB + khalf * 16;
   const int lcs = tsel ? 2 * ROWB : 2 * SROWB;
+  const int lcd = laneA0 + (KS - 1) * (ROWB + PIXB) + tsel * HALO_B;      // DBH cross step: last tap of slab 0 | of slab 1
   const int laneB = tsel * WTAP_B + (khalf * COUT + wn * (COUT / WN) + m) * 16;
 
   f32x4 acc[4][NT];
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) hv[k] = *(const f32x4*)(inc + (unsigned)(st_src[k] < 0 ? 0 : st_src[k]));
   };
-  auto store_halo = [&](const f32x4* hv, int c) {
+  auto store_halo = [&](const f32x4* hv, int c, int hb = 0) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       if (st_dst[k] >= 0) {
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
             bq[jj] = (_Float16)v[jj];
             v[jj] -= (float)bq[jj];
           }
-          *(kf16x4*)(halo + st_dst[k] + p * 32) = bq;
+          *(kf16x4*)(halo + hb * HALO_B + st_dst[k] + p * 32) = bq;
         }
       }
     }
@@ -218,15 +227,19 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
     _Pragma("unroll") for (int v = 0; v < WV; ++v) ((f32x4*)wb_)[tid + v * 256] = wreg[v]; \
   }
   // fragments of pair step st_ (taps 2 st_, 2 st_ + 1 of the resident block), plane p_
-#define LOAD_A(dst, p_, st_)                                                             \
+#define LOAD_A(dst, p_, st_, hb_)                                                        \
   {                                                                                      \
     const int kh_ = (2 * (st_)) / KS, kw_ = (2 * (st_)) - kh_ * KS;                      \
-    const char* ab_ = lds + (kw_ < KS - 1 ? lx : lw) + kh_ * ROWB + kw_ * PIXB + (p_) * 32; \
+    const char* ab_ = lds + (kw_ < KS - 1 ? lx : lw) + (hb_) * HALO_B + kh_ * ROWB + kw_ * PIXB + (p_) * 32; \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) dst[mt] = *(const kf16x8*)(ab_ + mt * 2 * ROWB); \
   }
 #define LOAD_A_CROSS(dst, p_)                                                            \
   {                                                                                      \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) dst[mt] = *(const kf16x8*)(lds + lc + mt * lcs + (p_) * 32); \
+  }
+#define LOAD_A_CROSSD(dst, p_)                                                           \
+  {                                                                                      \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) dst[mt] = *(const kf16x8*)(lds + lcd + mt * 2 * ROWB + (p_) * 32); \
   }
 #define LOAD_B(dst, p_, slot_)                                                           \
   {                                                                                      \
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
   __syncthreads();
 
   kf16x8 A0[4], A1[4], B0[NT], B1[NT];
-  LOAD_A(A1, 1, 0);
+  LOAD_A(A1, 1, 0, 0);
   LOAD_B(B0, 0, 0);
 
   // side-buffer copy of the last tap's 8x8 window (even blocks): IMG 16-B items per thread, item k = image k
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
       const bool cross = ODD && st == HS;
       f32x4 sidev[IMG];
       // this step's second-phase operands
-      if (cross) { LOAD_A_CROSS(A0, 0); } else { LOAD_A(A0, 0, st); }
+      if (cross) { LOAD_A_CROSS(A0, 0); } else { LOAD_A(A0, 0, st, 0); }
       LOAD_B(B1, 1, slot);
       if (!ODD && st == 0) {
 #pragma unroll
@@ -284,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
       MFMA_PHASE(A1, B0);                                          // P0: h2 g1
       if (!ODD && st == 0) { INTERLEAVE(8 + IMG, 1); } else { INTERLEAVE(8, 2); }
       if (st + 1 < NST) {                                          // next step's A1 (same block: the slab is resident)
-        if (ODD && st + 1 == HS) { LOAD_A_CROSS(A1, 1); } else { LOAD_A(A1, 1, st + 1); }
+        if (ODD && st + 1 == HS) { LOAD_A_CROSS(A1, 1); } else { LOAD_A(A1, 1, st + 1, 0); }
       }
       MFMA_PHASE(A0, B0);                                          // P1: h1 g1
       if (st + 1 < NST) { INTERLEAVE(4, 4); }
@@ -301,35 +314,72 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
       if (st + 1 == NST && c + 1 < nchunk) {
         store_halo(hv, c + 1);     // every wave is past its last read of the old slab (barrier above)
         __syncthreads();
-        LOAD_A(A1, 1, 0);
+        LOAD_A(A1, 1, 0, 0);
       }
       ++s;
       slot = slot1;
     }
   };
-  for (int c = 0; c < nchunk; c += 2) {
-    block(c, std::integral_constant<int, 0>());
-    block(c + 1, std::integral_constant<int, 1>());
+  if constexpr (!DBH) {
+    for (int c = 0; c < nchunk; c += 2) {
+      block(c, std::integral_constant<int, 0>());
+      block(c + 1, std::integral_constant<int, 1>());
+    }
+  } else {
+    for (int c = 0; c < nchunk; c += 2) {
+#pragma unroll
+      for (int p = 0; p < T; ++p) {          // even block: p < HS (slab 0); cross: p == HS; odd block: p > HS (slab 1)
+        const int slot1 = slot == 2 ? 0 : slot + 1;
+        const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
+        if (p == HS) { LOAD_A_CROSSD(A0, 0); }
+        else if (p < HS) { LOAD_A(A0, 0, p, 0); }
+        else { LOAD_A(A0, 0, p - HS - 1, 1); }
+        LOAD_B(B1, 1, slot);
+        if (p == 0) load_halo(c + 1, hv);                          // the odd block's slab (the block count is even)
+        if (p == HS + 1 && c + 2 < nchunk) load_halo(c + 2, hv);   // the next pair's even block
+        MFMA_PHASE(A1, B0);
+        INTERLEAVE(8, 2);
+        if (p + 1 == HS) { LOAD_A_CROSSD(A1, 1); }
+        else if (p + 1 < HS) { LOAD_A(A1, 1, p + 1, 0); }
+        else if (p + 1 < T) { LOAD_A(A1, 1, p - HS, 1); }
+        else { LOAD_A(A1, 1, 0, 0); }                              // next pair's first step (after the last pair: unused)
+        MFMA_PHASE(A0, B0);
+        INTERLEAVE(4, 4);
+        LOAD_B(B0, 0, slot1);
+        MFMA_PHASE(A0, B1);
+        INTERLEAVE(4, 4);
+        if (p == HS - 2) store_halo(hv, c + 1, 1);                 // slab 1: last read in the previous pair
+        if (p == T - 2 && c + 2 < nchunk) store_halo(hv, c + 2, 0);  // slab 0: last read by the cross step
+        if (s + 2 < S) STORE_W(slot2);
+        if (s + 3 < S) LOAD_W(s + 3);
+        __syncthreads();
+        ++s;
+        slot = slot1;
+      }
+    }
   }
 #undef LOAD_W
 #undef STORE_W
 #undef LOAD_A
 #undef LOAD_A_CROSS
+#undef LOAD_A_CROSSD
 #undef LOAD_B
 #undef MFMA_PHASE
 #undef INTERLEAVE
 
   if constexpr (FUSE2) conv_fuse1x1_epilogue16(a, acc, lds, b0, y0, x0, wm, wn, lane, HW, accmul);
-  else conv_epilogue16<COUT, EXT, WN>(a, acc, bid, b0, y0, x0, wm, wn, lane, HW, accmul);
+  else conv_epilogue16<COUT, EXT, WN>(a, acc, ebase, b0, y0, x0, wm, wn, lane, HW, accmul);
 }
 
 // ---- launchers (called from conv_mfma_split16.hip's dispatchers; argument checks were done there) -------------------
 template <int KS, int COUT, bool EXT>
 static int launch_k32(const ConvArgs& a, hipStream_t st) {
+  // (C_out = 64 as 2 images x 2 halves of 32 channels, 3 workgroups per CU, measured no better than the 4-image form:
+  // 5x5 3.41 vs 3.39 ms, 3x3 1.60 vs 1.68 ms at B = 4096; the 32x32x16 kernel does 3.23 / 1.61 ms)
   constexpr int WN = COUT / 64;
   constexpr int IMG = 4 / WN;
   const int grid = ((a.B + IMG - 1) / IMG) * a.tiles_x * a.tiles_y;
-  hipLaunchKernelGGL((conv_k32_kernel<KS, COUT, EXT, WN, false>), dim3(grid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((conv_k32_kernel<KS, COUT, EXT, WN, false, KS == 3>), dim3(grid), dim3(256), 0, st, a);
   return tsr_check_launch();
 }
 
@@ -351,6 +401,6 @@ int tsr_conv_k32(const ConvArgs& a, int cout, int ks, bool ext, hipStream_t st) 
 int tsr_conv_k32_fuse1x1(const ConvArgs& a, int ks, hipStream_t st) {
   const int grid = ((a.B + 1) / 2) * a.tiles_x * a.tiles_y;
   if (ks == 5) hipLaunchKernelGGL((conv_k32_kernel<5, 128, false, 2, true>), dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_k32_kernel<3, 128, false, 2, true>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_k32_kernel<3, 128, false, 2, true, true>), dim3(grid), dim3(256), 0, st, a);
   return tsr_check_launch();
 }

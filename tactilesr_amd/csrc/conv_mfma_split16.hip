@@ -227,18 +227,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
     if (IO16) {     // 4 bf16 = 8 B per item, carried in the low half of the f32x4 slot
       const __bf16* inc = in_base16 + (size_t)c * HW * 16;
 #pragma unroll
-      for (int k = 0; k < NIT; ++k) {   // branch-free (see below): dummy address, zeroed by a select
-        float2 t = *(const float2*)(inc + (unsigned)(st_src[k] < 0 ? 0 : st_src[k]));
-        if (st_src[k] < 0) t = make_float2(0.f, 0.f);
-        hv[k] = (f32x4){t.x, t.y, 0.f, 0.f};
+      for (int k = 0; k < NIT; ++k) {
+        hv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (st_src[k] >= 0) {
+          const float2 t = *(const float2*)(inc + st_src[k]);
+          hv[k][0] = t.x;
+          hv[k][1] = t.y;
+        }
       }
       return;
     }
     const float* inc = in_base + (size_t)c * HW * 16;
-    // branch-free: out-of-image items read a valid dummy address (offset 0) and are zeroed in store_halo (hipcc otherwise
-    // wraps every load in its own exec-masked branch)
+    // (a branch-free form -- dummy address + zero scale, as in conv_mfma_k32.hip -- measured 1-7 % slower here: every
+    // address is live at once and the one-plane variants start to spill)
 #pragma unroll
-    for (int k = 0; k < NIT; ++k) hv[k] = *(const f32x4*)(inc + (unsigned)(st_src[k] < 0 ? 0 : st_src[k]));
+    for (int k = 0; k < NIT; ++k) {
+      hv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (st_src[k] >= 0) hv[k] = *(const f32x4*)(inc + st_src[k]);
+    }
   };
   auto store_halo = [&](const f32x4* hv, int c, int hb) {
     if (IO16) {
@@ -251,17 +257,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
     for (int k = 0; k < NIT; ++k) {
       if (st_dst[k] >= 0) {
         f32x4 v = hv[k];
-        if (EXT && a.in_scale) {   // producer's train-mode BN+ReLU, fused into the load
+        if (EXT && a.in_scale && st_src[k] >= 0) {   // producer's train-mode BN+ReLU, fused into the load
           const int cq = c * 16 + ((tid + k * 256) & 3) * 4;
           const f32x4 sc = *(const f32x4*)(a.in_scale + cq);
           const f32x4 sh = *(const f32x4*)(a.in_shift + cq);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), 0.f);
         }
-        {   // operand scale of the fp16 planes; zero padding outside the image
-          const float mk = st_src[k] >= 0 ? (F16 ? sx : 1.f) : 0.f;
+        if (F16) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] *= mk;
+          for (int j = 0; j < 4; ++j) v[j] *= sx;
         }
 #pragma unroll
         for (int p = 0; p < NS; ++p) {
@@ -430,12 +435,15 @@ __global__ void pack_conv_weight_bf16s_kernel(const float* __restrict__ w, typen
     if (tap < T) v = ci0 < 0 ? w[((size_t)n * cin + ci) * T + tap]
                              : w[((size_t)ci * cin_f + ci0 + n) * T + (T - 1 - tap)];
     v *= wscale;
-    // position of this (block, tap) slab in the stream.  k32 (conv_mfma_k32.hip; tps = 1, blocks in pairs): the even
+    // position of this (block, tap) slab in the stream.  k32 = 1 (conv_mfma_k32.hip; tps = 1, blocks in pairs): the even
     // block's taps 0..T-2, the odd block's taps 0..T-2, then the cross pair (last tap of the even, of the odd block)
     size_t pos = (size_t)chunk * TP + tap;
-    if (k32) {
+    if (k32 == 1) {
       const int odd = chunk & 1;
       pos = (size_t)(chunk >> 1) * 2 * T + (tap < T - 1 ? odd * (T - 1) + tap : 2 * T - 2 + odd);
+    } else if (k32 == 2) {     // 3x3 (double-buffered halo): even block taps 0..T-2, cross pair, odd block taps 0..T-2
+      const int odd = chunk & 1;
+      pos = (size_t)(chunk >> 1) * 2 * T + (tap < T - 1 ? odd * (T + 1) + tap : T - 1 + odd);
     }
     for (int p = 0; p < ns; ++p) {
       const PT bq = (PT)v;
@@ -456,6 +464,7 @@ static bool use_k32(int ks, int kdim, int cout) {
   static const bool all = getenv("TSR_CONV_K32_ALL") != nullptr;
   return !off && ks > 1 && ((kdim >> 4) & 1) == 0 && (cout == 128 || all);
 }
+static int k32_mode(int ks, int kdim, int cout) { return use_k32(ks, kdim, cout) ? (ks == 3 ? 2 : 1) : 0; }
 
 // bf16 elements a packed weight needs (taps padded to a multiple of the step size)
 extern "C" long long tsr_conv_weight_bf16s_elems(int cout, int cin, int ks, int nsplit) {
@@ -484,7 +493,7 @@ extern "C" int tsr_pack_conv_weight_f16s(const float* w_oihw, void* w_packed, in
   if (!w_oihw || !w_packed || (cin & 15) || (cout != 64 && cout != 128) || (ks != 1 && ks != 3 && ks != 5) ||
       !(wscale > 0.f))
     return TSR_ERR_ARG;
-  const int k32 = use_k32(ks, cin, cout);
+  const int k32 = k32_mode(ks, cin, cout);
   const int tps = k32 ? 1 : taps_per_step(ks, cout, 2);
   const size_t total = (size_t)cout * cin * (((ks * ks + tps - 1) / tps) * tps);
   const int grid = (int)((total + 255) / 256);
@@ -497,7 +506,7 @@ extern "C" int tsr_pack_conv_weight_f16s_dev(const float* w_oihw, void* w_packed
                                              const float* w_amax, void* stream) {
   if (!w_oihw || !w_packed || !w_amax || (cin & 15) || (cout != 64 && cout != 128) || (ks != 1 && ks != 3 && ks != 5))
     return TSR_ERR_ARG;
-  const int k32 = use_k32(ks, cin, cout);
+  const int k32 = k32_mode(ks, cin, cout);
   const int tps = k32 ? 1 : taps_per_step(ks, cout, 2);
   const size_t total = (size_t)cout * cin * (((ks * ks + tps - 1) / tps) * tps);
   const int grid = (int)((total + 255) / 256);
@@ -511,7 +520,7 @@ extern "C" int tsr_pack_conv_weight_dgrad_f16s_dev(const float* w_oihw, void* w_
   if (!w_oihw || !w_packed || !w_amax || (cout & 15) || (nprime != 64 && nprime != 128) || ci0 < 0 ||
       ci0 + nprime > cin || (ks != 1 && ks != 3 && ks != 5))
     return TSR_ERR_ARG;
-  const int k32 = use_k32(ks, cout, nprime);
+  const int k32 = k32_mode(ks, cout, nprime);
   const int tps = k32 ? 1 : taps_per_step(ks, nprime, 2);
   const size_t total = (size_t)nprime * cout * (((ks * ks + tps - 1) / tps) * tps);
   const int grid = (int)((total + 255) / 256);
@@ -575,7 +584,7 @@ extern "C" int tsr_pack_conv_weight_dgrad_f16s(const float* w_oihw, void* w_pack
   if (!w_oihw || !w_packed || (cout & 15) || (nprime != 64 && nprime != 128) || ci0 < 0 || ci0 + nprime > cin ||
       (ks != 1 && ks != 3 && ks != 5) || !(wscale > 0.f))
     return TSR_ERR_ARG;
-  const int k32 = use_k32(ks, cout, nprime);
+  const int k32 = k32_mode(ks, cout, nprime);
   const int tps = k32 ? 1 : taps_per_step(ks, nprime, 2);
   const size_t total = (size_t)nprime * cout * (((ks * ks + tps - 1) / tps) * tps);
   const int grid = (int)((total + 255) / 256);

@@ -37,7 +37,18 @@ template <> struct TPlane<false> {
 };
 template <> struct TPlane<true> {
   typedef _Float16 T; typedef th16x8 V8; typedef th16x4 V4;
-  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
+#ifdef TSR_EXP_MFMA16   // timing experiment only (wrong results): the same FLOPs as two 16x16x32 instructions
+    f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+    c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
+    c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+  }
 };
 
 struct WgradTArgs {
@@ -461,6 +472,344 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// K = 32 form (v_mfma_f32_16x16x32_f16), fp16x3 arithmetic: the default weight-gradient kernel.  Same tiles, same staging,
+// same transposing LDS reads as wgrad_tr16_kernel; the matrix instruction is the 16x16x32 one because the chip holds a
+// higher clock on it under load (conv_mfma_k32.hip; measured here with the instruction swapped in place: 5x5 128x128
+// 3.42 -> 3.14 ms).  K = 32 = the whole 4-row x 8-column work item: lane group g = lane >> 4 supplies patch row g, two
+// ds_read_b64_tr_b16 give a lane the 8 pixels of that row for its channel.  Consequences:
+//   * the two 16-lane groups of a half-wave now read two ROWS of one channel block (not two blocks): rows are pitched
+//     12 pixels (384 B == 128 mod 256) in both tiles, so they still cover complementary halves of the 64 banks;
+//   * accumulators are 16x16 tiles (co tile x ci tile x tap x 4 registers: the same 160 / 144 registers), and to stay
+//     inside the register file the fragments are NOT all resident: the item runs as three product sweeps over its
+//     taps -- dz plane 1 x a plane 0, dz 0 x a 0, dz 0 x a 1 -- holding one dz plane (WM/16 fragments) and a
+//     ping-pong pair of a-fragments; plane 0 of a is read in two sweeps (LDS reads per item 76 instead of 56, at
+//     2 cycles each against 1,920 MFMA cycles).  The staging block (conversion + LDS writes of the next item) sits
+//     between the first and the second sweep.
+template <int KS, int KHW, int CO, int CI, int WM>
+struct WgradKGeom {
+  static constexpr int NWM = CO / WM, NWN = CI / 32, NWAVE = NWM * NWN, NT = 64 * NWAVE;
+  static constexpr int MT = WM / 16;
+  static constexpr int NKG = (KS + KHW - 1) / KHW;
+  static constexpr int NTAP = KHW * KS;
+  static constexpr int ACOLS = 8 + KS - 1, AROWS = 4 + KHW - 1;
+  static constexpr int PITCH = 12;                                   // pixels per tile row in LDS (both tiles)
+  static constexpr int DZ_PX = 32, A_PX = AROWS * ACOLS;             // staged pixels per block
+  static constexpr int DZ_BLKB = tr16_pad_px(4 * PITCH) * 32, A_BLKB = tr16_pad_px(AROWS * PITCH) * 32;
+  static constexpr int DZ_PLANEB = (CO / 16) * DZ_BLKB, A_PLANEB = (CI / 16) * A_BLKB;
+  static constexpr int BUFB = 2 * (DZ_PLANEB + A_PLANEB);
+  static constexpr int N_DZ = DZ_PX * (CO / 16) * 4, N_A = A_PX * (CI / 16) * 4;
+  static constexpr int NIT_DZ = (N_DZ + NT - 1) / NT, NIT_A = (N_A + NT - 1) / NT;
+  static constexpr int LDSB = (2 * BUFB > 32 * CO * 4 ? 2 * BUFB : 32 * CO * 4) + CI * 8;
+};
+
+template <int KS, int KHW, int CO, int CI, int WM>
+__global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kernel(const WgradTArgs g) {
+  typedef WgradKGeom<KS, KHW, CO, CI, WM> G;
+  typedef _Float16 PT;
+  typedef th16x8 PV8;
+  typedef th16x4 PV4;
+  typedef __attribute__((address_space(3))) tv4i16* lds_v4;
+  constexpr int P = KS / 2;
+  constexpr int NT = G::NT, MT = G::MT;
+
+  __shared__ __attribute__((aligned(16))) char lds[G::LDSB];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x;
+  const int wm = wave / G::NWN, wn = wave - wm * G::NWN;
+
+  const int nci = g.cin / CI, nco = g.cout / CO;
+  int bid;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int cib = bid % nci; bid /= nci;
+  const int cob = bid % nco; bid /= nco;
+  const int kg = bid % G::NKG;
+  const int sp = bid / G::NKG;
+  const int kh0 = kg * KHW;
+
+  const int HW = g.H * g.W;
+  const int a_blocks = g.a_ctot >> 4, dz_blocks = g.dz_ctot >> 4;
+  const int a_c0 = g.a_coff + cib * CI, dz_c0 = g.dz_coff + cob * CO;
+  const bool do_bias = g.bslab && cib == 0 && kg == 0;
+
+  float s_a = 1.f, s_d = 1.f;
+  {
+    float ma = g.a_amax ? *g.a_amax : 0.f;
+    if (g.a_scale) {
+      float* bnd = (float*)lds;
+      float ms = 0.f, mt = 0.f;
+      for (int c = threadIdx.x; c < CI; c += NT) {
+        ms = fmaxf(ms, fabsf(g.a_scale[cib * CI + c]));
+        mt = fmaxf(mt, fabsf(g.a_shift[cib * CI + c]));
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        ms = fmaxf(ms, __shfl_xor(ms, o));
+        mt = fmaxf(mt, __shfl_xor(mt, o));
+      }
+      if (lane == 0) { bnd[wave * 2] = ms; bnd[wave * 2 + 1] = mt; }
+      __syncthreads();
+      ms = 0.f; mt = 0.f;
+      for (int w = 0; w < NT / 64; ++w) { ms = fmaxf(ms, bnd[w * 2]); mt = fmaxf(mt, bnd[w * 2 + 1]); }
+      __syncthreads();
+      ma = ma * ms + mt;
+    }
+    s_a = tr16_pow2_scale(ma);
+    s_d = tr16_pow2_scale(g.dz_amax ? *g.dz_amax : 0.f);
+  }
+
+  f32x4 acc[MT][2][G::NTAP];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int k = 0; k < G::NTAP; ++k) acc[m][n][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float bsum[G::NIT_DZ][4];
+#pragma unroll
+  for (int j = 0; j < G::NIT_DZ; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bsum[j][q] = 0.f;
+
+  const int tpi = g.tiles_x * g.tiles_y;
+  const int total_items = g.B * tpi;
+  const int per = (total_items + g.nsplit - 1) / g.nsplit;
+  const int it0 = sp * per;
+  const int it1 = it0 + per < total_items ? it0 + per : total_items;
+  int nb = it0 / tpi, nty = (it0 - nb * tpi) / g.tiles_x, ntx = it0 - nb * tpi - nty * g.tiles_x;
+
+  // staging slots (see wgrad_tr16_kernel): branch-free loads, scalar item base + 32-bit per-thread offsets
+  int offd[G::NIT_DZ], safed[G::NIT_DZ], offa[G::NIT_A], safea[G::NIT_A], rcd[G::NIT_DZ], rca[G::NIT_A], ldsd[G::NIT_DZ], ldsa[G::NIT_A];
+#pragma unroll
+  for (int j = 0; j < G::NIT_DZ; ++j) {
+    const int i = (tid + j * NT) % G::N_DZ;
+    const int q = i & 3, px = (i >> 2) & 31, blk = i >> 7;
+    safed[j] = blk * HW * 16 + q * 4;
+    offd[j] = safed[j] + ((px >> 3) * g.W + (px & 7)) * 16;
+    rcd[j] = ((px >> 3) << 8) | (px & 7);
+    ldsd[j] = blk * G::DZ_BLKB + ((px >> 3) * G::PITCH + (px & 7)) * 32 + q * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < G::NIT_A; ++j) {
+    const int i = (tid + j * NT) % G::N_A;
+    const int q = i & 3, pi = i >> 2;
+    const int px = pi % G::A_PX, blk = pi / G::A_PX;
+    const int r = px / G::ACOLS, cx = px - r * G::ACOLS;
+    safea[j] = blk * HW * 16 + q * 4;
+    offa[j] = safea[j] + ((r + kh0 - P) * g.W + cx - P) * 16;
+    rca[j] = (r << 8) | cx;
+    ldsa[j] = blk * G::A_BLKB + (r * G::PITCH + cx) * 32 + q * 8;
+  }
+  float* tsc = (float*)(lds + 2 * G::BUFB);
+  if (g.a_scale) {
+    for (int c = threadIdx.x; c < CI; c += NT) {
+      tsc[c] = g.a_scale[cib * CI + c];
+      tsc[CI + c] = g.a_shift[cib * CI + c];
+    }
+  }
+
+  f32x4 hd[G::NIT_DZ], ha[G::NIT_A];
+  unsigned okd = 0, oka = 0;
+
+  auto load_item = [&]() {
+    const int b = nb, y0 = nty * 4, x0 = ntx * 8;
+    if (++ntx == g.tiles_x) {
+      ntx = 0;
+      if (++nty == g.tiles_y) { nty = 0; ++nb; }
+    }
+    const float* dzb = g.dz + (((size_t)b * dz_blocks + (dz_c0 >> 4)) * HW + y0 * g.W + x0) * 16;
+    const float* ab = g.a + (((size_t)b * a_blocks + (a_c0 >> 4)) * HW + y0 * g.W + x0) * 16;
+    okd = oka = 0;
+#pragma unroll
+    for (int j = 0; j < G::NIT_DZ; ++j) {
+      const bool ok = (y0 + (rcd[j] >> 8) < g.H) & (x0 + (rcd[j] & 255) < g.W);
+      hd[j] = *(const f32x4*)(dzb + (ok ? offd[j] : safed[j]));
+      okd |= (unsigned)ok << j;
+    }
+#pragma unroll
+    for (int j = 0; j < G::NIT_A; ++j) {
+      const int gy = y0 + (rca[j] >> 8) + kh0 - P, gx = x0 + (rca[j] & 255) - P;
+      const bool ok = (gy >= 0) & (gy < g.H) & (gx >= 0) & (gx < g.W);
+      ha[j] = *(const f32x4*)(ab + (ok ? offa[j] : safea[j]));
+      oka |= (unsigned)ok << j;
+    }
+  };
+
+  auto split_store = [&](f32x4 v, char* dst, int plane_stride, float mult) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] *= mult;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      PV4 qv;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        qv[c] = (PT)v[c];
+        v[c] -= (float)qv[c];
+      }
+      *(PV4*)(dst + p * plane_stride) = qv;
+    }
+  };
+
+  auto store_item = [&](int buf) {
+    char* dzt = lds + buf * G::BUFB;
+    char* at = dzt + 2 * G::DZ_PLANEB;
+#pragma unroll
+    for (int j = 0; j < G::NIT_DZ; ++j) {
+      if ((j + 1) * NT <= G::N_DZ || tid + j * NT < G::N_DZ) {
+        const f32x4 v = hd[j];
+        const bool ok = (okd >> j) & 1;
+        if (do_bias) {
+          const float keep = ok ? 1.f : 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) bsum[j][c] = fmaf(v[c], keep, bsum[j][c]);
+        }
+        split_store(v, dzt + ldsd[j], G::DZ_PLANEB, ok ? s_d : 0.f);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < G::NIT_A; ++j) {
+      if ((j + 1) * NT <= G::N_A || tid + j * NT < G::N_A) {
+        f32x4 v = ha[j];
+        if (g.a_scale) {
+          const int cq = ((ldsa[j] / G::A_BLKB) * 16) + ((ldsa[j] >> 1) & 12);
+          const f32x4 sc = *(const f32x4*)(tsc + cq), sh = *(const f32x4*)(tsc + CI + cq);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = fmaxf(fmaf(v[c], sc[c], sh[c]), 0.f);
+        }
+        split_store(v, at + ldsa[j], G::A_PLANEB, ((oka >> j) & 1) ? s_a : 0.f);
+      }
+    }
+  };
+
+  // fragment addressing: lane = 16 g + 4 q + p supplies the address of pixel (row g, column c0 + q), channels 4p..4p+3 of
+  // its block and receives pixels c0..c0+3 of row g for channel (lane & 15)
+  const int gq = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int a_lane = (wm * MT) * G::DZ_BLKB + (gq * G::PITCH + tq) * 32 + tp * 8;
+  const int b_lane = (wn * 2) * G::A_BLKB + (gq * G::PITCH + tq) * 32 + tp * 8;
+
+  auto mma_item = [&](int buf, auto&& between_sweeps) {
+    const char* dzt = lds + buf * G::BUFB;
+    const char* at = dzt + 2 * G::DZ_PLANEB;
+    auto load_b = [&](PV8* bf, int plane, int tap) {
+      const int khl = tap / KS, kw = tap - khl * KS;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const char* base = at + plane * G::A_PLANEB + b_lane + n * G::A_BLKB + (khl * G::PITCH + kw) * 32;
+        const tv4i16 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base));
+        const tv4i16 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base + 4 * 32));
+        bf[n] = __builtin_shufflevector(__builtin_bit_cast(PV4, r0), __builtin_bit_cast(PV4, r1), 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    };
+    auto load_a = [&](PV8* af, int plane) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const char* base = dzt + plane * G::DZ_PLANEB + a_lane + m * G::DZ_BLKB;
+        const tv4i16 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base));
+        const tv4i16 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base + 4 * 32));
+        af[m] = __builtin_shufflevector(__builtin_bit_cast(PV4, r0), __builtin_bit_cast(PV4, r1), 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+    };
+    // sweeps (small terms first): dz plane 1 x a plane 0, dz 0 x a 1, dz 0 x a 0
+    constexpr int SA[3] = {1, 0, 0}, SB[3] = {0, 1, 0};
+    PV8 af[MT], bf[2][2];
+#pragma unroll
+    for (int sw = 0; sw < 3; ++sw) {
+      // (prefetching sweep 2's first tap under sweep 1's last one spills at 128 x 128 x 5 taps: 3.28 -> 4.11 ms)
+      if (sw != 2) load_a(af, SA[sw]);                 // sweeps 1 and 2 share dz plane 0
+      load_b(bf[0], SB[sw], 0);
+#pragma unroll
+      for (int tap = 0; tap < G::NTAP; ++tap) {
+        const int cb = tap & 1;
+        if (tap + 1 < G::NTAP) load_b(bf[cb ^ 1], SB[sw], tap + 1);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            acc[m][n][tap] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf[cb][n], acc[m][n][tap], 0, 0, 0);
+        if (tap + 1 < G::NTAP) {
+          constexpr int NMF = MT * 2, PER = NMF / 4 > 0 ? NMF / 4 : 1;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (sw == 0) {       // the staging block: no fragment is live across it
+        between_sweeps();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  __syncthreads();
+  if (it0 < it1) {
+    load_item();
+    store_item(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int item = it0; item < it1; ++item) {
+    const bool more = item + 1 < it1;
+    if (more) load_item();
+    mma_item(cur, [&]() {
+      if (more) store_item(cur ^ 1);
+    });
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  {   // this split's partial dW: slab[sp][co][ci][kh][kw]
+    constexpr int T = KS * KS;
+    float* sl = g.slab + (size_t)sp * g.cout * g.cin * T;
+    const float inv = 1.f / (s_a * s_d);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int ci = cib * CI + wn * 32 + n * 16 + (lane & 15);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int tap = 0; tap < G::NTAP; ++tap) {
+          if (kh0 * KS + tap < T) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int co = cob * CO + wm * WM + m * 16 + 4 * gq + r;
+              sl[((size_t)co * g.cin + ci) * T + kh0 * KS + tap] = acc[m][n][tap][r] * inv;
+            }
+          }
+        }
+    }
+  }
+
+  if (do_bias) {
+    float* bred = (float*)lds;                 // [32 px][CO]
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < G::NIT_DZ; ++j) {
+      const int i = tid + j * NT;
+      if ((j + 1) * NT <= G::N_DZ || i < G::N_DZ) {
+        const int q = i & 3, px = (i >> 2) & 31, blk = i >> 7;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bred[px * CO + blk * 16 + q * 4 + c] = bsum[j][c];
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < CO; c += NT) {
+      float s = 0.f;
+#pragma unroll
+      for (int px = 0; px < 32; ++px) s += bred[px * CO + c];
+      g.bslab[(size_t)sp * g.cout + cob * CO + c] = s;
+    }
+  }
+}
+
 // Tile / row-group choice per layer shape (2-plane and 1-plane forms; the 3-plane bf16x6 cross-check path keeps one
 // row per workgroup).  The accumulators bound it: 32x32 wave tiles x taps x 16 registers.
 //   5x5 128->128 : 128 x 128, one row  (8 waves, wave = 64 co x 32 ci, 10 tiles)     1 workgroup / CU
@@ -487,9 +836,28 @@ static bool tr16_spec() {
   return on;
 }
 
+static bool tr16_m32() {       // TSR_WGRAD_M32=1: the 32x32x16 kernel for the fp16x3 path too (A/B measurements)
+  static const bool on = getenv("TSR_WGRAD_M32") != nullptr;
+  return on;
+}
+
 template <int KS, int NS, bool F16>
 static int launch_tr16(const WgradTArgs& g, hipStream_t st) {
   typedef WgradTCfg<KS, NS> C;
+  if constexpr (F16 && NS == 2) {
+    if (!tr16_m32() && !tr16_spec()) {
+      if (tr16_big(g.cout, g.cin, C::CI_BIG)) {
+        typedef WgradKGeom<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG> G;
+        const int grid = g.nsplit * G::NKG * (g.cout / 128) * (g.cin / C::CI_BIG);
+        hipLaunchKernelGGL((wgrad_k32_kernel<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG>), dim3(grid), dim3(G::NT), 0, st, g);
+        return tsr_check_launch();
+      }
+      typedef WgradKGeom<KS, C::KHW_SMALL, 64, 64, 32> G;
+      const int grid = g.nsplit * G::NKG * (g.cout / 64) * (g.cin / 64);
+      hipLaunchKernelGGL((wgrad_k32_kernel<KS, C::KHW_SMALL, 64, 64, 32>), dim3(grid), dim3(G::NT), 0, st, g);
+      return tsr_check_launch();
+    }
+  }
   if constexpr (KS == 5 && F16) {
     if (tr16_spec() && (g.cout % 128) == 0 && (g.cin % 64) == 0) {      // role-specialised 128 x 64 tile (4 + 4 waves)
       typedef WgradTGeom<KS, 1, 128, 64, 64, NS, F16> G;

@@ -6,6 +6,7 @@
 set -e -o pipefail
 TAG=${1:-rXX}
 OUT=gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 run() {  # name, rocprof args..., -- bench args
@@ -21,10 +22,12 @@ run eval_stats   --kernel-trace --stats --output-format csv -d $OUT/eval_stats  
 run eval_fetch   --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/eval_fetch -- $EVAL
 run eval_write   --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/eval_write -- $EVAL
 run eval_sq      --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/eval_sq -- $EVAL
+run eval_clk     --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/eval_clk -- $EVAL
 run train_stats  --kernel-trace --stats --output-format csv -d $OUT/train_stats -- $TRAIN
 run train_fetch  --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/train_fetch -- $TRAIN
 run train_write  --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/train_write -- $TRAIN
 run train_sq     --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/train_sq -- $TRAIN
+run train_clk    --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/train_clk -- $TRAIN
 run bf16_stats   --kernel-trace --stats --output-format csv -d $OUT/bf16_stats  -- $BF16
 run tpsf_stats   --kernel-trace --stats --output-format csv -d $OUT/tpsf_stats  -- $TPSF
 run tpsf_fetch   --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/tpsf_fetch -- $TPSF

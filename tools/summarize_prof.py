@@ -7,6 +7,8 @@ tracked profiles/ directory:
   profiles/rNN_<run>_kernel_stats.csv   the `--kernel-trace --stats` summaries (eval, train, bf16, tpsf)
   profiles/rNN_pmc_summary.json         per kernel: FETCH_SIZE / WRITE_SIZE per launch and HBM bytes per launch
   profiles/rNN_sq_summary.json          per kernel: SQ counters per launch and the derived shares
+  profiles/rNN_clock_summary.json       per kernel: effective shader clock = GRBM_GUI_ACTIVE / 8 XCDs / launch duration
+                                        (MI355X_MICROARCH.md 'DVFS give-back'; launches of >= 0.3 ms only)
 
 HBM bytes per launch follow MI355X_MICROARCH.md section HBM: the counters are in KiB, and on gfx950 FETCH_SIZE reports
 exactly half of the bytes of wide (16 B/lane) coalesced reads, so traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
@@ -88,3 +90,20 @@ for mode in ("eval", "train"):
 if sq:
     json.dump(sq, open(os.path.join(dst, f"{tag}_sq_summary.json"), "w"), indent=1, sort_keys=True)
 print("wrote", sorted(f for f in os.listdir(dst) if f.startswith(tag)))
+
+clk = {}
+for mode in ("eval", "train"):
+    per = collections.defaultdict(list)
+    for f in files(f"{mode}_clk", "_counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != "GRBM_GUI_ACTIVE" or r["Kernel_Name"].startswith("void at::"):
+                continue
+            dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            if dur >= 300000:
+                per[r["Kernel_Name"]].append((float(r["Counter_Value"]) / 8 / dur, dur))
+    for k, v in per.items():
+        clk[f"{mode}: {k}"] = {"effective_clock_GHz": round(sum(x for x, _ in v) / len(v), 3),
+                               "avg_launch_ms": round(sum(d for _, d in v) / len(v) / 1e6, 3), "launches": len(v)}
+if clk:
+    json.dump(clk, open(os.path.join(dst, f"{tag}_clock_summary.json"), "w"), indent=1, sort_keys=True)
+    print("wrote", f"{tag}_clock_summary.json")
