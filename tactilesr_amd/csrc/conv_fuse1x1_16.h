@@ -10,18 +10,19 @@
 typedef _Float16 fq_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 fq_f16x4 __attribute__((ext_vector_type(4)));
 
-struct Fuse1x1Geom16 {
+template <int IMG> struct Fuse1x1Geom16 {
   static constexpr int PIXB = 64;                  // [plane 2][16 ch] fp16 per (block, pixel)
   static constexpr int ROWB = (8 * 4 + 2) * 16;    // row stride == 2 (mod 4) slots: conflict-free A fragments (k32_row_slots)
   static constexpr int IMGB = 8 * ROWB;
-  static constexpr int BLKB = 2 * IMGB;            // two images per workgroup
-  static constexpr int BYTES = 8 * BLKB;           // 128 channels = 8 blocks: 69,632 B
+  static constexpr int BLKB = IMG * IMGB;          // IMG images per workgroup (2: 256 threads, 4: 512 threads)
+  static constexpr int BYTES = 8 * BLKB;           // 128 channels = 8 blocks: 69,632 B / 139,264 B
 };
 
 // acc[mt][nt]: lane (cl = lane & 15, ph = lane >> 4) holds channel wn*64 + 16 nt + cl, pixels (2 mt + (ph >> 1), 4 (ph & 1) + r)
+template <int IMG>
 __device__ __forceinline__ void conv_fuse1x1_epilogue16(const ConvArgs& a, f32x4 (&acc)[4][4], char* lds, int b0, int y0,
                                                         int x0, int wm, int wn, int lane, int HW, float accmul) {
-  typedef Fuse1x1Geom16 E;
+  typedef Fuse1x1Geom16<IMG> E;
   const int cl = lane & 15, ph = lane >> 4;
   const int k4 = cl >> 2, j = cl & 3;
   const int dyl = ph >> 1, dxl = 4 * (ph & 1);
@@ -51,7 +52,9 @@ __device__ __forceinline__ void conv_fuse1x1_epilogue16(const ConvArgs& a, f32x4
   // (the main loop ended on a barrier: no wave still reads the halo / weight ring)
   if (lane == 0) red[wm * 2 + wn] = amax;
   __syncthreads();
-  const float tmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float tmax = 0.f;
+#pragma unroll
+  for (int w = 0; w < 2 * IMG; ++w) tmax = fmaxf(tmax, red[w]);
   float s_e = 1.f;
   if (tmax > 0.f) {
     int e = (int)((__float_as_uint(tmax) >> 23) & 0xFF) - 127;

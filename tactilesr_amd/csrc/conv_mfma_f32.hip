@@ -303,16 +303,18 @@ extern "C" int tsr_conv2d_fwd(const float* in, int in_ctot, int in_coff, int cin
   return dispatch_conv<false>(a, cout, ks, (hipStream_t)stream);
 }
 
+int tsr_conv_f16s_images(int cout, int ks);     // conv_mfma_split16.hip: images per workgroup of the fp16x3 kernel in use
+
 // Number of (workgroup, image) slab entries a tsr_conv2d_ex launch of this shape emits.
 extern "C" int tsr_conv2d_slab_entries(int B, int H, int W) {
   return ((B + 1) / 2) * ((W + 7) / 8) * ((H + 7) / 8) * 2;
 }
 
 // Slab entries a tsr_conv2d_ex launch with these parameters writes: one per (workgroup, image slot).  The fp16-split
-// 3x3 / 5x5 kernels with 64 output channels and every one-plane (plain bf16) 3x3 / 5x5 kernel put 4 images in a
+// 3x3 / 5x5 kernels (tsr_conv_f16s_images: 4 images, 2 for the 1x1 and TSR_CONV_K32_256) and every one-plane 3x3 / 5x5 kernel put 4 images in a
 // workgroup, everything else 2 (must match launch_bf16s in conv_mfma_split16.hip).
 extern "C" int tsr_conv2d_slab_entries_ex(int B, int H, int W, int cout, int ks, int nsplit) {
-  const int img = (ks > 1 && ((nsplit == -2 && cout == 64) || nsplit == 1)) ? 4 : 2;
+  const int img = nsplit == -2 ? tsr_conv_f16s_images(cout, ks) : ((ks > 1 && nsplit == 1) ? 4 : 2);
   return ((B + img - 1) / img) * ((W + 7) / 8) * ((H + 7) / 8) * img;
 }
 

@@ -41,8 +41,8 @@ constexpr int k32_row_slots(int px) {
   return rs;
 }
 
-template <int KS, int COUT, int WN, bool DBH = false> struct K32Geom {
-  static constexpr int IMG = 4 / WN;
+template <int KS, int COUT, int WN, bool DBH = false, int NTHR = 256> struct K32Geom {
+  static constexpr int IMG = (NTHR / 64) / WN;
   static constexpr int HH = 8 + KS - 1;
   static constexpr int T = KS * KS;
   static constexpr int HS = (T - 1) / 2;                       // tap pairs per block; + the cross step per block pair
@@ -64,18 +64,24 @@ template <int KS, int COUT, int WN, bool DBH = false> struct K32Geom {
 // taps 0..7.  The odd block's slab is staged under the even block's steps and the next even block's under the odd
 // block's: no block boundary is left in the loop (a 3x3 block is only 4.5 steps long; the boundary's barrier pair,
 // conversion burst and exposed first fragment read cost 15 % there).
-template <int KS, int COUT, bool EXT, int WN, bool FUSE2 = false, bool DBH = false>
-__global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
+// NTHR = 512 (C_out = 128): 8 waves = 4 images x 2 C_out halves, one workgroup per CU.  The weight slab of a step then
+// serves 256 pixels instead of 128: the weight stream (1.6 MB per workgroup at 5x5 128->128, 7 TB/s through L2 over the
+// launch, i.e. the ~13 B/clk/CU a CU can pull) and its LDS writes are what the 256-thread form spends 20 % of its time
+// on (ablation without weight staging: 11.8 -> 9.5 ms).
+template <int KS, int COUT, bool EXT, int WN, bool FUSE2 = false, bool DBH = false, int NTHR = 256>
+__global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(const ConvArgs a) {
   static_assert(COUT == 64 * WN, "every wave owns 64 channels");
   static_assert(!FUSE2 || (!EXT && COUT == 128), "fused 1x1: 128 channels, inference");
-  typedef K32Geom<KS, COUT, WN, DBH> G;
+  static_assert(NTHR == 256 || (NTHR == 512 && WN == 2), "512 threads: 4 images x 2 C_out halves");
+  typedef K32Geom<KS, COUT, WN, DBH, NTHR> G;
+  constexpr int NW = NTHR / 64;
   constexpr int IMG = G::IMG, P = KS / 2, HH = G::HH, T = G::T, HS = G::HS, NT = COUT / (16 * WN);
   constexpr int PIXB = G::PIXB, ROWB = G::ROWB, IMGB = G::IMGB, HALO_B = G::HALO_B;
   constexpr int SROWB = G::SROWB, SIMGB = G::SIMGB, SIDE_B = G::SIDE_B;
   constexpr int WTAP_B = G::WTAP_B, WSLAB_B = G::WSLAB_B;
-  constexpr int WITEMS = WSLAB_B / 16, WV = (WITEMS + 255) / 256;
-  constexpr int NITEM = IMG * HH * HH * 4, NIT = (NITEM + 255) / 256;
-  constexpr int FUSE_LDS = FUSE2 ? Fuse1x1Geom16::BYTES + 64 : 0;
+  constexpr int WITEMS = WSLAB_B / 16, WV = (WITEMS + NTHR - 1) / NTHR;
+  constexpr int NITEM = IMG * HH * HH * 4, NIT = (NITEM + NTHR - 1) / NTHR;
+  constexpr int FUSE_LDS = FUSE2 ? Fuse1x1Geom16<IMG>::BYTES + 64 : 0;
   __shared__ __attribute__((aligned(16))) char lds[G::MAIN_LDS > FUSE_LDS ? G::MAIN_LDS : FUSE_LDS];
   char* halo = lds;
   char* wbuf = lds + G::NHB * HALO_B + SIDE_B;     // 3-slot ring: slab s lives in slot s % 3
@@ -91,9 +97,9 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
   {
     float mx = a.in_amax ? *a.in_amax : 0.f;
     if (EXT && a.in_scale) {
-      __shared__ float bnd[8];
+      __shared__ float bnd[2 * NW];
       float ms = 0.f, mt = 0.f;
-      for (int c = threadIdx.x; c < a.cin; c += 256) {
+      for (int c = threadIdx.x; c < a.cin; c += NTHR) {
         ms = fmaxf(ms, fabsf(a.in_scale[c]));
         mt = fmaxf(mt, fabsf(a.in_shift[c]));
       }
@@ -104,8 +110,9 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
       }
       if (lane == 0) { bnd[wave * 2] = ms; bnd[wave * 2 + 1] = mt; }
       __syncthreads();
-      ms = fmaxf(fmaxf(bnd[0], bnd[2]), fmaxf(bnd[4], bnd[6]));
-      mt = fmaxf(fmaxf(bnd[1], bnd[3]), fmaxf(bnd[5], bnd[7]));
+      ms = 0.f; mt = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { ms = fmaxf(ms, bnd[2 * w]); mt = fmaxf(mt, bnd[2 * w + 1]); }
       mx = mx * ms + mt;
     }
     if (mx > 0.f) {
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
   int st_src[NIT], st_dst[NIT];
 #pragma unroll
   for (int k = 0; k < NIT; ++k) {
-    const int it = tid + k * 256;
+    const int it = tid + k * NTHR;
     st_src[k] = -1;
     st_dst[k] = -1;
     if (it < NITEM) {
@@ -177,12 +184,14 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nchunk = a.cin >> 4;              // even (launch check)
+  const int nreal = a.cin >> 4;
+  const int nchunk = nreal + (nreal & 1);     // blocks come in pairs
   const int S = (nchunk >> 1) * T;            // steps: HS per even block, HS + 1 per odd block
   const char* wsrc = (const char*)a.wp;
 
   auto load_halo = [&](int c, f32x4* hv) {
-    const float* inc = in_base + (size_t)c * HW * 16;
+    // (an odd block count is padded to even: the phantom block re-reads the last real one against zero weights)
+    const float* inc = in_base + (size_t)(c < nreal ? c : nreal - 1) * HW * 16;
     // branch-free: out-of-image items read a valid dummy address (offset 0) and are zeroed by their scale in store_halo
     // (hipcc otherwise wraps every load in its own exec-masked branch with a wait in front)
 #pragma unroll
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
       if (st_dst[k] >= 0) {
         f32x4 v = hv[k];
         if (EXT && a.in_scale) {   // producer's train-mode BN+ReLU, fused into the load
-          const int cq = c * 16 + ((tid + k * 256) & 3) * 4;
+          const int cq = (c < nreal ? c : nreal - 1) * 16 + ((tid + k * NTHR) & 3) * 4;
           const f32x4 sc = *(const f32x4*)(a.in_scale + cq);
           const f32x4 sh = *(const f32x4*)(a.in_shift + cq);
 #pragma unroll
@@ -216,16 +225,34 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
       }
     }
   };
+  // (TSR_ABL_K32_* : timing ablations, wrong results -- tools/build_variant.py)
+#if defined(TSR_ABL_K32_NOW)
+#define LOAD_W(sidx) {}
+#define STORE_W(slot) {}
+#elif defined(TSR_ABL_K32_NOWST)
 #define LOAD_W(sidx)                                                                     \
   {                                                                                      \
     const f32x4* src_ = (const f32x4*)(wsrc + (size_t)(sidx) * WSLAB_B);                  \
-    _Pragma("unroll") for (int v = 0; v < WV; ++v) wreg[v] = src_[tid + v * 256];        \
+    _Pragma("unroll") for (int v = 0; v < WV; ++v) wreg[v] = src_[tid + v * NTHR];        \
+  }
+#define STORE_W(slot) { _Pragma("unroll") for (int v = 0; v < WV; ++v) asm volatile("" :: "v"(wreg[v])); }
+#else
+#define LOAD_W(sidx)                                                                     \
+  {                                                                                      \
+    const f32x4* src_ = (const f32x4*)(wsrc + (size_t)(sidx) * WSLAB_B);                  \
+    _Pragma("unroll") for (int v = 0; v < WV; ++v) wreg[v] = src_[tid + v * NTHR];        \
   }
 #define STORE_W(slot)                                                                    \
   {                                                                                      \
     char* wb_ = wbuf + (slot) * WSLAB_B;                                                 \
-    _Pragma("unroll") for (int v = 0; v < WV; ++v) ((f32x4*)wb_)[tid + v * 256] = wreg[v]; \
+    _Pragma("unroll") for (int v = 0; v < WV; ++v) ((f32x4*)wb_)[tid + v * NTHR] = wreg[v]; \
   }
+#endif
+#ifdef TSR_ABL_K32_NOBAR
+#define STEP_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define STEP_BARRIER() __syncthreads()
+#endif
   // fragments of pair step st_ (taps 2 st_, 2 st_ + 1 of the resident block), plane p_
 #define LOAD_A(dst, p_, st_, hb_)                                                        \
   {                                                                                      \
@@ -241,11 +268,15 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
   {                                                                                      \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) dst[mt] = *(const kf16x8*)(lds + lcd + mt * 2 * ROWB + (p_) * 32); \
   }
+#ifdef TSR_ABL_K32_NOBRD
+#define LOAD_B(dst, p_, slot_) { if (a.B < 0) { const char* wb_ = wbuf + laneB; _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) dst[nt] = *(const kf16x8*)(wb_ + nt * 256); } }
+#else
 #define LOAD_B(dst, p_, slot_)                                                           \
   {                                                                                      \
     const char* wb_ = wbuf + (slot_) * WSLAB_B + laneB + (p_) * (2 * COUT * 16);         \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) dst[nt] = *(const kf16x8*)(wb_ + nt * 256); \
   }
+#endif
 #define MFMA_PHASE(A_, B_)                                                               \
   _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                       \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                    \
@@ -267,13 +298,15 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
   if (S > 2) LOAD_W(2);
   __syncthreads();
 
-  kf16x8 A0[4], A1[4], B0[NT], B1[NT];
+  kf16x8 A0[4], A1[4], B0[NT] = {}, B1[NT] = {};
   LOAD_A(A1, 1, 0, 0);
   LOAD_B(B0, 0, 0);
 
-  // side-buffer copy of the last tap's 8x8 window (even blocks): IMG 16-B items per thread, item k = image k
-  const int sc_src = ((tid >> 5) + KS - 1) * ROWB + (((tid >> 2) & 7) + KS - 1) * PIXB + (tid & 3) * 16;
-  const int sc_dst = HALO_B + (tid >> 5) * SROWB + ((tid >> 2) & 7) * PIXB + (tid & 3) * 16;
+  // side-buffer copy of the last tap's 8x8 window (even blocks): 256 16-B items per image, SCI images per thread
+  constexpr int SCI = IMG * 256 / NTHR, SCS = NTHR / 256;       // thread t: images (t >> 8) + SCS * k
+  const int sc_t = tid & 255, sc_i0 = tid >> 8;
+  const int sc_src = sc_i0 * IMGB + ((sc_t >> 5) + KS - 1) * ROWB + (((sc_t >> 2) & 7) + KS - 1) * PIXB + (sc_t & 3) * 16;
+  const int sc_dst = HALO_B + sc_i0 * SIMGB + (sc_t >> 5) * SROWB + ((sc_t >> 2) & 7) * PIXB + (sc_t & 3) * 16;
 
   int s = 0;
   int slot = 0;                            // s % 3, kept incrementally
@@ -285,17 +318,17 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
       const int slot1 = slot == 2 ? 0 : slot + 1;
       const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
       const bool cross = ODD && st == HS;
-      f32x4 sidev[IMG];
+      f32x4 sidev[SCI];
       // this step's second-phase operands
       if (cross) { LOAD_A_CROSS(A0, 0); } else { LOAD_A(A0, 0, st, 0); }
       LOAD_B(B1, 1, slot);
       if (!ODD && st == 0) {
 #pragma unroll
-        for (int k = 0; k < IMG; ++k) sidev[k] = *(const f32x4*)(lds + sc_src + k * IMGB);
+        for (int k = 0; k < SCI; ++k) sidev[k] = *(const f32x4*)(lds + sc_src + k * SCS * IMGB);
       }
       if (st == NST - 2 && c + 1 < nchunk) load_halo(c + 1, hv);   // next block's slab: in flight for a step and a half
       MFMA_PHASE(A1, B0);                                          // P0: h2 g1
-      if (!ODD && st == 0) { INTERLEAVE(8 + IMG, 1); } else { INTERLEAVE(8, 2); }
+      if (!ODD && st == 0) { INTERLEAVE(8 + SCI, 1); } else { INTERLEAVE(8, 2); }
       if (st + 1 < NST) {                                          // next step's A1 (same block: the slab is resident)
         if (ODD && st + 1 == HS) { LOAD_A_CROSS(A1, 1); } else { LOAD_A(A1, 1, st + 1, 0); }
       }
@@ -306,11 +339,11 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
       INTERLEAVE(4, 4);
       if (!ODD && st == 0) {
 #pragma unroll
-        for (int k = 0; k < IMG; ++k) *(f32x4*)(lds + sc_dst + k * SIMGB) = sidev[k];
+        for (int k = 0; k < SCI; ++k) *(f32x4*)(lds + sc_dst + k * SCS * SIMGB) = sidev[k];
       }
       if (s + 2 < S) STORE_W(slot2);           // slot (s+2)%3 was last read one barrier ago
       if (s + 3 < S) LOAD_W(s + 3);
-      __syncthreads();
+      STEP_BARRIER();
       if (st + 1 == NST && c + 1 < nchunk) {
         store_halo(hv, c + 1);     // every wave is past its last read of the old slab (barrier above)
         __syncthreads();
@@ -352,13 +385,14 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
         if (p == T - 2 && c + 2 < nchunk) store_halo(hv, c + 2, 0);  // slab 0: last read by the cross step
         if (s + 2 < S) STORE_W(slot2);
         if (s + 3 < S) LOAD_W(s + 3);
-        __syncthreads();
+        STEP_BARRIER();
         ++s;
         slot = slot1;
       }
     }
   }
 #undef LOAD_W
+#undef STEP_BARRIER
 #undef STORE_W
 #undef LOAD_A
 #undef LOAD_A_CROSS
@@ -367,16 +401,31 @@ __global__ __launch_bounds__(256, 2) void conv_k32_kernel(const ConvArgs a) {
 #undef MFMA_PHASE
 #undef INTERLEAVE
 
-  if constexpr (FUSE2) conv_fuse1x1_epilogue16(a, acc, lds, b0, y0, x0, wm, wn, lane, HW, accmul);
+  if constexpr (FUSE2) conv_fuse1x1_epilogue16<IMG>(a, acc, lds, b0, y0, x0, wm, wn, lane, HW, accmul);
   else conv_epilogue16<COUT, EXT, WN>(a, acc, ebase, b0, y0, x0, wm, wn, lane, HW, accmul);
 }
 
 // ---- launchers (called from conv_mfma_split16.hip's dispatchers; argument checks were done there) -------------------
+// C_out = 128: 512-thread workgroups (4 images); TSR_CONV_K32_256=1 keeps the 256-thread form (2 images) -- NB the
+// statistics-slab numbering of the train epilogues follows the image count (tsr_conv2d_slab_entries_ex asks k32_images)
+static bool k32_256() {
+  static const bool on = getenv("TSR_CONV_K32_256") != nullptr;
+  return on;
+}
+int tsr_conv_k32_images(int cout) { return cout == 128 && k32_256() ? 2 : 4; }
+
 template <int KS, int COUT, bool EXT>
 static int launch_k32(const ConvArgs& a, hipStream_t st) {
   // (C_out = 64 as 2 images x 2 halves of 32 channels, 3 workgroups per CU, measured no better than the 4-image form:
   // 5x5 3.41 vs 3.39 ms, 3x3 1.60 vs 1.68 ms at B = 4096; the 32x32x16 kernel does 3.23 / 1.61 ms)
   constexpr int WN = COUT / 64;
+  if constexpr (COUT == 128) {
+    if (!k32_256()) {
+      const int grid = ((a.B + 3) / 4) * a.tiles_x * a.tiles_y;
+      hipLaunchKernelGGL((conv_k32_kernel<KS, COUT, EXT, WN, false, KS == 3, 512>), dim3(grid), dim3(512), 0, st, a);
+      return tsr_check_launch();
+    }
+  }
   constexpr int IMG = 4 / WN;
   const int grid = ((a.B + IMG - 1) / IMG) * a.tiles_x * a.tiles_y;
   hipLaunchKernelGGL((conv_k32_kernel<KS, COUT, EXT, WN, false, KS == 3>), dim3(grid), dim3(256), 0, st, a);
@@ -399,6 +448,12 @@ int tsr_conv_k32(const ConvArgs& a, int cout, int ks, bool ext, hipStream_t st) 
 }
 
 int tsr_conv_k32_fuse1x1(const ConvArgs& a, int ks, hipStream_t st) {
+  if (!k32_256()) {
+    const int grid = ((a.B + 3) / 4) * a.tiles_x * a.tiles_y;
+    if (ks == 5) hipLaunchKernelGGL((conv_k32_kernel<5, 128, false, 2, true, false, 512>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv_k32_kernel<3, 128, false, 2, true, true, 512>), dim3(grid), dim3(512), 0, st, a);
+    return tsr_check_launch();
+  }
   const int grid = ((a.B + 1) / 2) * a.tiles_x * a.tiles_y;
   if (ks == 5) hipLaunchKernelGGL((conv_k32_kernel<5, 128, false, 2, true>), dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv_k32_kernel<3, 128, false, 2, true, true>), dim3(grid), dim3(256), 0, st, a);

@@ -422,7 +422,8 @@ __global__ void pack_conv_weight_bf16s_kernel(const float* __restrict__ w, typen
   const int T = ks * ks;
   const int nstep = (T + tps - 1) / tps;
   const int TP = nstep * tps;                          // padded tap count
-  const size_t total = (size_t)cout * cin * TP;        // one thread per (padded) fp32 weight -> ns outputs
+  const int cin_p = k32 ? ((cin + 31) & ~31) : cin;    // k32: channel blocks in pairs (the phantom block is all zero)
+  const size_t total = (size_t)cout * cin_p * TP;      // one thread per (padded) fp32 weight -> ns outputs
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int j = i & 7;
     size_t r = i >> 3;
@@ -432,8 +433,8 @@ __global__ void pack_conv_weight_bf16s_kernel(const float* __restrict__ w, typen
     const int chunk = r / TP;
     const int ci = chunk * 16 + kh * 8 + j;
     float v = 0.f;
-    if (tap < T) v = ci0 < 0 ? w[((size_t)n * cin + ci) * T + tap]
-                             : w[((size_t)ci * cin_f + ci0 + n) * T + (T - 1 - tap)];
+    if (tap < T && ci < cin) v = ci0 < 0 ? w[((size_t)n * cin + ci) * T + tap]
+                                         : w[((size_t)ci * cin_f + ci0 + n) * T + (T - 1 - tap)];
     v *= wscale;
     // position of this (block, tap) slab in the stream.  k32 = 1 (conv_mfma_k32.hip; tps = 1, blocks in pairs): the even
     // block's taps 0..T-2, the odd block's taps 0..T-2, then the cross pair (last tap of the even, of the odd block)
@@ -462,7 +463,14 @@ int tsr_conv_k32_fuse1x1(const ConvArgs& a, int ks, hipStream_t st);
 static bool use_k32(int ks, int kdim, int cout) {
   static const bool off = getenv("TSR_CONV_M32") != nullptr;
   static const bool all = getenv("TSR_CONV_K32_ALL") != nullptr;
-  return !off && ks > 1 && ((kdim >> 4) & 1) == 0 && (cout == 128 || all);
+  (void)kdim;          // an odd channel-block count is padded with a zero-weight block (pack) / a re-read block (kernel)
+  return !off && ks > 1 && (cout == 128 || all);
+}
+// images per workgroup (= statistics-slab entries per workgroup) of the fp16x3 kernel that runs (cout, ks)
+int tsr_conv_k32_images(int cout);            // conv_mfma_k32.hip
+int tsr_conv_f16s_images(int cout, int ks) {
+  if (use_k32(ks, 0, cout)) return tsr_conv_k32_images(cout);
+  return (ks > 1 && cout == 64) ? 4 : 2;
 }
 static int k32_mode(int ks, int kdim, int cout) { return use_k32(ks, kdim, cout) ? (ks == 3 ? 2 : 1) : 0; }
 
@@ -470,7 +478,9 @@ static int k32_mode(int ks, int kdim, int cout) { return use_k32(ks, kdim, cout)
 extern "C" long long tsr_conv_weight_bf16s_elems(int cout, int cin, int ks, int nsplit) {
   const int tps = taps_per_step(ks, cout, nsplit);
   const int T = ks * ks;
-  return (long long)nsplit * cout * cin * (((T + tps - 1) / tps) * tps);
+  const long long a = (long long)nsplit * cout * cin * (((T + tps - 1) / tps) * tps);
+  const long long b = (long long)nsplit * cout * ((cin + 31) & ~31) * T;      // K = 32 kernel: channel blocks in pairs
+  return a > b ? a : b;
 }
 
 extern "C" int tsr_pack_conv_weight_bf16s(const float* w_oihw, void* w_packed, int cout, int cin, int ks,

@@ -285,7 +285,13 @@ def test_full_size_batch4096_tiling_invariance(T, impl):
     assert relerr(y[0], ref) < TOL
 
 
-@pytest.mark.parametrize("ks,cin,cout,B,H,W", BF16S_CASES)
+# + shapes aimed at the K = 32 kernel (C_out = 128, channel blocks in pairs): one block pair, odd batches, partial tiles,
+# the sf = 25 image size; and an odd block count (falls back to the 32x32x16 kernel and its pack order)
+K32_CASES = [(5, 32, 128, 3, 100, 100), (3, 32, 128, 3, 9, 17), (5, 64, 128, 2, 40, 40), (3, 64, 128, 5, 24, 8),
+             (5, 256, 128, 1, 16, 16), (3, 48, 128, 2, 16, 16), (5, 48, 128, 1, 8, 24)]
+
+
+@pytest.mark.parametrize("ks,cin,cout,B,H,W", BF16S_CASES + K32_CASES)
 @pytest.mark.parametrize("outlier", [False, True])
 def test_conv2d_fwd_fp16_split(T, ks, cin, cout, B, H, W, outlier):
     """fp16 two-plane split conv (3 products) with power-of-two operand scaling: fp32-grade single-layer accuracy,
