@@ -222,7 +222,7 @@ def main():
         executed = alg * nprod if ev else None                               # MFMA FLOP/s actually executed
         k32 = args.impl == "fp16x3" and not os.environ.get("TSR_CONV_M32")      # conv_mfma_k32.hip (16x16x32 MFMA)
         kname = ("conv_mfma_f32_kernel<5, 128" if args.impl == "f32" else
-                 ("conv_k32_kernel<5, 128, false, 2, %s" % ("true" if fused else "false")) if k32 else
+                 ("conv_k32_kernel<5, 128, false, 2, %s" % ("true, false, 256" if fused else "false, false, 512")) if k32 else
                  "conv_mfma_split16_kernel<5, 128, %d, false, %s" % ({"fp16x3": 2, "bf16x6": 3, "bf16x3": 2, "bf16": 1}[args.impl],
                                                                      "true" if args.impl == "fp16x3" else "false"))
         per_kernel = {f"conv{k[0]}x{k[0]}_c{k[1]}": round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 3)
