@@ -225,8 +225,9 @@ def main():
                  ("conv_k32_kernel<5, 128, false, 2, %s" % ("true, false, 256" if fused else "false, false, 512")) if k32 else
                  "conv_mfma_split16_kernel<5, 128, %d, false, %s" % ({"fp16x3": 2, "bf16x6": 3, "bf16x3": 2, "bf16": 1}[args.impl],
                                                                      "true" if args.impl == "fp16x3" else "false"))
-        per_kernel = {f"conv{k[0]}x{k[0]}_c{k[1]}": round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 3)
-                      for k, v in sorted(prof.items())}
+        per_kernel = {(f"conv{k[0]}x{k[0]}_c{k[1]}" if k[0] != "pair" else "conv3x3_5x5_pair_c128"):
+                      round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 3)
+                      for k, v in sorted(prof.items(), key=lambda kv: str(kv[0]))}
         traffic, traffic_src = pmc_traffic(kname) if B == 4096 else (None, None)
         dtype = {"fp16x3": "f32 as 2 power-of-two-scaled fp16 planes x 3 MFMA products, fp32 accumulate (fp32-grade)",
                  "bf16x6": "f32 as 3 bf16 planes x 6 MFMA products, fp32 accumulate (fp32-equivalent)",

@@ -70,6 +70,19 @@ int tsr_conv2d_fwd_bf16s(const float* in, int in_ctot, int in_coff, int cin,
                          float* out, int out_ctot, int out_coff, int relu,
                          int B, int H, int W, void* stream);
 
+/* The two stage-1 convolutions of an MSRB (3x3 64->64 and 5x5 64->64 on the same input,
+ * model/tactileSR_model.py:167-175,198-200) as ONE launch on one staged halo (inference, fp16x3 arithmetic): a 5x5 conv
+ * to 128 channels whose 3x3 half skips the 16 outer taps.  Output channels, scale and shift are in the kernel's channel
+ * order: tsr_pair_channel_perm fills perm[k] = channel of torch.cat([conv3, conv5], 1) that kernel channel k holds; the
+ * consumers' weights are permuted along C_in accordingly.  w_packed: tsr_conv_weight_pair_elems(cin) fp16 elements. */
+int tsr_pair_channel_perm(int* perm128);      /* host array of 128 ints */
+long long tsr_conv_weight_pair_elems(int cin);
+int tsr_pack_conv_weight_pair_f16s(const float* w3_oihw, const float* w5_oihw, void* w_packed, int cin, float wscale,
+                                   const float* w_amax, void* stream);
+int tsr_conv2d_fwd_f16s_pair(const float* in, int in_ctot, int in_coff, int cin, const void* w_packed, float w_inv_scale,
+                             const float* in_amax, float* out_amax, const float* scale, const float* shift,
+                             float* out, int out_ctot, int out_coff, int relu, int B, int H, int W, void* stream);
+
 /* fp16 two-plane variant ("fp16x3"): operands are scaled by powers of two into fp16's range -- weights at pack
  * time (wscale chosen by the caller: max|w|*wscale in [2^13,2^14); pass w_inv_scale = 1/wscale), activations in
  * the kernel from the device scalar in_amax = max|x| that the producer wrote through its out_amax -- then split

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TSR_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libtactilesr_hip.so")   # override: kernel A/B experiments
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _P, _I, _F, _L = c_void_p, c_int, c_float, c_longlong
 
@@ -32,6 +32,10 @@ SIGNATURES = {
     "tsr_conv2d_fwd_f16s": [_P, _I, _I, _I, _P, _I, _I, _F, _P, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "tsr_conv2d_fwd_f16s_fuse1x1": [_P, _I, _I, _I, _P, _I, _F, _P, _P, _P, _P, _I, _P, _F, _P, _P, _I, _I, _P, _I, _I,
                                     _I, _I, _I, _I, _P],
+    "tsr_pair_channel_perm": [_P],
+    "tsr_conv_weight_pair_elems": [_I],
+    "tsr_pack_conv_weight_pair_f16s": [_P, _P, _P, _I, _F, _P, _P],
+    "tsr_conv2d_fwd_f16s_pair": [_P, _I, _I, _I, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "tsr_head_fwd": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _P],
     "tsr_conv2d_fwd_b16": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "tsr_conv2d_fwd_b16_fuse1x1": [_P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],

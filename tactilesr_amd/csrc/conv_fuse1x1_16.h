@@ -28,6 +28,19 @@ __device__ __forceinline__ void conv_fuse1x1_epilogue16(const ConvArgs& a, f32x4
   const int dyl = ph >> 1, dxl = 4 * (ph & 1);
   const int b = b0 + wm;
   const bool img_ok = b < a.B;
+  // W2 fragments of the second GEMM (16 x 16 B per lane, from L2): requested first, so that their latency runs under the
+  // BN / park phase instead of behind its barriers
+  const int khalf = ph & 1, bsel = ph >> 1;
+  // 1x1 pack of tsr_pack_conv_weight_f16s: [chunk][plane][k half][64][8]
+  const _Float16* wb = (const _Float16*)a.w2 + ((size_t)(bsel * 2 * 2 + khalf) * 64 + wn * 32 + cl) * 8;
+  fq_f16x8 fb[4][2][2];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int n2 = 0; n2 < 2; ++n2)
+        fb[kk][p][n2] = *(const fq_f16x8*)(wb + (size_t)((2 * kk) * 2 + p) * (2 * 64 * 8) + n2 * 16 * 8);
   // ---- 1. BatchNorm fold + ReLU in place (lane = channel), zero outside the image, tile maximum
   float amax = 0.f;
 #pragma unroll
@@ -90,37 +103,31 @@ __device__ __forceinline__ void conv_fuse1x1_epilogue16(const ConvArgs& a, f32x4
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
     for (int n2 = 0; n2 < 2; ++n2) acc2[mt][n2] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int khalf = ph & 1, bsel = ph >> 1;
   const char* ea = lds + bsel * E::BLKB + wm * E::IMGB + (cl >> 3) * E::ROWB + (cl & 7) * E::PIXB + khalf * 16;
-  // 1x1 pack of tsr_pack_conv_weight_f16s: [chunk][plane][k half][64][8]
-  const _Float16* wb = (const _Float16*)a.w2 + ((size_t)(bsel * 2 * 2 + khalf) * 64 + wn * 32 + cl) * 8;
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    fq_f16x8 fa[2][4], fb[2][2];
+    fq_f16x8 fa[2][4];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) fa[p][mt] = *(const fq_f16x8*)(ea + (2 * kk) * E::BLKB + (2 * mt) * E::ROWB + p * 32);
-#pragma unroll
-      for (int n2 = 0; n2 < 2; ++n2)
-        fb[p][n2] = *(const fq_f16x8*)(wb + (size_t)((2 * kk) * 2 + p) * (2 * 64 * 8) + n2 * 16 * 8);
     }
     // small terms first: h2.g1, h1.g2, h1.g1
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int n2 = 0; n2 < 2; ++n2)
-        acc2[mt][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1][mt], fb[0][n2], acc2[mt][n2], 0, 0, 0);
+        acc2[mt][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1][mt], fb[kk][0][n2], acc2[mt][n2], 0, 0, 0);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int n2 = 0; n2 < 2; ++n2)
-        acc2[mt][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][mt], fb[1][n2], acc2[mt][n2], 0, 0, 0);
+        acc2[mt][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][mt], fb[kk][1][n2], acc2[mt][n2], 0, 0, 0);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int n2 = 0; n2 < 2; ++n2)
-        acc2[mt][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][mt], fb[0][n2], acc2[mt][n2], 0, 0, 0);
+        acc2[mt][n2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0][mt], fb[kk][0][n2], acc2[mt][n2], 0, 0, 0);
   }
   // ---- 4. + bias + residual, ReLU, max|out|, 16-B stores
   const float mul2 = a.w2_inv_scale / s_e;

@@ -68,8 +68,20 @@ template <int KS, int COUT, int WN, bool DBH = false, int NTHR = 256> struct K32
 // serves 256 pixels instead of 128: the weight stream (1.6 MB per workgroup at 5x5 128->128, 7 TB/s through L2 over the
 // launch, i.e. the ~13 B/clk/CU a CU can pull) and its LDS writes are what the 256-thread form spends 20 % of its time
 // on (ablation without weight staging: 11.8 -> 9.5 ms).
-template <int KS, int COUT, bool EXT, int WN, bool FUSE2 = false, bool DBH = false, int NTHR = 256>
+// PAIR (5x5 geometry, 128 output channels, inference): the two stage-1 convolutions of an MSRB -- 3x3 64->64 and
+// 5x5 64->64 on the SAME input (model/tactileSR_model.py:167-175,198-200) -- as one launch on one staged halo.  The
+// launch is a 5x5 conv to 128 channels whose 3x3 half has zero weights on the 16 outer taps; those MFMAs are not issued:
+// every wave owns two n-tiles of each conv (host-side channel permutation, tsr_pair_channel_perm), tap pairs are ordered
+// outer ring first (8 steps of half work), then the inner 3x3 (4 steps) with its centre-right tap (3,3) as the cross
+// tap, and all pairs are horizontal or vertical neighbours (lane deltas: one pixel / one row).
+constexpr int PAIR_KH[12] = {0, 0, 0, 2, 1, 3, 4, 4, 1, 1, 2, 3};
+constexpr int PAIR_KW[12] = {0, 2, 4, 4, 0, 0, 1, 3, 1, 3, 1, 1};
+constexpr int PAIR_V[12] = {0, 0, 1, 1, 1, 1, 0, 0, 0, 1, 0, 0};      // second tap: 0 = next column, 1 = next row
+constexpr int PAIR_OUTER = 8;                                        // steps 0..7 touch only the 5x5 conv's channels
+
+template <int KS, int COUT, bool EXT, int WN, bool FUSE2 = false, bool DBH = false, int NTHR = 256, bool PAIR = false>
 __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(const ConvArgs a) {
+  static_assert(!PAIR || (KS == 5 && COUT == 128 && !EXT && !FUSE2 && !DBH), "pair form: 5x5 geometry, inference");
   static_assert(COUT == 64 * WN, "every wave owns 64 channels");
   static_assert(!FUSE2 || (!EXT && COUT == 128), "fused 1x1: 128 channels, inference");
   static_assert(NTHR == 256 || (NTHR == 512 && WN == 2), "512 threads: 4 images x 2 C_out halves");
@@ -171,12 +183,15 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
   // wraps to the next row, lc / lcs = cross step (first tap from the side buffer, second from the halo)
   const int laneA0 = wm * IMGB + (m >> 3) * ROWB + (m & 7) * PIXB + khalf * 16;
   const int lx = laneA0 + tsel * PIXB;
-  const int lw = laneA0 + tsel * (ROWB - (KS - 1) * PIXB);
-  const int lc = tsel ? laneA0 + (KS - 1) * ROWB + (KS - 1) * PIXB
+  constexpr int CK = PAIR ? 3 : KS - 1;                 // cross tap (CK, CK): the last tap, or the pair form's (3,3)
+  const int lw = PAIR ? laneA0 + tsel * ROWB            // pair form: vertical neighbour
+                      : laneA0 + tsel * (ROWB - (KS - 1) * PIXB);
+  const int lc = tsel ? laneA0 + CK * ROWB + CK * PIXB
                       : HALO_B + wm * SIMGB + (m >> 3) * SROWB + (m & 7) * PIXB + khalf * 16;
   const int lcs = tsel ? 2 * ROWB : 2 * SROWB;
   const int lcd = laneA0 + (KS - 1) * (ROWB + PIXB) + tsel * HALO_B;      // DBH cross step: last tap of slab 0 | of slab 1
   const int laneB = tsel * WTAP_B + (khalf * COUT + wn * (COUT / WN) + m) * 16;
+  const int laneBh = tsel * (WTAP_B / 2) + (khalf * 64 + wn * 32 + m) * 16;      // pair form, half slabs: [plane][k half][64][8]
 
   f32x4 acc[4][NT];
 #pragma unroll
@@ -248,6 +263,29 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
     _Pragma("unroll") for (int v = 0; v < WV; ++v) ((f32x4*)wb_)[tid + v * NTHR] = wreg[v]; \
   }
 #endif
+  // pair form: the slabs of the outer-ring steps hold the 5x5 conv's 64 channels only (half size); the stream is walked
+  // with a running offset.  pq_ = index of the step within its block pair (0..24), compile time.
+#define PAIR_HALF(pq_) ((pq_) < 24 && ((pq_) % 12) < PAIR_OUTER)
+#define LOAD_WP(pq_)                                                                     \
+  {                                                                                      \
+    const f32x4* src_ = (const f32x4*)(wsrc + woff3);                                    \
+    if (PAIR_HALF(pq_)) {                                                                \
+      _Pragma("unroll") for (int v = 0; v < WV / 2; ++v) wreg[v] = src_[tid + v * NTHR]; \
+      woff3 += WSLAB_B / 2;                                                              \
+    } else {                                                                             \
+      _Pragma("unroll") for (int v = 0; v < WV; ++v) wreg[v] = src_[tid + v * NTHR];     \
+      woff3 += WSLAB_B;                                                                  \
+    }                                                                                    \
+  }
+#define STORE_WP(slot, pq_)                                                              \
+  {                                                                                      \
+    char* wb_ = wbuf + (slot) * WSLAB_B;                                                 \
+    if (PAIR_HALF(pq_)) {                                                                \
+      _Pragma("unroll") for (int v = 0; v < WV / 2; ++v) ((f32x4*)wb_)[tid + v * NTHR] = wreg[v]; \
+    } else {                                                                             \
+      _Pragma("unroll") for (int v = 0; v < WV; ++v) ((f32x4*)wb_)[tid + v * NTHR] = wreg[v]; \
+    }                                                                                    \
+  }
 #ifdef TSR_ABL_K32_NOBAR
 #define STEP_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -256,8 +294,9 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
   // fragments of pair step st_ (taps 2 st_, 2 st_ + 1 of the resident block), plane p_
 #define LOAD_A(dst, p_, st_, hb_)                                                        \
   {                                                                                      \
-    const int kh_ = (2 * (st_)) / KS, kw_ = (2 * (st_)) - kh_ * KS;                      \
-    const char* ab_ = lds + (kw_ < KS - 1 ? lx : lw) + (hb_) * HALO_B + kh_ * ROWB + kw_ * PIXB + (p_) * 32; \
+    const int kh_ = PAIR ? PAIR_KH[(st_)] : (2 * (st_)) / KS, kw_ = PAIR ? PAIR_KW[(st_)] : (2 * (st_)) - kh_ * KS; \
+    const bool x_ = PAIR ? PAIR_V[(st_)] == 0 : kw_ < KS - 1;                            \
+    const char* ab_ = lds + (x_ ? lx : lw) + (hb_) * HALO_B + kh_ * ROWB + kw_ * PIXB + (p_) * 32; \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) dst[mt] = *(const kf16x8*)(ab_ + mt * 2 * ROWB); \
   }
 #define LOAD_A_CROSS(dst, p_)                                                            \
@@ -277,6 +316,16 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) dst[nt] = *(const kf16x8*)(wb_ + nt * 256); \
   }
 #endif
+  // pair form, outer-ring steps: only n-tiles 2, 3 (the 5x5 conv's channels of this wave)
+#define LOAD_B_HI(dst, p_, slot_)                                                        \
+  {                                                                                      \
+    const char* wb_ = wbuf + (slot_) * WSLAB_B + laneBh + (p_) * (2 * 64 * 16);          \
+    _Pragma("unroll") for (int nt = 2; nt < NT; ++nt) dst[nt] = *(const kf16x8*)(wb_ + (nt - 2) * 256); \
+  }
+#define MFMA_PHASE_HI(A_, B_)                                                            \
+  _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                       \
+    _Pragma("unroll") for (int nt = 2; nt < NT; ++nt)                                    \
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_[mt], B_[nt], acc[mt][nt], 0, 0, 0);
 #define MFMA_PHASE(A_, B_)                                                               \
   _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                       \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                    \
@@ -290,22 +339,30 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
 
   // ---- prologue: halo(0), W(0), W(1) in LDS; W(2) in flight
   f32x4 hv[NIT], wreg[WV];
+  size_t woff3 = 0;                       // pair form: byte offset of the next slab to load
   load_halo(0, hv);
-  LOAD_W(0);
-  STORE_W(0);
-  if (S > 1) { LOAD_W(1); STORE_W(1); }
-  store_halo(hv, 0);
-  if (S > 2) LOAD_W(2);
+  if constexpr (PAIR) {                   // S >= 25; steps 0, 1, 2 are outer-ring steps
+    LOAD_WP(0); STORE_WP(0, 0);
+    LOAD_WP(1); STORE_WP(1, 1);
+    store_halo(hv, 0);
+    LOAD_WP(2);
+  } else {
+    LOAD_W(0);
+    STORE_W(0);
+    if (S > 1) { LOAD_W(1); STORE_W(1); }
+    store_halo(hv, 0);
+    if (S > 2) LOAD_W(2);
+  }
   __syncthreads();
 
   kf16x8 A0[4], A1[4], B0[NT] = {}, B1[NT] = {};
   LOAD_A(A1, 1, 0, 0);
-  LOAD_B(B0, 0, 0);
+  if constexpr (PAIR) { LOAD_B_HI(B0, 0, 0); } else { LOAD_B(B0, 0, 0); }
 
   // side-buffer copy of the last tap's 8x8 window (even blocks): 256 16-B items per image, SCI images per thread
   constexpr int SCI = IMG * 256 / NTHR, SCS = NTHR / 256;       // thread t: images (t >> 8) + SCS * k
   const int sc_t = tid & 255, sc_i0 = tid >> 8;
-  const int sc_src = sc_i0 * IMGB + ((sc_t >> 5) + KS - 1) * ROWB + (((sc_t >> 2) & 7) + KS - 1) * PIXB + (sc_t & 3) * 16;
+  const int sc_src = sc_i0 * IMGB + ((sc_t >> 5) + CK) * ROWB + (((sc_t >> 2) & 7) + CK) * PIXB + (sc_t & 3) * 16;
   const int sc_dst = HALO_B + sc_i0 * SIMGB + (sc_t >> 5) * SROWB + ((sc_t >> 2) & 7) * PIXB + (sc_t & 3) * 16;
 
   int s = 0;
@@ -319,30 +376,54 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
       const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
       const bool cross = ODD && st == HS;
       f32x4 sidev[SCI];
+      const bool outer = PAIR && st < PAIR_OUTER;                  // half-work step: the 5x5 conv's n-tiles only
+      const bool next_outer = PAIR && (st + 1 < PAIR_OUTER || st + 1 == NST);   // (a block starts on the outer ring)
       // this step's second-phase operands
       if (cross) { LOAD_A_CROSS(A0, 0); } else { LOAD_A(A0, 0, st, 0); }
-      LOAD_B(B1, 1, slot);
+      if (outer) { LOAD_B_HI(B1, 1, slot); } else { LOAD_B(B1, 1, slot); }
       if (!ODD && st == 0) {
 #pragma unroll
         for (int k = 0; k < SCI; ++k) sidev[k] = *(const f32x4*)(lds + sc_src + k * SCS * IMGB);
       }
       if (st == NST - 2 && c + 1 < nchunk) load_halo(c + 1, hv);   // next block's slab: in flight for a step and a half
-      MFMA_PHASE(A1, B0);                                          // P0: h2 g1
-      if (!ODD && st == 0) { INTERLEAVE(8 + SCI, 1); } else { INTERLEAVE(8, 2); }
+      if (outer) {
+        MFMA_PHASE_HI(A1, B0);
+        if (!ODD && st == 0) { INTERLEAVE(6 + SCI, 1); } else { INTERLEAVE(6, 1); }
+      } else {
+        MFMA_PHASE(A1, B0);                                        // P0: h2 g1
+        if (!ODD && st == 0) { INTERLEAVE(8 + SCI, 1); } else { INTERLEAVE(8, 2); }
+      }
       if (st + 1 < NST) {                                          // next step's A1 (same block: the slab is resident)
         if (ODD && st + 1 == HS) { LOAD_A_CROSS(A1, 1); } else { LOAD_A(A1, 1, st + 1, 0); }
       }
-      MFMA_PHASE(A0, B0);                                          // P1: h1 g1
-      if (st + 1 < NST) { INTERLEAVE(4, 4); }
-      LOAD_B(B0, 0, slot1);        // next step's B0: published one barrier ago (after the last step: stale, unused)
-      MFMA_PHASE(A0, B1);                                          // P2: h1 g2
-      INTERLEAVE(4, 4);
+      if (outer) {
+        MFMA_PHASE_HI(A0, B0);                                     // P1: h1 g1
+        if (st + 1 < NST) { INTERLEAVE(4, 2); }
+      } else {
+        MFMA_PHASE(A0, B0);
+        if (st + 1 < NST) { INTERLEAVE(4, 4); }
+      }
+      // next step's B0: published one barrier ago (after the last step: stale, unused)
+      if (next_outer) { LOAD_B_HI(B0, 0, slot1); } else { LOAD_B(B0, 0, slot1); }
+      if (outer) {
+        MFMA_PHASE_HI(A0, B1);                                     // P2: h1 g2
+        if (next_outer) { INTERLEAVE(2, 4); } else { INTERLEAVE(4, 2); }
+      } else {
+        MFMA_PHASE(A0, B1);
+        if (next_outer) { INTERLEAVE(2, 8); } else { INTERLEAVE(4, 4); }
+      }
       if (!ODD && st == 0) {
 #pragma unroll
         for (int k = 0; k < SCI; ++k) *(f32x4*)(lds + sc_dst + k * SCS * SIMGB) = sidev[k];
       }
-      if (s + 2 < S) STORE_W(slot2);           // slot (s+2)%3 was last read one barrier ago
-      if (s + 3 < S) LOAD_W(s + 3);
+      if constexpr (PAIR) {
+        const int pq = ODD * HS + st;           // step index within the block pair (the cross step: 24)
+        if (s + 2 < S) STORE_WP(slot2, (pq + 2) % 25);
+        if (s + 3 < S) LOAD_WP((pq + 3) % 25);
+      } else {
+        if (s + 2 < S) STORE_W(slot2);           // slot (s+2)%3 was last read one barrier ago
+        if (s + 3 < S) LOAD_W(s + 3);
+      }
       STEP_BARRIER();
       if (st + 1 == NST && c + 1 < nchunk) {
         store_halo(hv, c + 1);     // every wave is past its last read of the old slab (barrier above)
@@ -392,12 +473,17 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
     }
   }
 #undef LOAD_W
+#undef LOAD_WP
+#undef STORE_WP
+#undef PAIR_HALF
 #undef STEP_BARRIER
 #undef STORE_W
 #undef LOAD_A
 #undef LOAD_A_CROSS
 #undef LOAD_A_CROSSD
 #undef LOAD_B
+#undef LOAD_B_HI
+#undef MFMA_PHASE_HI
 #undef MFMA_PHASE
 #undef INTERLEAVE
 
@@ -445,6 +531,119 @@ int tsr_conv_k32(const ConvArgs& a, int cout, int ks, bool ext, hipStream_t st) 
     if (cout == 128 && ks == 5) return launch_k32<5, 128, false>(a, st);
   }
   return TSR_ERR_ARG;
+}
+
+// ---- stage-1 pair: channel order and weight pack ---------------------------------------------------------------------
+// Kernel channel k = wn*64 + nt*16 + c (wave half wn, n-tile nt): n-tiles 0,1 carry the 3x3 conv's channels
+// wn*32 + nt*16 + c, n-tiles 2,3 the 5x5 conv's channels wn*32 + (nt-2)*16 + c.  perm[k] = the channel of
+// torch.cat([conv3, conv5], 1) (model/tactileSR_model.py:200) that kernel channel k holds.
+__host__ __device__ inline int pair_logical_channel(int k) {
+  const int wn = k >> 6, nt = (k >> 4) & 3, c = k & 15;
+  return (nt < 2 ? 0 : 64) + wn * 32 + (nt & 1) * 16 + c;
+}
+extern "C" int tsr_pair_channel_perm(int* perm128) {      // host array
+  if (!perm128) return TSR_ERR_ARG;
+  for (int k = 0; k < 128; ++k) perm128[k] = pair_logical_channel(k);
+  return TSR_OK;
+}
+
+// w3: [64][cin][3][3], w5: [64][cin][5][5] fp32 -> the K = 32 kernel's stream for the pair form: per pair of channel
+// blocks 12 tap pairs of the even block, 12 of the odd block (PAIR_KH / PAIR_KW / PAIR_V order), the cross pair (3,3);
+// each tap slab [plane 2][k half 2][128 kernel channels][8] fp16, scaled by wscale (or by the power of two derived from
+// *w_amax); the 3x3 conv's outer-ring entries are zero.
+__global__ void pack_pair_kernel(const float* __restrict__ w3, const float* __restrict__ w5, _Float16* __restrict__ wp,
+                                 int cin, float wscale, const float* __restrict__ w_amax) {
+  if (w_amax) {
+    const float wm = *w_amax;
+    wscale = 1.f;
+    if (wm > 0.f && wm < 3.0e38f) {
+      int be = 127 + 13 - ((int)((__float_as_uint(wm) >> 23) & 0xFF) - 127);
+      be = be < 1 ? 1 : (be > 254 ? 254 : be);
+      wscale = __uint_as_float((unsigned)be << 23);
+    }
+  }
+  const int cin_p = (cin + 31) & ~31;
+  const size_t total = (size_t)128 * cin_p * 25;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i & 7;
+    size_t r = i >> 3;
+    const int k = r & 127; r >>= 7;
+    const int kh2 = r & 1; r >>= 1;
+    const int tap = r % 25;
+    const int chunk = r / 25;
+    const int ci = chunk * 16 + kh2 * 8 + j;
+    const int kh = tap / 5, kw = tap - kh * 5;
+    const int nt = (k >> 4) & 3, ch = (k >> 6) * 32 + (nt & 1) * 16 + (k & 15);
+    float v = 0.f;
+    if (ci < cin) {
+      if (nt >= 2) v = w5[((size_t)ch * cin + ci) * 25 + tap];
+      else if (kh >= 1 && kh <= 3 && kw >= 1 && kw <= 3) v = w3[((size_t)ch * cin + ci) * 9 + (kh - 1) * 3 + (kw - 1)];
+    }
+    v *= wscale;
+    // position of the tap in the block's step order
+    int pos = 24;                                   // (3,3): the cross tap
+#pragma unroll
+    for (int st = 0; st < 12; ++st) {
+      if (kh == PAIR_KH[st] && kw == PAIR_KW[st]) pos = 2 * st;
+      if (kh == PAIR_KH[st] + PAIR_V[st] && kw == PAIR_KW[st] + 1 - PAIR_V[st]) pos = 2 * st + 1;
+    }
+    // element offset of the tap slab: per block pair [even block | odd block | cross step]; a block = 8 outer-ring steps
+    // of 2 x 2048 elements (the 5x5 conv's 64 channels only) + 4 inner steps of 2 x 4096; the cross step 2 x 4096
+    const int odd = chunk & 1;
+    const bool half = pos < 2 * PAIR_OUTER;
+    if (half && nt < 2) continue;                 // the 3x3 conv has no weight on the outer ring
+    size_t base = (size_t)(chunk >> 1) * (2 * 65536 + 8192);
+    if (pos >= 24) base += 2 * 65536 + (size_t)odd * 4096;
+    else if (half) base += (size_t)odd * 65536 + (size_t)(pos >> 1) * 4096 + (size_t)(pos & 1) * 2048;
+    else base += (size_t)odd * 65536 + 32768 + (size_t)((pos - 16) >> 1) * 8192 + (size_t)(pos & 1) * 4096;
+    const int nch = half ? 64 : 128;
+    const int kk = half ? (k >> 6) * 32 + (nt - 2) * 16 + (k & 15) : k;
+    for (int p = 0; p < 2; ++p) {
+      const _Float16 q = (_Float16)v;
+      v -= (float)q;
+      wp[base + ((size_t)(p * 2 + kh2) * nch + kk) * 8 + j] = q;
+    }
+  }
+}
+
+extern "C" long long tsr_conv_weight_pair_elems(int cin) { return (long long)(((cin + 31) & ~31) / 32) * (2 * 65536 + 8192); }
+
+extern "C" int tsr_pack_conv_weight_pair_f16s(const float* w3_oihw, const float* w5_oihw, void* w_packed, int cin,
+                                              float wscale, const float* w_amax, void* stream) {
+  if (!w3_oihw || !w5_oihw || !w_packed || cin <= 0 || (cin & 15) || (!w_amax && !(wscale > 0.f))) return TSR_ERR_ARG;
+  const size_t total = (size_t)128 * ((cin + 31) & ~31) * 25;
+  const int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(pack_pair_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, (hipStream_t)stream, w3_oihw,
+                     w5_oihw, (_Float16*)w_packed, cin, wscale, w_amax);
+  return tsr_check_launch();
+}
+
+extern "C" int tsr_conv2d_fwd_f16s_pair(const float* in, int in_ctot, int in_coff, int cin, const void* w_packed,
+                                        float w_inv_scale, const float* in_amax, float* out_amax,
+                                        const float* scale, const float* shift, float* out, int out_ctot, int out_coff,
+                                        int relu, int B, int H, int W, void* stream) {
+  if (!in || !w_packed || !out || !in_amax || B <= 0 || H <= 0 || W <= 0 || !(w_inv_scale > 0.f)) return TSR_ERR_ARG;
+  if ((cin & 15) || (in_ctot & 15) || (in_coff & 15) || (out_ctot & 15) || (out_coff & 15) || cin <= 0 ||
+      in_coff + cin > in_ctot || out_coff + 128 > out_ctot)
+    return TSR_ERR_ARG;
+  ConvArgs a = {};
+  a.in = in; a.in_ctot = in_ctot; a.in_coff = in_coff; a.cin = cin;
+  a.wp = (const float*)w_packed; a.scale = scale; a.shift = shift;
+  a.out = out; a.out_ctot = out_ctot; a.out_coff = out_coff; a.relu = relu;
+  a.B = B; a.H = H; a.W = W;
+  a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8;
+  a.in_amax = in_amax; a.w_inv_scale = w_inv_scale; a.out_amax = out_amax;
+  static const bool p512 = getenv("TSR_CONV_PAIR512") != nullptr;
+  if (p512) {
+    const int grid4 = ((B + 3) / 4) * a.tiles_x * a.tiles_y;
+    hipLaunchKernelGGL((conv_k32_kernel<5, 128, false, 2, false, false, 512, true>), dim3(grid4), dim3(512), 0,
+                       (hipStream_t)stream, a);
+    return tsr_check_launch();
+  }
+  const int grid = ((B + 1) / 2) * a.tiles_x * a.tiles_y;
+  hipLaunchKernelGGL((conv_k32_kernel<5, 128, false, 2, false, false, 256, true>), dim3(grid), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  return tsr_check_launch();
 }
 
 int tsr_conv_k32_fuse1x1(const ConvArgs& a, int ks, hipStream_t st) {

@@ -38,7 +38,18 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <bool F16> struct Plane;
 template <> struct Plane<false> {
   typedef __bf16 T; typedef bf16x8 V8; typedef bf16x4 V4;
-  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
+#ifdef TSR_EXP_MFMA16   // timing experiment only (wrong results): the same FLOPs as two 16x16x32 instructions
+    f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0);
+    c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
+    c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+  }
 };
 template <> struct Plane<true> {
   typedef _Float16 T; typedef f16x8 V8; typedef f16x4 V4;
@@ -358,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
             // interleave the next tap's fragment reads with this tap's MFMAs (hipcc otherwise sinks all ds_reads
             // below the MFMA block, exposing their latency in front of the barrier's lgkmcnt(0) every step)
             #ifdef TSR_EXP_MFMA16
-            constexpr int MFX = F16 ? 2 : 1;
+            constexpr int MFX = 2;
 #else
             constexpr int MFX = 1;
 #endif

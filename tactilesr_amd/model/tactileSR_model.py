@@ -76,8 +76,11 @@ class _PackedConv:
     """Device-side constants of one conv launch: packed weight, folded scale/shift."""
     __slots__ = ("w", "scale", "shift", "cin", "cout", "ks", "nsplit", "w_inv_scale")
 
-    def __init__(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], nsplit: int = 0):
-        w = conv.weight.detach().float().contiguous()
+    def __init__(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], nsplit: int = 0, cin_perm=None):
+        w = conv.weight.detach().float()
+        if cin_perm is not None:         # the producer wrote its channels in another order (stage-1 pair kernel)
+            w = w[:, cin_perm]
+        w = w.contiguous()
         self.cout, self.cin, self.ks = w.shape[0], w.shape[1], w.shape[2]
         self.nsplit = nsplit
         self.w_inv_scale = 1.0
@@ -100,6 +103,40 @@ class _PackedConv:
             call("tsr_pack_conv_weight_bf16s", ptr(w), ptr(self.w), _I(self.cout), _I(self.cin), _I(self.ks),
                  _I(nsplit), stream())
         self.scale, self.shift = _fold(conv.bias, bn, self.cout, w.device)
+
+
+class _PackedPair:
+    """Stage-1 pair of an MSRB (conv_3_1 || conv_5_1 on the same input) as one launch of the K = 32 kernel: packed weight
+    stream, folded BN scale / shift in the kernel's channel order, and that order (`perm[k]` = channel of
+    cat([conv3, conv5]) held by kernel channel k) for the consumers' weights."""
+    __slots__ = ("w", "scale", "shift", "cin", "w_inv_scale", "perm")
+    _perm = None
+
+    @classmethod
+    def channel_perm(cls, device):
+        if cls._perm is None:
+            import ctypes
+            arr = (ctypes.c_int * 128)()
+            call("tsr_pair_channel_perm", ctypes.cast(arr, ctypes.c_void_p))
+            cls._perm = list(arr)
+        return torch.tensor(cls._perm, dtype=torch.long, device=device)
+
+    def __init__(self, seq3: nn.Sequential, seq5: nn.Sequential):
+        import math
+        w3 = seq3[0].weight.detach().float().contiguous()
+        w5 = seq5[0].weight.detach().float().contiguous()
+        self.cin = w3.shape[1]
+        m = max(float(w3.abs().max()), float(w5.abs().max()))
+        wscale = 2.0 ** (13 - math.floor(math.log2(m))) if m > 0 else 1.0
+        self.w_inv_scale = 1.0 / wscale
+        self.w = torch.empty(_lib.load().tsr_conv_weight_pair_elems(self.cin), dtype=torch.float16, device=w3.device)
+        call("tsr_pack_conv_weight_pair_f16s", ptr(w3), ptr(w5), ptr(self.w), _I(self.cin), _lib.c_float(wscale),
+             ptr(None), stream())
+        s3, sh3 = _fold(seq3[0].bias, seq3[1], 64, w3.device)
+        s5, sh5 = _fold(seq5[0].bias, seq5[1], 64, w3.device)
+        self.perm = self.channel_perm(w3.device)
+        self.scale = torch.cat([s3, s5])[self.perm].contiguous()
+        self.shift = torch.cat([sh3, sh5])[self.perm].contiguous()
 
 
 class _PackedHalf:
@@ -189,6 +226,8 @@ class TactileSR(nn.Module):
         # fp16x3 eval: apply each half of an MSRB's 1x1 `confusion` inside the stage-2 conv that produced its input
         # (csrc/conv_fuse1x1.h): `cat2` never exists in HBM.  TSR_FUSE1X1=0 keeps the separate 1x1 launches (A/B).
         self.fuse_1x1 = os.environ.get("TSR_FUSE1X1", "1") != "0"
+        # eval, fp16x3: the two stage-1 convs of an MSRB as one launch on one staged halo (TSR_FUSE_PAIR=0: two launches)
+        self.fuse_pair = os.environ.get("TSR_FUSE_PAIR", "1") != "0"
         self.max_images_per_pass = 4096   # workspace bound: ~6.6 MB of CB16 activations per image
 
     def make_layer(self, block, num_of_layer):
@@ -199,7 +238,7 @@ class TactileSR(nn.Module):
 
     # ------------------------------------------------------------------ engine
     def _param_key(self):
-        return (self.conv_impl, self.head_impl, self.fuse_1x1, _lib.param_epoch()) + tuple((t.data_ptr(), t._version)
+        return (self.conv_impl, self.head_impl, self.fuse_1x1, self.fuse_pair, _lib.param_epoch()) + tuple((t.data_ptr(), t._version)
                                          for t in list(self.parameters()) + list(self.buffers()))
 
     def _build_plan(self):
@@ -218,6 +257,15 @@ class TactileSR(nn.Module):
             if self.fuse_1x1 and (ns == -2 or self.conv_impl == "bf16"):
                 # the two 64x128 halves of the 1x1, each packed like a 1x1 conv weight
                 halves = tuple(_PackedHalf(blk.confusion.weight.detach()[:, o:o + 128], ns) for o in (0, 128))
+            if self.fuse_pair and ns == -2:
+                # stage 1 as ONE launch (3x3 || 5x5 on one staged halo); cat1 then holds the kernel's channel order and
+                # the stage-2 weights are permuted along C_in to match
+                pair = _PackedPair(blk.conv_3_1, blk.conv_5_1)
+                msrbs.append((pair, None,
+                              _PackedConv(blk.conv_3_2[0], blk.conv_3_2[1], ns, cin_perm=pair.perm),
+                              _PackedConv(blk.conv_5_2[0], blk.conv_5_2[1], ns, cin_perm=pair.perm),
+                              _PackedConv(blk.confusion, None, ns), halves))
+                continue
             msrbs.append((_PackedConv(blk.conv_3_1[0], blk.conv_3_1[1], ns), _PackedConv(blk.conv_5_1[0], blk.conv_5_1[1], ns),
                           _PackedConv(blk.conv_3_2[0], blk.conv_3_2[1], ns), _PackedConv(blk.conv_5_2[0], blk.conv_5_2[1], ns),
                           _PackedConv(blk.confusion, None, ns), halves))
@@ -261,6 +309,19 @@ class TactileSR(nn.Module):
         if prof is not None:
             e1.record()
             prof.setdefault((pc.ks, pc.cout), []).append((e0, e1))
+
+    def _conv_pair(self, pp: "_PackedPair", src, dst, B, H, W, amax_in, amax_out):
+        """conv_3_1 || conv_5_1 (+ BN + ReLU each) of an MSRB: 64 -> 128 channels of `cat1`, one launch."""
+        prof = self._profile
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        call("tsr_conv2d_fwd_f16s_pair", ptr(src), _I(64), _I(0), _I(pp.cin), ptr(pp.w), _lib.c_float(pp.w_inv_scale),
+             ptr(amax_in), ptr(amax_out), ptr(pp.scale), ptr(pp.shift), ptr(dst), _I(128), _I(0), _I(1),
+             _I(B), _I(H), _I(W), stream())
+        if prof is not None:
+            e1.record()
+            prof.setdefault(("pair", 128), []).append((e0, e1))
 
     def _conv_fused(self, pc: _PackedConv, half: "_PackedHalf", shift2, src, dst, d_ctot, d_coff, res, r_ctot, r_coff,
                     relu2, amax_out, amax_in, B, H, W):
@@ -347,8 +408,11 @@ class TactileSR(nn.Module):
         for i, (c31, c51, c32, c52, conf, halves) in enumerate(plan["msrb"]):
             last = i == n_msrb - 1
             s_c1, s_c2 = slot(), slot()
-            self._conv(c31, cur, 64, 0, cat1, 128, 0, True, B, H, W, amax_in=s_x, amax_out=s_c1)
-            self._conv(c51, cur, 64, 0, cat1, 128, 64, True, B, H, W, amax_in=s_x, amax_out=s_c1)
+            if c51 is None:      # stage-1 pair kernel
+                self._conv_pair(c31, cur, cat1, B, H, W, s_x, s_c1)
+            else:
+                self._conv(c31, cur, 64, 0, cat1, 128, 0, True, B, H, W, amax_in=s_x, amax_out=s_c1)
+                self._conv(c51, cur, 64, 0, cat1, 128, 64, True, B, H, W, amax_in=s_x, amax_out=s_c1)
             nxt = xb if cur is xa else xa
             if halves is not None:
                 # stage 2 with the 1x1 fused: P = W_a.relu(bn(conv3)) + b + x ; out = relu(W_b.relu(bn(conv5)) + P)

@@ -480,6 +480,62 @@ def test_conv2d_fused_1x1_epilogue(T, ks, cin, B, H, W, relu2, with_res, with_bi
     assert torch.isnan(T.from_cb16(out, B, 16, H, W, 96, 0)).all() and torch.isnan(T.from_cb16(out, B, 16, H, W, 96, 80)).all()
 
 
+@pytest.mark.parametrize("cin,B,H,W", [(64, 2, 40, 40), (64, 3, 13, 21), (32, 1, 100, 100), (48, 5, 8, 24), (128, 2, 16, 16)])
+def test_conv2d_stage1_pair_kernel(T, cin, B, H, W):
+    """tsr_conv2d_fwd_f16s_pair: conv3x3 || conv5x5 (each + folded BN + ReLU) of one input as ONE launch, output in the
+    kernel's channel order (tsr_pair_channel_perm) -- against fp64 at the fp32-grade bar; ragged tiles, odd batches, one
+    block pair and an odd block count (zero-padded)."""
+    import ctypes
+    import math
+    from tactilesr_amd._lib import call, ptr, stream, load, c_int as I, c_float as Fl
+    g = torch.Generator().manual_seed(cin + 7 * B + H)
+    x = torch.randn(B, cin, H, W, generator=g).clamp_(min=0) * 3
+    w3 = torch.randn(64, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    w5 = torch.randn(64, cin, 5, 5, generator=g) * (2.0 / (cin * 25)) ** 0.5
+    scale, shift = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.3
+    ref = torch.cat([F.conv2d(x.double(), w3.double(), padding=1), F.conv2d(x.double(), w5.double(), padding=2)], 1)
+    ref = F.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    arr = (ctypes.c_int * 128)()
+    call("tsr_pair_channel_perm", ctypes.cast(arr, ctypes.c_void_p))
+    perm = torch.tensor(list(arr))
+    assert sorted(perm.tolist()) == list(range(128))
+    xin = T.to_cb16(x.cuda())
+    wscale = 2.0 ** (13 - math.floor(math.log2(float(max(w3.abs().max(), w5.abs().max())))))
+    wp = torch.empty(load().tsr_conv_weight_pair_elems(cin), dtype=torch.float16, device="cuda")
+    w3d, w5d = w3.cuda().contiguous(), w5.cuda().contiguous()        # (kept alive until the pack kernel has run)
+    call("tsr_pack_conv_weight_pair_f16s", ptr(w3d), ptr(w5d), ptr(wp), I(cin), Fl(wscale), ptr(None), stream())
+    torch.cuda.synchronize()
+    amax_in = x.abs().max().reshape(1).cuda()
+    amax_out = torch.zeros(1, device="cuda")
+    out = torch.empty(B * 128 * H * W, device="cuda")
+    sc, sh = scale[perm].cuda().contiguous(), shift[perm].cuda().contiguous()
+    call("tsr_conv2d_fwd_f16s_pair", ptr(xin), I(cin), I(0), I(cin), ptr(wp), Fl(1.0 / wscale), ptr(amax_in),
+         ptr(amax_out), ptr(sc), ptr(sh), ptr(out), I(128), I(0), I(1), I(B), I(H), I(W), stream())
+    got = T.from_cb16(out, B, 128, H, W)              # kernel channel order
+    err = relerr(got, ref[:, perm])
+    print(f"[pair] {cin}->64||64 B={B} {H}x{W}: err vs f64 {err:.2e}")
+    assert err < TOL
+    assert abs(float(amax_out) - float(got.abs().max())) == 0.0
+
+
+def test_pair_and_two_launch_stage1_paths_agree(T, golden):
+    """The whole eval forward with the stage-1 pair kernel (default) and with two launches per stage (the stage-2 weights
+    then see their input channels in the other order)."""
+    g = golden("eval")
+    sd = O.random_state_dict(O.tactilesr_state_shapes(), int(g["t1/seed"]))
+    m = T.TactileSR()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    LR = torch.rand(5, 3, 4, 4, device="cuda") * 8
+    m.fuse_pair = True
+    y1 = m(LR)
+    m.fuse_pair = False
+    y0 = m(LR)
+    err = relerr(y1, y0)
+    print(f"[pair vs two launches] {err:.2e}")
+    assert not torch.equal(y0, y1) and err < 2 * TOL      # two fp32-grade evaluations: within the sum of their bars
+
+
 def test_fused_and_unfused_1x1_paths_agree(T, golden):
     """model.fuse_1x1 on/off: two fp32-grade evaluations of the same MSRB arithmetic (the fused form splits the tile with
     a tile-local scale instead of the tensor-wide one): within the sum of their 1e-5 bars."""
