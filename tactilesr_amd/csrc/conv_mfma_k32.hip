@@ -87,6 +87,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
   static_assert(NTHR == 256 || (NTHR == 512 && WN == 2), "512 threads: 4 images x 2 C_out halves");
   typedef K32Geom<KS, COUT, WN, DBH, NTHR> G;
   constexpr int NW = NTHR / 64;
+  constexpr bool WDMA = !EXT;             // weight slabs by LDS-DMA (inference) or through registers (training)
   constexpr int IMG = G::IMG, P = KS / 2, HH = G::HH, T = G::T, HS = G::HS, NT = COUT / (16 * WN);
   constexpr int PIXB = G::PIXB, ROWB = G::ROWB, IMGB = G::IMGB, HALO_B = G::HALO_B;
   constexpr int SROWB = G::SROWB, SIMGB = G::SIMGB, SIDE_B = G::SIDE_B;
@@ -240,18 +241,26 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
       }
     }
   };
-  // (TSR_ABL_K32_* : timing ablations, wrong results -- tools/build_variant.py)
+  // Weight slabs travel global memory -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction, no VGPR hop,
+  // no ds_write): slab s+2 is requested at the START of step s into ring slot (s+2)%3 -- free since the barrier that ended
+  // step s-1 -- and awaited (vmcnt 0) before the barrier that ends step s, which publishes it.  Against register staging
+  // (4 global loads + 4 ds_write_b128 per thread and step, 16 VGPRs): 5x5 128->128 11.57 -> 10.75 ms, eval forward
+  // 141.4 -> 137.0 ms.  (TSR_ABL_K32_* : timing ablations, wrong results -- tools/build_variant.py)
 #if defined(TSR_ABL_K32_NOW)
-#define LOAD_W(sidx) {}
-#define STORE_W(slot) {}
-#elif defined(TSR_ABL_K32_NOWST)
-#define LOAD_W(sidx)                                                                     \
-  {                                                                                      \
-    const f32x4* src_ = (const f32x4*)(wsrc + (size_t)(sidx) * WSLAB_B);                  \
-    _Pragma("unroll") for (int v = 0; v < WV; ++v) wreg[v] = src_[tid + v * NTHR];        \
-  }
-#define STORE_W(slot) { _Pragma("unroll") for (int v = 0; v < WV; ++v) asm volatile("" :: "v"(wreg[v])); }
+#define DMA_BYTES(goff_, slot_, nv_) {}
 #else
+#define DMA_BYTES(goff_, slot_, nv_)                                                     \
+  {                                                                                      \
+    const char* src_ = wsrc + (size_t)(goff_) + (size_t)tid * 16;                        \
+    char* dst_ = wbuf + (slot_) * WSLAB_B + (tid >> 6) * 1024;                           \
+    _Pragma("unroll") for (int v = 0; v < (nv_); ++v)                                    \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + v * NTHR * 16), \
+                                       (__attribute__((address_space(3))) void*)(dst_ + v * NTHR * 16), 16, 0, 0); \
+  }
+#endif
+  // Training launches (EXT) keep REGISTER staging -- slab s+3 loaded into VGPRs at the end of step s, written to LDS at
+  // the end of step s+1 -- and 512-thread workgroups: same-box A/B of the train step 277.2 ms against 281.7 (LDS-DMA, 256
+  // threads) / 285 (LDS-DMA, 512 threads); the inference launches gain 4 % from LDS-DMA at 256 threads (138.5 -> 132.8 ms).
 #define LOAD_W(sidx)                                                                     \
   {                                                                                      \
     const f32x4* src_ = (const f32x4*)(wsrc + (size_t)(sidx) * WSLAB_B);                  \
@@ -262,29 +271,18 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
     char* wb_ = wbuf + (slot) * WSLAB_B;                                                 \
     _Pragma("unroll") for (int v = 0; v < WV; ++v) ((f32x4*)wb_)[tid + v * NTHR] = wreg[v]; \
   }
-#endif
+#define DMA_W(sidx, slot) DMA_BYTES((size_t)(sidx) * WSLAB_B, slot, WV)
+  // wait for the slab only: the n_ YOUNGEST vector-memory operations (the next block's halo loads, issued after the
+  // slab request of the same step) may stay in flight -- vmcnt counts in issue order
+#define DMA_WAIT_N(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14))
+#define DMA_WAIT() DMA_WAIT_N(0)
   // pair form: the slabs of the outer-ring steps hold the 5x5 conv's 64 channels only (half size); the stream is walked
   // with a running offset.  pq_ = index of the step within its block pair (0..24), compile time.
 #define PAIR_HALF(pq_) ((pq_) < 24 && ((pq_) % 12) < PAIR_OUTER)
-#define LOAD_WP(pq_)                                                                     \
+#define DMA_WP(slot, pq_)                                                                \
   {                                                                                      \
-    const f32x4* src_ = (const f32x4*)(wsrc + woff3);                                    \
-    if (PAIR_HALF(pq_)) {                                                                \
-      _Pragma("unroll") for (int v = 0; v < WV / 2; ++v) wreg[v] = src_[tid + v * NTHR]; \
-      woff3 += WSLAB_B / 2;                                                              \
-    } else {                                                                             \
-      _Pragma("unroll") for (int v = 0; v < WV; ++v) wreg[v] = src_[tid + v * NTHR];     \
-      woff3 += WSLAB_B;                                                                  \
-    }                                                                                    \
-  }
-#define STORE_WP(slot, pq_)                                                              \
-  {                                                                                      \
-    char* wb_ = wbuf + (slot) * WSLAB_B;                                                 \
-    if (PAIR_HALF(pq_)) {                                                                \
-      _Pragma("unroll") for (int v = 0; v < WV / 2; ++v) ((f32x4*)wb_)[tid + v * NTHR] = wreg[v]; \
-    } else {                                                                             \
-      _Pragma("unroll") for (int v = 0; v < WV; ++v) ((f32x4*)wb_)[tid + v * NTHR] = wreg[v]; \
-    }                                                                                    \
+    if (PAIR_HALF(pq_)) { DMA_BYTES(woff, slot, WV / 2); woff += WSLAB_B / 2; }          \
+    else { DMA_BYTES(woff, slot, WV); woff += WSLAB_B; }                                 \
   }
 #ifdef TSR_ABL_K32_NOBAR
 #define STEP_BARRIER() __builtin_amdgcn_sched_barrier(0)
@@ -338,21 +336,22 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
   }
 
   // ---- prologue: halo(0), W(0), W(1) in LDS; W(2) in flight
-  f32x4 hv[NIT], wreg[WV];
-  size_t woff3 = 0;                       // pair form: byte offset of the next slab to load
+  f32x4 hv[NIT], wreg[WDMA ? 1 : WV];
+  size_t woff = 0;                        // pair form: byte offset of the next slab to request
   load_halo(0, hv);
-  if constexpr (PAIR) {                   // S >= 25; steps 0, 1, 2 are outer-ring steps
-    LOAD_WP(0); STORE_WP(0, 0);
-    LOAD_WP(1); STORE_WP(1, 1);
-    store_halo(hv, 0);
-    LOAD_WP(2);
+  if constexpr (PAIR) {                   // S >= 25; steps 0, 1 are outer-ring steps
+    DMA_WP(0, 0);
+    DMA_WP(1, 1);
+  } else if constexpr (WDMA) {
+    DMA_W(0, 0);
+    if (S > 1) DMA_W(1, 1);
   } else {
     LOAD_W(0);
     STORE_W(0);
     if (S > 1) { LOAD_W(1); STORE_W(1); }
-    store_halo(hv, 0);
-    if (S > 2) LOAD_W(2);
   }
+  store_halo(hv, 0);
+  if constexpr (WDMA) { DMA_WAIT(); } else { if (S > 2) LOAD_W(2); }
   __syncthreads();
 
   kf16x8 A0[4], A1[4], B0[NT] = {}, B1[NT] = {};
@@ -376,6 +375,9 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
       const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
       const bool cross = ODD && st == HS;
       f32x4 sidev[SCI];
+      if (WDMA && s + 2 < S) {                                     // slab s+2 -> the slot last read a barrier ago
+        if constexpr (PAIR) { DMA_WP(slot2, (ODD * HS + st + 2) % 25); } else { DMA_W(s + 2, slot2); }
+      }
       const bool outer = PAIR && st < PAIR_OUTER;                  // half-work step: the 5x5 conv's n-tiles only
       const bool next_outer = PAIR && (st + 1 < PAIR_OUTER || st + 1 == NST);   // (a block starts on the outer ring)
       // this step's second-phase operands
@@ -416,10 +418,8 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
 #pragma unroll
         for (int k = 0; k < SCI; ++k) *(f32x4*)(lds + sc_dst + k * SCS * SIMGB) = sidev[k];
       }
-      if constexpr (PAIR) {
-        const int pq = ODD * HS + st;           // step index within the block pair (the cross step: 24)
-        if (s + 2 < S) STORE_WP(slot2, (pq + 2) % 25);
-        if (s + 3 < S) LOAD_WP((pq + 3) % 25);
+      if constexpr (WDMA) {
+        if (st == NST - 2 && c + 1 < nchunk) { DMA_WAIT_N(NIT); } else { DMA_WAIT(); }
       } else {
         if (s + 2 < S) STORE_W(slot2);           // slot (s+2)%3 was last read one barrier ago
         if (s + 3 < S) LOAD_W(s + 3);
@@ -445,6 +445,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
       for (int p = 0; p < T; ++p) {          // even block: p < HS (slab 0); cross: p == HS; odd block: p > HS (slab 1)
         const int slot1 = slot == 2 ? 0 : slot + 1;
         const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
+        if (WDMA && s + 2 < S) DMA_W(s + 2, slot2);
         if (p == HS) { LOAD_A_CROSSD(A0, 0); }
         else if (p < HS) { LOAD_A(A0, 0, p, 0); }
         else { LOAD_A(A0, 0, p - HS - 1, 1); }
@@ -464,20 +465,27 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
         INTERLEAVE(4, 4);
         if (p == HS - 2) store_halo(hv, c + 1, 1);                 // slab 1: last read in the previous pair
         if (p == T - 2 && c + 2 < nchunk) store_halo(hv, c + 2, 0);  // slab 0: last read by the cross step
-        if (s + 2 < S) STORE_W(slot2);
-        if (s + 3 < S) LOAD_W(s + 3);
+        if constexpr (WDMA) {
+          if (p == 0 || (p == HS + 1 && c + 2 < nchunk)) { DMA_WAIT_N(NIT); } else { DMA_WAIT(); }
+        } else {
+          if (s + 2 < S) STORE_W(slot2);
+          if (s + 3 < S) LOAD_W(s + 3);
+        }
         STEP_BARRIER();
         ++s;
         slot = slot1;
       }
     }
   }
+#undef DMA_W
 #undef LOAD_W
-#undef LOAD_WP
-#undef STORE_WP
+#undef STORE_W
+#undef DMA_WP
+#undef DMA_BYTES
+#undef DMA_WAIT
+#undef DMA_WAIT_N
 #undef PAIR_HALF
 #undef STEP_BARRIER
-#undef STORE_W
 #undef LOAD_A
 #undef LOAD_A_CROSS
 #undef LOAD_A_CROSSD
@@ -505,7 +513,7 @@ static int launch_k32(const ConvArgs& a, hipStream_t st) {
   // (C_out = 64 as 2 images x 2 halves of 32 channels, 3 workgroups per CU, measured no better than the 4-image form:
   // 5x5 3.41 vs 3.39 ms, 3x3 1.60 vs 1.68 ms at B = 4096; the 32x32x16 kernel does 3.23 / 1.61 ms)
   constexpr int WN = COUT / 64;
-  if constexpr (COUT == 128) {
+  if constexpr (COUT == 128 && EXT) {      // training: 512 threads + register staging; inference: 256 threads + LDS-DMA
     if (!k32_256()) {
       const int grid = ((a.B + 3) / 4) * a.tiles_x * a.tiles_y;
       hipLaunchKernelGGL((conv_k32_kernel<KS, COUT, EXT, WN, false, KS == 3, 512>), dim3(grid), dim3(512), 0, st, a);
