@@ -305,6 +305,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
     _Pragma("unroll") for (int v = 0; v < WV; ++v)                                       \
       if ((v + 1) * 256 <= WITEMS || tid + v * 256 < WITEMS) ((f32x4*)wb_)[tid + v * 256] = wreg[v]; \
   }
+  // Inference launches (!EXT): the weight slab goes global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR hop, no
+  // ds_write; see conv_mfma_k32.hip): slab s+2 is requested at the start of step s into ring slot (s+2)%3 and awaited before
+  // the barrier that ends the step.  Training launches keep the register staging above (measured faster there).
+#define DMA_W(sidx, slot)                                                                \
+  {                                                                                      \
+    const char* src_ = wsrc + (size_t)(sidx) * WSLAB_B + (size_t)tid * 16;                \
+    char* dst_ = wbuf + (slot) * WSLAB_B + (tid >> 6) * 1024;                            \
+    _Pragma("unroll") for (int v = 0; v < WV; ++v)                                       \
+      if ((v + 1) * 256 <= WITEMS || tid + v * 256 < WITEMS)                             \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + v * 4096), \
+                                         (__attribute__((address_space(3))) void*)(dst_ + v * 4096), 16, 0, 0); \
+  }
+  // vmcnt wait that leaves the n_ youngest vector-memory operations (the next block's halo loads) in flight
+#define DMA_WAIT_N(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14))
   // fragments of one (block, tap) step -> register set `set` (compile-time index after unrolling)
 #define LOAD_FRAGS(set, slot, tapoff, kh_, kw_, hb_)                                     \
   {                                                                                      \
@@ -318,13 +332,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
   }
 
   // ---- prologue: halo(0), W(0), W(1) in LDS; W(2) in flight
-  f32x4 hv[NIT], wreg[WV];
+  constexpr bool WDMA = !EXT;
+  f32x4 hv[NIT], wreg[WDMA ? 1 : WV];
   load_halo(0, hv);
-  LOAD_W(0);
-  STORE_W(0);
-  if (S > 1) { LOAD_W(1); STORE_W(1); }
-  store_halo(hv, 0, 0);
-  if (S > 2) LOAD_W(2);
+  if constexpr (WDMA) {
+    DMA_W(0, 0);
+    if (S > 1) DMA_W(1, 1);
+    store_halo(hv, 0, 0);
+    DMA_WAIT_N(0);
+  } else {
+    LOAD_W(0);
+    STORE_W(0);
+    if (S > 1) { LOAD_W(1); STORE_W(1); }
+    store_halo(hv, 0, 0);
+    if (S > 2) LOAD_W(2);
+  }
   __syncthreads();
 
   PV8 fa[2][NS][2], fb[2][NS][NB];        // ping-pong fragment sets, statically indexed
@@ -339,6 +361,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
     for (int st = 0; st < NSTEP; ++st) {
       const int slot1 = slot == 2 ? 0 : slot + 1;
       const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
+      if (WDMA && s + 2 < S) DMA_W(s + 2, slot2);                   // slot (s+2)%3 was last read one barrier ago
       if (DBH && st == 0 && c + 1 < nchunk) load_halo(c + 1, hv);   // next block's slab: in flight for NSTEP-2 steps
 #pragma unroll
       for (int tt = 0; tt < TPS; ++tt) {
@@ -383,8 +406,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
         }
       }
       if (DBH && st == NSTEP - 2 && c + 1 < nchunk) store_halo(hv, c + 1, P ^ 1);   // other buffer: last read a block ago
-      if (s + 2 < S) STORE_W(slot2);           // slot (s+2)%3 was last read one barrier ago
-      if (s + 3 < S) LOAD_W(s + 3);
+      if constexpr (WDMA) {
+        // (the step that issued the next block's halo loads lets them fly on)
+        if ((DBH ? st == 0 : st + 1 == NSTEP) && c + 1 < nchunk) { DMA_WAIT_N(NIT); } else { DMA_WAIT_N(0); }
+      } else {
+        if (s + 2 < S) STORE_W(slot2);           // slot (s+2)%3 was last read one barrier ago
+        if (s + 3 < S) LOAD_W(s + 3);
+      }
       __syncthreads();
       if (!DBH && st + 1 == NSTEP && c + 1 < nchunk) {
         store_halo(hv, c + 1, 0);  // every wave is past its last read of the old slab (barrier above)
@@ -405,6 +433,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
   }
 #undef LOAD_W
 #undef STORE_W
+#undef DMA_W
+#undef DMA_WAIT_N
 #undef LOAD_FRAGS
 
   if constexpr (FUSE2 && IO16) conv_fuse1x1_b16_epilogue(a, acc, lds, b0, y0, x0, wm, h, li, HW);
