@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
   }
 
   // ---- prologue: halo(0), W(0), W(1) in LDS; W(2) in flight
-  constexpr bool WDMA = !EXT;
+  constexpr bool WDMA = !EXT;       // (LDS-DMA in the training instantiations: neutral here, -5 ms/step in the K = 32 kernel)
   f32x4 hv[NIT], wreg[WDMA ? 1 : WV];
   load_halo(0, hv);
   if constexpr (WDMA) {
