@@ -90,7 +90,11 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
   static_assert(NTHR == 256 || (NTHR == 512 && WN == 2), "512 threads: 4 images x 2 C_out halves");
   typedef K32Geom<KS, COUT, WN, DBH, NTHR> G;
   constexpr int NW = NTHR / 64;
+#ifdef TSR_EXP_K32_EXTDMA                 // experiment: LDS-DMA in the training instantiations too
+  constexpr bool WDMA = true;
+#else
   constexpr bool WDMA = !EXT;             // weight slabs by LDS-DMA (inference) or through registers (training)
+#endif
   constexpr int IMG = G::IMG, P = KS / 2, HH = G::HH, T = G::T, HS = G::HS, NT = COUT / (16 * WN);
   constexpr int PIXB = G::PIXB, ROWB = G::ROWB, IMGB = G::IMGB, HALO_B = G::HALO_B;
   constexpr int SROWB = G::SROWB, SIMGB = G::SIMGB, SIDE_B = G::SIDE_B;
