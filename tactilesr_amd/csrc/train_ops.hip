@@ -304,29 +304,32 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   }
   __syncthreads();
   const int HW = H * W, b = blockIdx.y, nblk = cin >> 4;
-  const int item = blockIdx.x * 256 + tid;        // (pixel, channel block)
+  // item = (channel block, pixel, channel quad): the four lanes of a quad cover one 64-B CB16 line, a wave 16 whole
+  // lines = 1 KB contiguous per load / store instruction (one lane per (pixel, block) with four 16-B accesses at a
+  // 64-B lane stride: 3.5 ms per step at B = 2048; this form 2.9 ms.  Staging the masked dout strip in LDS per 64-pixel
+  // workgroup instead of 18 small global loads per lane measured slower and erratic, 2.9-18 ms: its serial prologue)
+  const int item = blockIdx.x * 256 + tid;
   float amax = 0.f;
-  if (item < HW * nblk) {
-  const int blk = item / HW, q = item - blk * HW;
-  const int y = q / W, x = q - y * W;
-  float dp[9];
+  if (item < HW * nblk * 4) {
+    const int qd = item & 3, pq = item >> 2;
+    const int blk = pq / HW, q = pq - blk * HW;
+    const int y = q / W, x = q - y * W;
+    float dp[9];
 #pragma unroll
-  for (int kh = 0; kh < 3; ++kh)
+    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int py = y - kh + 1, px = x - kw + 1;
-      float v = 0.f;
-      if (py >= 0 && py < H && px >= 0 && px < W) {
-        const size_t o = (size_t)b * HW + py * W + px;
-        v = out[o] > 0.f ? dout[o] : 0.f;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int py = y - kh + 1, px = x - kw + 1;
+        float v = 0.f;
+        if (py >= 0 && py < H && px >= 0 && px < W) {
+          const size_t o = (size_t)b * HW + py * W + px;
+          v = out[o] > 0.f ? dout[o] : 0.f;
+        }
+        dp[kh * 3 + kw] = v;
       }
-      dp[kh * 3 + kw] = v;
-    }
-  const f32x4* hp = (const f32x4*)(h0 + (((size_t)b * (h_ctot >> 4) + blk) * HW + q) * 16);
-  f32x4* dp4 = (f32x4*)(dz + (((size_t)b * (dz_ctot >> 4) + blk) * HW + q) * 16);
-#pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
-    const f32x4 hv = hp[qd];
+    const size_t eo = (((size_t)b * (h_ctot >> 4) + blk) * HW + q) * 16 + qd * 4;
+    const size_t zo = (((size_t)b * (dz_ctot >> 4) + blk) * HW + q) * 16 + qd * 4;
+    const f32x4 hv = *(const f32x4*)(h0 + eo);
     f32x4 r;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -337,8 +340,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       r[j] = hv[j] > 0.f ? s : 0.f;
       amax = fmaxf(amax, fabsf(r[j]));
     }
-    dp4[qd] = r;
-  }
+    *(f32x4*)(dz + zo) = r;
   }
   if (out_amax) {
 #pragma unroll
@@ -404,7 +406,7 @@ extern "C" int tsr_head_bwd(const float* dout, const float* out, const float* h0
       cin > dz_ctot || (h_ctot & 15) || (dz_ctot & 15))
     return TSR_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const int items = H * W * (cin >> 4);
+  const int items = H * W * (cin >> 4) * 4;
   hipLaunchKernelGGL(head_bwd_kernel, dim3((items + 255) / 256, B), dim3(256), (size_t)9 * cin * 4, st, dout, out,
                      h0, h_ctot, cin, w_oihw, dz_h0, dz_ctot, B, H, W, dz_amax);
   size_t fl = (size_t)(H + 2) * (W + 2);
