@@ -109,6 +109,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);       // wave-uniform copy (LDS-DMA base goes to M0)
   const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
   const int m = lane & 15, g = lane >> 4, khalf = g & 1, tsel = g >> 1;
 
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
 #define DMA_BYTES(goff_, slot_, nv_)                                                     \
   {                                                                                      \
     const char* src_ = wsrc + (size_t)(goff_) + (size_t)tid * 16;                        \
-    char* dst_ = wbuf + (slot_) * WSLAB_B + (tid >> 6) * 1024;                           \
+    char* dst_ = wbuf + (slot_) * WSLAB_B + wave_s * 1024;                               \
     _Pragma("unroll") for (int v = 0; v < (nv_); ++v)                                    \
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + v * NTHR * 16), \
                                        (__attribute__((address_space(3))) void*)(dst_ + v * NTHR * 16), 16, 0, 0); \
