@@ -212,6 +212,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
   const int nchunk = nreal + (nreal & 1);     // blocks come in pairs
   const int S = (nchunk >> 1) * T;            // steps: HS per even block, HS + 1 per odd block
   const char* wsrc = (const char*)a.wp;
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 0x7fffffff, 0x00020000);
 
   auto load_halo = [&](int c, f32x4* hv) {
     // (an odd block count is padded to even: the phantom block re-reads the last real one against zero weights)
@@ -251,7 +252,10 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
   };
   // Weight slabs travel global memory -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction, no VGPR hop,
   // no ds_write): slab s+2 is requested at the START of step s into ring slot (s+2)%3 -- free since the barrier that ended
-  // step s-1 -- and awaited (vmcnt 0) before the barrier that ends step s, which publishes it.  Against register staging
+  // step s-1 -- and awaited (vmcnt 0) before the barrier that ends step s, which publishes it.  The instruction is the
+  // MUBUF form (buffer_load_dwordx4 ... lds), not global_load_lds: hipcc models the FLAT-encoded one as a possible LDS
+  // access through FLAT and then degrades every counted lgkmcnt wait of the step to lgkmcnt(0) -- a full LDS drain in the
+  // middle of every step (whole eval forward 133.3 -> 131.9 ms with the MUBUF form).  Against register staging
   // (4 global loads + 4 ds_write_b128 per thread and step, 16 VGPRs): 5x5 128->128 11.57 -> 10.75 ms, eval forward
   // 141.4 -> 137.0 ms.  (TSR_ABL_K32_* : timing ablations, wrong results -- tools/build_variant.py)
 #if defined(TSR_ABL_K32_NOW)
@@ -259,11 +263,11 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
 #else
 #define DMA_BYTES(goff_, slot_, nv_)                                                     \
   {                                                                                      \
-    const char* src_ = wsrc + (size_t)(goff_) + (size_t)tid * 16;                        \
+    const int vo_ = (int)(goff_) + tid * 16;                                             \
     char* dst_ = wbuf + (slot_) * WSLAB_B + wave_s * 1024;                               \
     _Pragma("unroll") for (int v = 0; v < (nv_); ++v)                                    \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + v * NTHR * 16), \
-                                       (__attribute__((address_space(3))) void*)(dst_ + v * NTHR * 16), 16, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(dst_ + v * NTHR * 16), 16, \
+                                               vo_ + v * NTHR * 16, 0, 0, 0);             \
   }
 #endif
   // Training launches (EXT) keep REGISTER staging -- slab s+3 loaded into VGPRs at the end of step s, written to LDS at

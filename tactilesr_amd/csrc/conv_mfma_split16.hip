@@ -232,6 +232,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
   const int nchunk = a.cin >> 4;
   const int S = nchunk * NSTEP;
   const char* wsrc = (const char*)a.wp;
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 0x7fffffff, 0x00020000);
+  const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   // ---- helpers (all loops fully unrolled: fragment registers are plain SSA values)
   auto load_halo = [&](int c, f32x4* hv) {
@@ -308,14 +310,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
   // Inference launches (!EXT): the weight slab goes global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR hop, no
   // ds_write; see conv_mfma_k32.hip): slab s+2 is requested at the start of step s into ring slot (s+2)%3 and awaited before
   // the barrier that ends the step.  Training launches keep the register staging above (measured faster there).
+  // (MUBUF form -- buffer_load_dwordx4 ... lds -- not global_load_lds: hipcc treats the FLAT-encoded instruction as a
+  // possible LDS access through FLAT and then turns every later counted lgkmcnt wait of the step into lgkmcnt(0))
 #define DMA_W(sidx, slot)                                                                \
   {                                                                                      \
-    const char* src_ = wsrc + (size_t)(sidx) * WSLAB_B + (size_t)tid * 16;                \
-    char* dst_ = wbuf + (slot) * WSLAB_B + (tid >> 6) * 1024;                            \
+    const int vo_ = (sidx) * WSLAB_B + tid * 16;                                         \
+    char* dst_ = wbuf + (slot) * WSLAB_B + wave_s * 1024;                                \
     _Pragma("unroll") for (int v = 0; v < WV; ++v)                                       \
       if ((v + 1) * 256 <= WITEMS || tid + v * 256 < WITEMS)                             \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + v * 4096), \
-                                         (__attribute__((address_space(3))) void*)(dst_ + v * 4096), 16, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(dst_ + v * 4096), 16, \
+                                                 vo_ + v * 4096, 0, 0, 0);                \
   }
   // vmcnt wait that leaves the n_ youngest vector-memory operations (the next block's halo loads) in flight
 #define DMA_WAIT_N(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14))
