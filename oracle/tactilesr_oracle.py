@@ -195,29 +195,62 @@ def _relu(tap: Optional[ReluTap], name: str, x: torch.Tensor) -> torch.Tensor:
     return F.relu(x) if tap is None else tap(name, x)
 
 
-def _conv_bn_relu(p, prefix_conv, prefix_bn, x, pad, training, new_stats, tap=None):
-    y = F.conv2d(x, p[prefix_conv + ".weight"], p.get(prefix_conv + ".bias"), padding=pad)
-    return _relu(tap, prefix_bn, _bn(p, prefix_bn, y, training, new_stats))
+# ---- reduced-precision emulation (BASELINE's "bf16" configurations) ----------------------------------------------
+# The reference has no bf16 numerics (cpu/trainer.py:96,203,346-362 only carries an unused fp16 autocast switch), so
+# the bf16 paths of the build are checked against THIS restatement of their arithmetic: every tensor the device
+# stores in HBM as bf16 is rounded to bf16 (round-to-nearest-even) at the same point, conv weights are rounded to
+# bf16 once, products are exact and accumulation is wide (float64 here, fp32 inside the MFMA on the device), the
+# epilogue arithmetic (BatchNorm fold, bias, residual, ReLU) is fp32 on fp32 parameters.  `emulate=None` is the
+# reference's plain fp32 path and leaves every function below exactly as it was.
+def _q(t: torch.Tensor, emulate) -> torch.Tensor:
+    """Round to the storage type of the emulated path (identity for emulate=None)."""
+    if emulate is None:
+        return t
+    assert emulate == "bf16", emulate
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def _conv_q(x, w, bias, pad, emulate):
+    """conv2d with the operand handling of the emulated path: weights rounded to the storage type, exact products,
+    wide accumulation; the input must already hold storage-type values."""
+    if emulate is None:
+        return F.conv2d(x, w, bias, padding=pad)
+    y = F.conv2d(x.double(), _q(w, emulate).double(), None, padding=pad).to(x.dtype)
+    return y if bias is None else y + bias.view(1, -1, 1, 1)
+
+
+def _conv_bn_relu(p, prefix_conv, prefix_bn, x, pad, training, new_stats, tap=None, emulate=None):
+    y = _conv_q(x, p[prefix_conv + ".weight"], p.get(prefix_conv + ".bias"), pad, emulate)
+    return _q(_relu(tap, prefix_bn, _bn(p, prefix_bn, y, training, new_stats)), emulate)
 
 
 def msrb_forward(p: Params, prefix: str, x: torch.Tensor, training=False,
-                 new_stats: Optional[Params] = None, tap: Optional[ReluTap] = None) -> torch.Tensor:
-    """MSRB.forward, model/tactileSR_model.py:196-206."""
-    o31 = _conv_bn_relu(p, f"{prefix}.conv_3_1.0", f"{prefix}.conv_3_1.1", x, 1, training, new_stats, tap)
-    o51 = _conv_bn_relu(p, f"{prefix}.conv_5_1.0", f"{prefix}.conv_5_1.1", x, 2, training, new_stats, tap)
+                 new_stats: Optional[Params] = None, tap: Optional[ReluTap] = None, emulate=None) -> torch.Tensor:
+    """MSRB.forward, model/tactileSR_model.py:196-206.  `emulate="bf16"`: the inference path with bf16 activation
+    storage applies each 128-channel half of the 1x1 `confusion` inside the stage-2 launch that produced its input
+    (the 3x3 half first, its partial sum + bias + x stored as bf16, then the 5x5 half + ReLU), so the rounding points
+    are: cat1, the two stage-2 tiles, the partial sum, the block output."""
+    o31 = _conv_bn_relu(p, f"{prefix}.conv_3_1.0", f"{prefix}.conv_3_1.1", x, 1, training, new_stats, tap, emulate)
+    o51 = _conv_bn_relu(p, f"{prefix}.conv_5_1.0", f"{prefix}.conv_5_1.1", x, 2, training, new_stats, tap, emulate)
     in2 = torch.cat([o31, o51], 1)
-    o32 = _conv_bn_relu(p, f"{prefix}.conv_3_2.0", f"{prefix}.conv_3_2.1", in2, 1, training, new_stats, tap)
-    o52 = _conv_bn_relu(p, f"{prefix}.conv_5_2.0", f"{prefix}.conv_5_2.1", in2, 2, training, new_stats, tap)
+    o32 = _conv_bn_relu(p, f"{prefix}.conv_3_2.0", f"{prefix}.conv_3_2.1", in2, 1, training, new_stats, tap, emulate)
+    o52 = _conv_bn_relu(p, f"{prefix}.conv_5_2.0", f"{prefix}.conv_5_2.1", in2, 2, training, new_stats, tap, emulate)
+    wc, bc = p[f"{prefix}.confusion.weight"], p[f"{prefix}.confusion.bias"]
+    if emulate is not None and not training:
+        part = _q(_conv_q(o32, wc[:, :128], bc, 0, emulate) + x, emulate)
+        return _q(_relu(tap, f"{prefix}.out", _conv_q(o52, wc[:, 128:], None, 0, emulate) + part), emulate)
     in3 = torch.cat([o32, o52], 1)
-    out = F.conv2d(in3, p[f"{prefix}.confusion.weight"], p[f"{prefix}.confusion.bias"])
-    return _relu(tap, f"{prefix}.out", out + x)
+    out = _conv_q(in3, wc, bc, 0, emulate)
+    return _q(_relu(tap, f"{prefix}.out", out + x), emulate)
 
 
-def resblock_forward(p: Params, prefix: str, x: torch.Tensor, tap: Optional[ReluTap] = None) -> torch.Tensor:
+def resblock_forward(p: Params, prefix: str, x: torch.Tensor, tap: Optional[ReluTap] = None,
+                     emulate=None) -> torch.Tensor:
     """ResBlock.forward, model/tactileSR_model.py:222-225."""
-    y = _relu(tap, f"{prefix}.conv1", F.conv2d(x, p[f"{prefix}.conv1.weight"], p[f"{prefix}.conv1.bias"], padding=1))
-    y = F.conv2d(y, p[f"{prefix}.conv2.weight"], p[f"{prefix}.conv2.bias"], padding=1)
-    return _relu(tap, f"{prefix}.out", x + y)
+    y = _q(_relu(tap, f"{prefix}.conv1", _conv_q(x, p[f"{prefix}.conv1.weight"], p[f"{prefix}.conv1.bias"], 1, emulate)),
+           emulate)
+    y = _conv_q(y, p[f"{prefix}.conv2.weight"], p[f"{prefix}.conv2.bias"], 1, emulate)
+    return _q(_relu(tap, f"{prefix}.out", x + y), emulate)
 
 
 def _count(p: Params, stem: str) -> int:
@@ -230,10 +263,16 @@ def _count(p: Params, stem: str) -> int:
 def tactilesr_forward(p: Params, x: torch.Tensor, scale_factor=10, axisCnt=3,
                       training=False, new_stats: Optional[Params] = None,
                       stages: Optional[Dict[str, torch.Tensor]] = None,
-                      tap: Optional[ReluTap] = None) -> torch.Tensor:
+                      tap: Optional[ReluTap] = None, emulate=None,
+                      teacher: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
     """TactileSR.forward, model/tactileSR_model.py:67-84.  ``stages`` (optional)
     receives named intermediate activations for per-stage parity probes; ``tap``
-    (optional, tests only) records / overrides the ReLU activation pattern."""
+    (optional, tests only) records / overrides the ReLU activation pattern.
+    ``emulate="bf16"`` restates the arithmetic of the build's bf16 activation-storage path (see ``_q``).
+    ``teacher`` (optional, tests only; name -> tensor): after stage ``name`` has been computed (and recorded in
+    ``stages``) the given tensor -- the device's output of that stage -- is what the following stages consume, so
+    that every recorded stage is the oracle's answer to the DEVICE's inputs (a rounding-boundary flip in one stage
+    then cannot cascade into the comparison of the next)."""
     seqsCnt = _count(p, "inputLayer_pattern_list")
     n_msrb = _count(p, "patternFeatureExtra_layer")
     n_res = _count(p, "forceFeatureExtra_layer")
@@ -243,30 +282,34 @@ def tactilesr_forward(p: Params, x: torch.Tensor, scale_factor=10, axisCnt=3,
     def rec(name, t):
         if stages is not None:
             stages[name] = t
+        if teacher is not None and name in teacher:
+            return teacher[name].to(t.dtype)
         return t
 
     feats = []
     for t in range(seqsCnt):
         pre = f"inputLayer_pattern_list.{t}"
         u = bilinear_resize(x[:, axisCnt * t:axisCnt * (t + 1)], size)
-        h = _conv_bn_relu(p, f"{pre}.1", f"{pre}.2", u, 1, training, new_stats, tap)
-        h = _conv_bn_relu(p, f"{pre}.4", f"{pre}.5", h, 1, training, new_stats, tap)
+        # (the stem kernel fuses the upsample with its fp32 3->64 conv: fp32 operands, only its OUTPUT is stored)
+        h = _q(_conv_bn_relu(p, f"{pre}.1", f"{pre}.2", u, 1, training, new_stats, tap), emulate)
+        h = _conv_bn_relu(p, f"{pre}.4", f"{pre}.5", h, 1, training, new_stats, tap, emulate)
         feats.append(rec(f"stem{t}", h))
     h = torch.cat(feats, 1) if seqsCnt > 1 else feats[0]
     h = rec("fuse", _conv_bn_relu(p, "inputContact_layer.0", "inputContact_layer.1", h, 1,
-                                  training, new_stats, tap))
+                                  training, new_stats, tap, emulate))
     for i in range(n_msrb):
-        h = rec(f"msrb{i}", msrb_forward(p, f"patternFeatureExtra_layer.{i}", h, training, new_stats, tap))
+        h = rec(f"msrb{i}", msrb_forward(p, f"patternFeatureExtra_layer.{i}", h, training, new_stats, tap, emulate))
     pattern = h
 
     u = bilinear_resize(x[:, :axisCnt], size)
-    f = rec("force_in", _relu(tap, "force_in", F.conv2d(u, p["input_layer_force.1.weight"], padding=1)))
+    f = rec("force_in", _q(_relu(tap, "force_in", F.conv2d(u, p["input_layer_force.1.weight"], padding=1)), emulate))
     for i in range(n_res):
-        f = resblock_forward(p, f"forceFeatureExtra_layer.{i}", f, tap)
-    rec("force", f)
+        f = resblock_forward(p, f"forceFeatureExtra_layer.{i}", f, tap, emulate)
+    f = rec("force", f)
 
     out = torch.cat((f, pattern), 1)           # force first (model/tactileSR_model.py:81)
-    out = rec("head0", _relu(tap, "head0", F.conv2d(out, p["output_layer.0.weight"], padding=1)))
+    out = rec("head0", _q(_relu(tap, "head0", _conv_q(out, p["output_layer.0.weight"], None, 1, emulate)), emulate))
+    # (the head kernel reads the stored activations but keeps its 128->1 weights and its output in fp32)
     out = _relu(tap, "out", F.conv2d(out, p["output_layer.2.weight"], padding=1))
     # final F.interpolate to the same size is an exact identity (model/tactileSR_model.py:83)
     out = F.interpolate(out, size=(4 * scale_factor, 4 * scale_factor), mode="bilinear",

@@ -94,14 +94,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
               }
               if (EXT && a.res_scale) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) rv[c] = fmaxf(fmaf(rv[c], rsc4[c], rsh4[c]), 0.f);
+                for (int c = 0; c < 4; ++c) rv[c] = tsr_relu(fmaf(rv[c], rsc4[c], rsh4[c]));
               }
 #pragma unroll
               for (int c = 0; c < 4; ++c) v[c] += rv[c];
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-              if (a.relu) v[c] = fmaxf(v[c], 0.f);
+              if (a.relu) v[c] = tsr_relu(v[c]);
               amax = fmaxf(amax, fabsf(v[c]));
             }
             if (IO16) {

@@ -45,7 +45,7 @@ __device__ __forceinline__ void conv_fuse1x1_epilogue(const ConvArgs& a, f32x16 
         const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
         const int gy = y0 + 4 * mb + (m >> 3), gx = x0 + (m & 7);
         float v = fmaf(acc[mb][nb][r], sc, sh);
-        if (a.relu) v = fmaxf(v, 0.f);
+        if (a.relu) v = tsr_relu(v);
         if (!(img_ok && gy < a.H && gx < a.W)) v = 0.f;
         acc[mb][nb][r] = v;
         amax = fmaxf(amax, fabsf(v));
@@ -57,7 +57,10 @@ __device__ __forceinline__ void conv_fuse1x1_epilogue(const ConvArgs& a, f32x16 
   // (the main loop ended on a barrier: no wave still reads the halo / weight ring)
   if ((h | li) == 0) red[wm * 2 + wn] = amax;
   __syncthreads();
-  const float tmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  // (a wave whose image holds an Inf does not take part in the tile scale: the other image of the tile keeps its result)
+  float tmax = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) tmax = fmaxf(tmax, red[w] < 3.0e38f ? red[w] : 0.f);
   float s_e = 1.f;
   if (tmax > 0.f) {
     int e = (int)((__float_as_uint(tmax) >> 23) & 0xFF) - 127;
@@ -151,7 +154,7 @@ __device__ __forceinline__ void conv_fuse1x1_epilogue(const ConvArgs& a, f32x16 
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          if (a.relu2) v[c] = fmaxf(v[c], 0.f);
+          if (a.relu2) v[c] = tsr_relu(v[c]);
           omax = fmaxf(omax, fabsf(v[c]));
         }
         *(f32x4*)(ob4 + po) = v;
@@ -216,7 +219,7 @@ __device__ __forceinline__ void conv_fuse1x1_b16_epilogue(const ConvArgs& a, f32
             const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
             const int gy = y0 + 4 * mb + (m >> 3), gx = x0 + (m & 7);
             float v = fmaf(acc[mb][nb][r], sc, sh);
-            if (a.relu) v = fmaxf(v, 0.f);
+            if (a.relu) v = tsr_relu(v);
             if (!(img_ok && gy < a.H && gx < a.W)) v = 0.f;
             t[c] = v;
           }
@@ -276,7 +279,7 @@ __device__ __forceinline__ void conv_fuse1x1_b16_epilogue(const ConvArgs& a, f32
           }
           fz_bf16x4 o;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) o[c] = (__bf16)(a.relu2 ? fmaxf(v[c], 0.f) : v[c]);
+          for (int c = 0; c < 4; ++c) o[c] = (__bf16)(a.relu2 ? tsr_relu(v[c]) : v[c]);
           *(fz_bf16x4*)(ob4 + po) = o;
         }
       }

@@ -53,7 +53,7 @@ __device__ __forceinline__ void conv_fuse1x1_epilogue16(const ConvArgs& a, f32x4
       for (int r = 0; r < 4; ++r) {
         const int gy = y0 + 2 * mt + dyl, gx = x0 + dxl + r;
         float v = fmaf(acc[mt][nt][r], sc, sh);
-        if (a.relu) v = fmaxf(v, 0.f);
+        if (a.relu) v = tsr_relu(v);
         if (!(img_ok && gy < a.H && gx < a.W)) v = 0.f;
         acc[mt][nt][r] = v;
         amax = fmaxf(amax, fabsf(v));
@@ -67,7 +67,8 @@ __device__ __forceinline__ void conv_fuse1x1_epilogue16(const ConvArgs& a, f32x4
   __syncthreads();
   float tmax = 0.f;
 #pragma unroll
-  for (int w = 0; w < 2 * IMG; ++w) tmax = fmaxf(tmax, red[w]);
+  // (a wave whose image holds an Inf does not take part in the tile scale: the other images of the tile keep their result)
+  for (int w = 0; w < 2 * IMG; ++w) tmax = fmaxf(tmax, red[w] < 3.0e38f ? red[w] : 0.f);
   float s_e = 1.f;
   if (tmax > 0.f) {
     int e = (int)((__float_as_uint(tmax) >> 23) & 0xFF) - 127;
@@ -164,7 +165,7 @@ __device__ __forceinline__ void conv_fuse1x1_epilogue16(const ConvArgs& a, f32x4
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          if (a.relu2) v[c] = fmaxf(v[c], 0.f);
+          if (a.relu2) v[c] = tsr_relu(v[c]);
           omax = fmaxf(omax, fabsf(v[c]));
         }
         *(f32x4*)(ob4 + po) = v;

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_f32_kernel(const ConvArgs a)
           const f32x4 sc = *(const f32x4*)(a.in_scale + cq);
           const f32x4 sh = *(const f32x4*)(a.in_shift + cq);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) hv[k][j] = fmaxf(fmaf(hv[k][j], sc[j], sh[j]), 0.f);
+          for (int j = 0; j < 4; ++j) hv[k][j] = tsr_relu(fmaf(hv[k][j], sc[j], sh[j]));
         }
       }
     }

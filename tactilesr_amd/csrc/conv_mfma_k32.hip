@@ -154,6 +154,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
     }
     accmul = w_inv / sx;
   }
+  const float sxh = (EXT && a.in_scale) ? 0.5f * sx : sx;     // staging scale (virtual inputs arrive as 2 relu(.))
 
   int bid;
   {
@@ -232,11 +233,13 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
           const f32x4 sc = *(const f32x4*)(a.in_scale + cq);
           const f32x4 sh = *(const f32x4*)(a.in_shift + cq);
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) v[jj] = fmaxf(fmaf(v[jj], sc[jj], sh[jj]), 0.f);
+          for (int jj = 0; jj < 4; ++jj) v[jj] = tsr_relu_x2(fmaf(v[jj], sc[jj], sh[jj]));     // 2 relu(bn(z)); sxh = sx / 2
         }
-        const float mk = st_src[k] >= 0 ? sx : 0.f;       // zero padding outside the image
+        // zero padding outside the image: a SELECT, not a multiply by 0 -- the dummy element that was loaded for a padded
+        // slot may be NaN / Inf (another image's pixel) and must not leak into this image's border
+        const bool inside = st_src[k] >= 0;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) v[jj] *= mk;
+        for (int jj = 0; jj < 4; ++jj) v[jj] = inside ? v[jj] * sxh : 0.f;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
           kf16x4 bq;

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
           const f32x4 sc = *(const f32x4*)(a.in_scale + cq);
           const f32x4 sh = *(const f32x4*)(a.in_shift + cq);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), 0.f);
+          for (int j = 0; j < 4; ++j) v[j] = tsr_relu(fmaf(v[j], sc[j], sh[j]));
         }
         if (F16) {
 #pragma unroll

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ lr,
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float t = acc[px][4 * q + j] * scv[q][j] + shv[q][j];
-            v[j] = relu ? fmaxf(t, 0.f) : t;
+            v[j] = relu ? tsr_relu(t) : t;
             amax = fmaxf(amax, fabsf(v[j]));
           }
           if (OUT16) {
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ in,
   float v = (a0 + a1) + a2;
   v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // lane ^ 1
   v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // lane ^ 2
-  if (relu) v = fmaxf(v, 0.f);
+  if (relu) v = tsr_relu(v);
   if (live && q == 0) out[(size_t)b * HW + p] = v;
 }
 

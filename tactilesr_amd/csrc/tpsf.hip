@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict
       const int gi = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (gi < M) {
         float v = acc[r] + bv;
-        if (act == 1) v = fmaxf(v, 0.f);
+        if (act == 1) v = tsr_relu(v);
         else if (act == 2) v = v > 20.f ? v : log1pf(expf(v));
         C[(size_t)gi * N + gj] = v;
       }

@@ -30,10 +30,22 @@ static inline int tsr_check_launch() {
 // to (nearly) the tensor's maximum almost every later wave skips the atomic -- 100 k same-address atomics per
 // launch otherwise serialize at ~10 ns each in the L2 (measured: 0.8 ms on the 0.6 ms stem kernel).  A stale
 // (smaller) cached value only costs a redundant atomic.
+// A non-finite wave maximum is NOT published (fmaxf already drops NaN; +Inf would turn the consumer's power-of-two
+// operand scale into ~0 for every image of the batch): images without non-finite values keep their exact results, the
+// image that holds the Inf / NaN stays non-finite through the planes of the split (Inf - Inf = NaN) -- frames are
+// independent in eval mode in the reference too (model/tactileSR_model.py:67-84), and a non-finite loss is what its
+// trainer raises on (cpu/trainer.py:280-284).
 __device__ __forceinline__ void publish_amax(float* slot, float amax) {
   const unsigned v = __float_as_uint(amax);
-  if (v > __builtin_nontemporal_load((const unsigned*)slot)) atomicMax((unsigned int*)slot, v);
+  if (v < 0x7f800000u && v > __builtin_nontemporal_load((const unsigned*)slot)) atomicMax((unsigned int*)slot, v);
 }
+
+// ReLU that PROPAGATES NaN like torch's relu / clamp_min (fmaxf / v_max_f32 return the non-NaN operand and would turn a
+// NaN activation -- a diverged weight, a NaN taxel -- into 0, hiding it from the trainer's non-finite-loss check).
+__device__ __forceinline__ float tsr_relu(float v) { return v < 0.f ? 0.f : v; }
+// 2*relu(t) in one VALU instruction (v_add_f32 v, v, |v|), NaN-propagating; callers fold the factor 1/2 into the
+// power-of-two operand scale that multiplies the value next (staging loops of the split-operand kernels).
+__device__ __forceinline__ float tsr_relu_x2(float t) { return t + fabsf(t); }
 
 __device__ __forceinline__ size_t cb16_index(int b, int c, int pix, int C, int HW) {
   return (((size_t)b * (C >> 4) + (c >> 4)) * HW + pix) * 16 + (c & 15);

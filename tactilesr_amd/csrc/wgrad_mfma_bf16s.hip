@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_bf16s_kernel(const WgradBAr
 #pragma unroll
         for (int y = 0; y < 8; ++y) {
           col[y] = v0[y][j];
-          if (!r0_dz && g.a_scale && ((ok0 >> y) & 1)) col[y] = fmaxf(fmaf(col[y], sc0[j], sh0[j]), 0.f);
+          if (!r0_dz && g.a_scale && ((ok0 >> y) & 1)) col[y] = tsr_relu(fmaf(col[y], sc0[j], sh0[j]));
         }
         if (r0_dz && do_bias) {
 #pragma unroll
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_bf16s_kernel(const WgradBAr
 #pragma unroll
       for (int y = 0; y < 8; ++y) {
         col[y] = v1[y];
-        if (g.a_scale && ((ok1 >> y) & 1)) col[y] = fmaxf(fmaf(col[y], sc1, sh1), 0.f);
+        if (g.a_scale && ((ok1 >> y) & 1)) col[y] = tsr_relu(fmaf(col[y], sc1, sh1));
       }
       split_store8<NS, F16>(col, at + (r1_x * 64 + swz(r1_blk * 16 + r1_q * 4 + r1_j)) * 16, A_PLANE, s_a);
     }

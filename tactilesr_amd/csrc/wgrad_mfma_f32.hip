@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_mfma_f32_kernel(const WgradArgs 
                 const f32x4 sc = *(const f32x4*)(g.a_scale + cq);
                 const f32x4 sh = *(const f32x4*)(g.a_shift + cq);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), 0.f);
+                for (int j = 0; j < 4; ++j) v[j] = tsr_relu(fmaf(v[j], sc[j], sh[j]));
               }
               av[k] = v;
             }

@@ -167,6 +167,7 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
     s_a = tr16_pow2_scale(ma);
     s_d = tr16_pow2_scale(g.dz_amax ? *g.dz_amax : 0.f);
   }
+  const float s_ah = g.a_scale ? 0.5f * s_a : s_a;      // staging scale of the input operand (virtual inputs arrive as 2 relu(.))
 
   // (in the role-specialised form the accumulators must be live in the MFMA role's branch ONLY -- zeroed, used and
   // written out there -- or the register allocator keeps 160 of them alive through the staging role's loop)
@@ -298,9 +299,9 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
           const int cq = ((ldsa[j] / G::A_BLKB) * 16) + ((ldsa[j] >> 1) & 12);
           const f32x4 sc = *(const f32x4*)(tsc + cq), sh = *(const f32x4*)(tsc + CI + cq);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = fmaxf(fmaf(v[c], sc[c], sh[c]), 0.f);
+          for (int c = 0; c < 4; ++c) v[c] = tsr_relu_x2(fmaf(v[c], sc[c], sh[c]));      // 2 relu(.): s_ah = s_a / 2
         }
-        split_store(v, at + ldsa[j], G::A_PLANEB, ((oka >> j) & 1) ? s_a : 0.f);
+        split_store(v, at + ldsa[j], G::A_PLANEB, ((oka >> j) & 1) ? s_ah : 0.f);
       }
     }
   };
@@ -562,6 +563,7 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
     s_a = tr16_pow2_scale(ma);
     s_d = tr16_pow2_scale(g.dz_amax ? *g.dz_amax : 0.f);
   }
+  const float s_ah = g.a_scale ? 0.5f * s_a : s_a;      // staging scale of the input operand (virtual inputs arrive as 2 relu(.))
 
   f32x4 acc[MT][2][G::NTAP];
 #pragma unroll
@@ -680,9 +682,9 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
           const int cq = ((ldsa[j] / G::A_BLKB) * 16) + ((ldsa[j] >> 1) & 12);
           const f32x4 sc = *(const f32x4*)(tsc + cq), sh = *(const f32x4*)(tsc + CI + cq);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = fmaxf(fmaf(v[c], sc[c], sh[c]), 0.f);
+          for (int c = 0; c < 4; ++c) v[c] = tsr_relu_x2(fmaf(v[c], sc[c], sh[c]));      // 2 relu(.): s_ah = s_a / 2
         }
-        split_store(v, at + ldsa[j], G::A_PLANEB, ((oka >> j) & 1) ? s_a : 0.f);
+        split_store(v, at + ldsa[j], G::A_PLANEB, ((oka >> j) & 1) ? s_ah : 0.f);
       }
     }
   };

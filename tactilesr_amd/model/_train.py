@@ -230,18 +230,14 @@ class TrainEngine:
         return self._bn_finalize(c, conv.bias, bn, c.slab, c.slab_cnt, self._entries(c, cout, ks), cout)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x: torch.Tensor):
-        m = self.m
+    def _new_ctx(self, B, H, W, dev):
+        """Per-forward context: geometry + the statistics slabs / workspace every BatchNorm layer reuses."""
         c = _Ctx()
-        dev = x.device
-        B, hin, win = x.shape[0], x.shape[2], x.shape[3]
-        sf, T, A = m.scale_factor, m.seqsCnt, m.axisCnt
-        H, W = hin * sf, win * sf
         HW = H * W
-        c.B, c.H, c.W, c.HW, c.x, c.hin, c.win = B, H, W, HW, x, hin, win
+        c.B, c.H, c.W, c.HW = B, H, W, HW
         lib = _lib.load()
         c.entries = lib.tsr_conv2d_slab_entries(B, H, W)
-        st_entries = lib.tsr_cb16_stats_entries(B, HW)
+        c.st_entries = st_entries = lib.tsr_cb16_stats_entries(B, HW)
         # statistics slabs are indexed by (workgroup, image slot): the entry count depends on how many images the
         # kernel variant of (C_out, k, arithmetic) puts in a workgroup -- ask the library for every shape in use
         e64 = max(lib.tsr_conv2d_slab_entries_ex(B, H, W, 64, k, self.nsplit) for k in (1, 3, 5))
@@ -249,6 +245,59 @@ class TrainEngine:
         c.slab = torch.empty(max(e128 * 128 * 2, e64 * 64 * 2, st_entries * 64 * 2), dtype=torch.float32, device=dev)
         c.slab_cnt = torch.empty(max(e128, e64, st_entries), dtype=torch.float32, device=dev)
         c.work = torch.empty(512 * 128 * 3, dtype=torch.float64, device=dev)
+        return c
+
+    # ------------------------------------------------------------------ blocks (shared with the standalone modules)
+    def _msrb_fwd(self, c, blk, X: Act, out, octot, ocoff, am_o, new_amax, buf):
+        """One MSRB in train mode (reference model/tactileSR_model.py:196-206): X -> `out[ocoff:ocoff+64]`."""
+        dev = X.buf.device
+        s = _Ctx()
+        s.X = X
+        s.cat1, s.cat2 = buf(128), buf(256)
+        s.bn_c1 = torch.empty(4, 128, dtype=torch.float32, device=dev)
+        s.bn_c2 = torch.empty(4, 256, dtype=torch.float32, device=dev)
+        am_c1, am_c2 = new_amax(), new_amax()
+        s.bn_c1[:, 0:64] = self._conv_bn(c, X, blk.conv_3_1[0], blk.conv_3_1[1], s.cat1, 128, 0, am_c1)
+        s.bn_c1[:, 64:128] = self._conv_bn(c, X, blk.conv_5_1[0], blk.conv_5_1[1], s.cat1, 128, 64, am_c1)
+        A1 = Act(s.cat1, 128, 0, 128, s.bn_c1[0], s.bn_c1[1], s.bn_c1[2], s.bn_c1[3], amax=am_c1)
+        s.bn_c2[:, 0:128] = self._conv_bn(c, A1, blk.conv_3_2[0], blk.conv_3_2[1], s.cat2, 256, 0, am_c2)
+        s.bn_c2[:, 128:256] = self._conv_bn(c, A1, blk.conv_5_2[0], blk.conv_5_2[1], s.cat2, 256, 128, am_c2)
+        A2 = Act(s.cat2, 256, 0, 256, s.bn_c2[0], s.bn_c2[1], s.bn_c2[2], s.bn_c2[3], amax=am_c2)
+        s.A1, s.A2 = A1, A2
+        wp, wis = self._packw(c, blk.confusion)
+        conv_ex(B=c.B, H=c.H, W=c.W, src=A2, w=wp, cout=64, ks=1, out=out, out_ctot=octot, out_coff=ocoff,
+                shift=blk.confusion.bias.detach(), relu=1, res=X, nsplit=self.nsplit, w_amax=wis,
+                out_amax=am_o)
+        s.Y = Act(out, octot, ocoff, 64, amax=am_o)
+        return s
+
+    def _res_fwd(self, c, rb, F0: Act, out, octot, ocoff, am_o, new_amax, buf):
+        """One ResBlock (reference model/tactileSR_model.py:222-225): relu(x + conv2(relu(conv1(x))))."""
+        s = _Ctx()
+        s.X = F0
+        s.f1 = buf(64)
+        s.F1 = Act(s.f1, 64, 0, 64, amax=new_amax())
+        w1, wis1 = self._packw(c, rb.conv1)
+        conv_ex(B=c.B, H=c.H, W=c.W, src=F0, w=w1, cout=64, ks=3, out=s.f1, out_ctot=64, out_coff=0,
+                shift=rb.conv1.bias.detach(), relu=1, nsplit=self.nsplit, w_amax=wis1, out_amax=s.F1.amax)
+        w2, wis2 = self._packw(c, rb.conv2)
+        conv_ex(B=c.B, H=c.H, W=c.W, src=s.F1, w=w2, cout=64, ks=3, out=out, out_ctot=octot,
+                out_coff=ocoff, shift=rb.conv2.bias.detach(), relu=1, res=F0, nsplit=self.nsplit,
+                w_amax=wis2, out_amax=am_o)
+        s.Y = Act(out, octot, ocoff, 64, amax=am_o)
+        return s
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor):
+        m = self.m
+        dev = x.device
+        B, hin, win = x.shape[0], x.shape[2], x.shape[3]
+        sf, T, A = m.scale_factor, m.seqsCnt, m.axisCnt
+        H, W = hin * sf, win * sf
+        HW = H * W
+        c = self._new_ctx(B, H, W, dev)
+        c.x, c.hin, c.win = x, hin, win
+        st_entries = c.st_entries
 
         def buf(ch):
             return torch.empty(B * ch * HW, dtype=torch.float32, device=dev)
@@ -287,29 +336,12 @@ class TrainEngine:
         c.blocks = []
         n_msrb = len(m.patternFeatureExtra_layer)
         for i, blk in enumerate(m.patternFeatureExtra_layer):
-            s = _Ctx()
-            s.X = X
-            s.cat1, s.cat2 = buf(128), buf(256)
-            s.bn_c1 = torch.empty(4, 128, dtype=torch.float32, device=dev)
-            s.bn_c2 = torch.empty(4, 256, dtype=torch.float32, device=dev)
-            am_c1, am_c2 = new_amax(), new_amax()
-            s.bn_c1[:, 0:64] = self._conv_bn(c, X, blk.conv_3_1[0], blk.conv_3_1[1], s.cat1, 128, 0, am_c1)
-            s.bn_c1[:, 64:128] = self._conv_bn(c, X, blk.conv_5_1[0], blk.conv_5_1[1], s.cat1, 128, 64, am_c1)
-            A1 = Act(s.cat1, 128, 0, 128, s.bn_c1[0], s.bn_c1[1], s.bn_c1[2], s.bn_c1[3], amax=am_c1)
-            s.bn_c2[:, 0:128] = self._conv_bn(c, A1, blk.conv_3_2[0], blk.conv_3_2[1], s.cat2, 256, 0, am_c2)
-            s.bn_c2[:, 128:256] = self._conv_bn(c, A1, blk.conv_5_2[0], blk.conv_5_2[1], s.cat2, 256, 128, am_c2)
-            A2 = Act(s.cat2, 256, 0, 256, s.bn_c2[0], s.bn_c2[1], s.bn_c2[2], s.bn_c2[3], amax=am_c2)
-            s.A1, s.A2 = A1, A2
-            wp, wis = self._packw(c, blk.confusion)
             if i == n_msrb - 1:
                 out, octot, ocoff, am_o = c.hcat, 128, 64, c.am_hcat
             else:
                 out, octot, ocoff, am_o = buf(64), 64, 0, new_amax()
-            conv_ex(B=B, H=H, W=W, src=A2, w=wp, cout=64, ks=1, out=out, out_ctot=octot, out_coff=ocoff,
-                    shift=blk.confusion.bias.detach(), relu=1, res=X, nsplit=self.nsplit, w_amax=wis,
-                    out_amax=am_o)
-            X = Act(out, octot, ocoff, 64, amax=am_o)
-            s.Y = X
+            s = self._msrb_fwd(c, blk, X, out, octot, ocoff, am_o, new_amax, buf)
+            X = s.Y
             c.blocks.append(s)
         if n_msrb == 0:
             raise _lib.TactileSRHipError("train path needs patternFeatureExtraLayerCnt >= 1")
@@ -325,23 +357,12 @@ class TrainEngine:
         if n_res == 0:
             raise _lib.TactileSRHipError("train path needs forceFeatureExtraLayerCnt >= 1")
         for i, rb in enumerate(m.forceFeatureExtra_layer):
-            s = _Ctx()
-            s.X = F0
-            s.f1 = buf(64)
-            s.F1 = Act(s.f1, 64, 0, 64, amax=new_amax())
-            w1, wis1 = self._packw(c, rb.conv1)
-            conv_ex(B=B, H=H, W=W, src=F0, w=w1, cout=64, ks=3, out=s.f1, out_ctot=64, out_coff=0,
-                    shift=rb.conv1.bias.detach(), relu=1, nsplit=self.nsplit, w_amax=wis1, out_amax=s.F1.amax)
-            w2, wis2 = self._packw(c, rb.conv2)
             if i == n_res - 1:
                 out, octot, ocoff, am_o = c.hcat, 128, 0, c.am_hcat
             else:
                 out, octot, ocoff, am_o = buf(64), 64, 0, new_amax()
-            conv_ex(B=B, H=H, W=W, src=s.F1, w=w2, cout=64, ks=3, out=out, out_ctot=octot,
-                    out_coff=ocoff, shift=rb.conv2.bias.detach(), relu=1, res=F0, nsplit=self.nsplit,
-                    w_amax=wis2, out_amax=am_o)
-            F0 = Act(out, octot, ocoff, 64, amax=am_o)
-            s.Y = F0
+            s = self._res_fwd(c, rb, F0, out, octot, ocoff, am_o, new_amax, buf)
+            F0 = s.Y
             c.res.append(s)
         # ---- head
         c.h0 = buf(128)
@@ -462,6 +483,70 @@ class TrainEngine:
              ptr(out[2]), ptr(out[3]), ptr(out[4]), _I(C), _I(c.B), _I(c.HW), ptr(out_amax), stream())
         return out   # rows 0,1 = dgamma, dbeta
 
+    def _res_bwd(self, c, s, rb, name, dpre: Act, grads, new_amax, buf, mask_input=True):
+        """Backward of one ResBlock.  `dpre` = gradient w.r.t. the block output BEFORE its ReLU; returns the gradient
+        w.r.t. the block input -- masked by the input's own ReLU pattern (`mask_input`, the chained engine: the input is
+        the previous block's post-ReLU output) or plain (standalone module)."""
+        name = name + "." if name else ""          # (standalone module: parameter names carry no prefix)
+        F1 = s.F1
+        self._wgrad(c, F1, dpre, rb.conv2, grads, name + "conv2", True)
+        d1 = buf(64)
+        D1 = Act(d1, 64, 0, 64, amax=new_amax())
+        self._dgrad(c, dpre, rb.conv2, 0, 64, d1, 64, 0, mask=F1, out_amax=D1.amax)
+        self._wgrad(c, s.X, D1, rb.conv1, grads, name + "conv1", True)
+        d0 = buf(64)
+        am = new_amax()
+        self._dgrad(c, D1, rb.conv1, 0, 64, d0, 64, 0, res=dpre, mask=s.X if mask_input else None, out_amax=am)
+        return Act(d0, 64, 0, 64, amax=am)
+
+    def _msrb_bwd(self, c, s, blk, name, dpre: Act, grads, new_amax, buf, tag="msrb", mask_input=True):
+        """Backward of one MSRB.  `dpre` = gradient w.r.t. the block output BEFORE its ReLU; returns the gradient w.r.t.
+        the block input: masked by the input's ReLU pattern / with the BatchNorm-backward sums of a virtual input
+        (`mask_input`, the chained engine) or plain (standalone module)."""
+        name = name + "." if name else ""          # (standalone module: parameter names carry no prefix)
+        # confusion 1x1: a = relu(bn(cat2)), dz = dpre
+        self._wgrad(c, s.A2, dpre, blk.confusion, grads, name + "confusion", True)
+        g2 = buf(256)
+        am_g2 = [new_amax(), new_amax()]
+        for half, (cv, bnm, nm) in enumerate(((blk.conv_3_2[0], blk.conv_3_2[1], "conv_3_2"),
+                                              (blk.conv_5_2[0], blk.conv_5_2[1], "conv_5_2"))):
+            o = 128 * half
+            mk = Act(s.cat2, 256, o, 128, s.bn_c2[0, o:o + 128], s.bn_c2[1, o:o + 128], s.bn_c2[2, o:o + 128],
+                     s.bn_c2[3, o:o + 128])
+            self._dgrad(c, dpre, blk.confusion, o, 128, g2, 256, o, mask=mk, bn=True)
+            r = self._bn_bwd(c, g2, 256, o, Act(s.cat2, 256, 0, 256), o, 128, s.bn_c2[:, o:o + 128], bnm, grads,
+                             nm, out_amax=am_g2[half])
+            grads.put_copy(f"{name}{nm}.1.weight", r[0])
+            grads.put_copy(f"{name}{nm}.1.bias", r[1])
+        if self.debug is not None:
+            self.debug[f"{tag}.dz2"] = g2.clone()
+        DZ32, DZ52 = Act(g2, 256, 0, 128, amax=am_g2[0]), Act(g2, 256, 128, 128, amax=am_g2[1])
+        self._wgrad(c, s.A1, DZ32, blk.conv_3_2[0], grads, f"{name}conv_3_2.0", True)
+        self._wgrad(c, s.A1, DZ52, blk.conv_5_2[0], grads, f"{name}conv_5_2.0", True)
+        g1 = buf(128)
+        self._dgrad(c, DZ32, blk.conv_3_2[0], 0, 128, g1, 128, 0)
+        mk = Act(s.cat1, 128, 0, 128, s.bn_c1[0], s.bn_c1[1], s.bn_c1[2], s.bn_c1[3])
+        self._dgrad(c, DZ52, blk.conv_5_2[0], 0, 128, g1, 128, 0, res=Act(g1, 128, 0, 128), mask=mk, bn=True)
+        am_g1 = new_amax()
+        r = self._bn_bwd(c, g1, 128, 0, Act(s.cat1, 128, 0, 128), 0, 128, s.bn_c1, None, grads, "", out_amax=am_g1)
+        grads.put_copy(f"{name}conv_3_1.1.weight", r[0, :64])
+        grads.put_copy(f"{name}conv_3_1.1.bias", r[1, :64])
+        grads.put_copy(f"{name}conv_5_1.1.weight", r[0, 64:])
+        grads.put_copy(f"{name}conv_5_1.1.bias", r[1, 64:])
+        del g2
+        if self.debug is not None:
+            self.debug[f"{tag}.dz1"] = g1.clone()
+        DZ31, DZ51 = Act(g1, 128, 0, 64, amax=am_g1), Act(g1, 128, 64, 64, amax=am_g1)
+        self._wgrad(c, s.X, DZ31, blk.conv_3_1[0], grads, f"{name}conv_3_1.0", True)
+        self._wgrad(c, s.X, DZ51, blk.conv_5_1[0], grads, f"{name}conv_5_1.0", True)
+        dx = buf(64)
+        self._dgrad(c, DZ31, blk.conv_3_1[0], 0, 64, dx, 64, 0, res=dpre)
+        virtual = mask_input and s.X.scale is not None
+        am = new_amax()
+        self._dgrad(c, DZ51, blk.conv_5_1[0], 0, 64, dx, 64, 0, res=Act(dx, 64, 0, 64),
+                    mask=s.X if mask_input else None, bn=virtual, out_amax=None if virtual else am)
+        return Act(dx, 64, 0, 64, amax=am)
+
     # ------------------------------------------------------------------ backward
     def backward(self, c: _Ctx, dout: torch.Tensor):
         m = self.m
@@ -500,18 +585,8 @@ class TrainEngine:
         # ---- force branch (ResBlocks, reversed); gradient w.r.t. block output pre-ReLU in `dpre`
         dpre = Act(g_hcat, 128, 0, 64, amax=am_ghcat)
         for i in reversed(range(len(c.res))):
-            s, rb = c.res[i], m.forceFeatureExtra_layer[i]
-            name = f"forceFeatureExtra_layer.{i}"
-            F1 = s.F1
-            self._wgrad(c, F1, dpre, rb.conv2, grads, name + ".conv2", True)
-            d1 = buf(64)
-            D1 = Act(d1, 64, 0, 64, amax=new_amax())
-            self._dgrad(c, dpre, rb.conv2, 0, 64, d1, 64, 0, mask=F1, out_amax=D1.amax)
-            self._wgrad(c, s.X, D1, rb.conv1, grads, name + ".conv1", True)
-            d0 = buf(64)
-            am = new_amax()
-            self._dgrad(c, D1, rb.conv1, 0, 64, d0, 64, 0, res=dpre, mask=s.X, out_amax=am)
-            dpre = Act(d0, 64, 0, 64, amax=am)
+            dpre = self._res_bwd(c, c.res[i], m.forceFeatureExtra_layer[i], f"forceFeatureExtra_layer.{i}", dpre, grads,
+                                 new_amax, buf)
         ns = max(1, min(B, 2048))     # image splits: ~8 resident workgroups per CU hide the load latency
         sslab = torch.empty(ns * 64 * 27, dtype=torch.float32, device=dev)
         call("tsr_stem_wgrad", ptr(c.x), _I(c.x.shape[1]), _I(0), _I(c.hin), _I(c.win), _I(m.scale_factor),
@@ -523,51 +598,8 @@ class TrainEngine:
         # ---- pattern branch: MSRB blocks reversed
         dpre = Act(g_hcat, 128, 64, 64, amax=am_ghcat)
         for i in reversed(range(len(c.blocks))):
-            s, blk = c.blocks[i], m.patternFeatureExtra_layer[i]
-            name = f"patternFeatureExtra_layer.{i}"
-            # confusion 1x1: a = relu(bn(cat2)), dz = dpre
-            self._wgrad(c, s.A2, dpre, blk.confusion, grads, name + ".confusion", True)
-            g2 = buf(256)
-            am_g2 = [new_amax(), new_amax()]
-            for half, (cv, bnm, nm) in enumerate(((blk.conv_3_2[0], blk.conv_3_2[1], "conv_3_2"),
-                                                  (blk.conv_5_2[0], blk.conv_5_2[1], "conv_5_2"))):
-                o = 128 * half
-                mk = Act(s.cat2, 256, o, 128, s.bn_c2[0, o:o + 128], s.bn_c2[1, o:o + 128], s.bn_c2[2, o:o + 128],
-                         s.bn_c2[3, o:o + 128])
-                self._dgrad(c, dpre, blk.confusion, o, 128, g2, 256, o, mask=mk, bn=True)
-                r = self._bn_bwd(c, g2, 256, o, Act(s.cat2, 256, 0, 256), o, 128, s.bn_c2[:, o:o + 128], bnm, grads,
-                                 nm, out_amax=am_g2[half])
-                grads.put_copy(f"{name}.{nm}.1.weight", r[0])
-                grads.put_copy(f"{name}.{nm}.1.bias", r[1])
-            if self.debug is not None:
-                self.debug[f"msrb{i}.dz2"] = g2.clone()
-            DZ32, DZ52 = Act(g2, 256, 0, 128, amax=am_g2[0]), Act(g2, 256, 128, 128, amax=am_g2[1])
-            self._wgrad(c, s.A1, DZ32, blk.conv_3_2[0], grads, f"{name}.conv_3_2.0", True)
-            self._wgrad(c, s.A1, DZ52, blk.conv_5_2[0], grads, f"{name}.conv_5_2.0", True)
-            g1 = buf(128)
-            self._dgrad(c, DZ32, blk.conv_3_2[0], 0, 128, g1, 128, 0)
-            mk = Act(s.cat1, 128, 0, 128, s.bn_c1[0], s.bn_c1[1], s.bn_c1[2], s.bn_c1[3])
-            self._dgrad(c, DZ52, blk.conv_5_2[0], 0, 128, g1, 128, 0, res=Act(g1, 128, 0, 128), mask=mk, bn=True)
-            am_g1 = new_amax()
-            r = self._bn_bwd(c, g1, 128, 0, Act(s.cat1, 128, 0, 128), 0, 128, s.bn_c1, None, grads, "", out_amax=am_g1)
-            grads.put_copy(f"{name}.conv_3_1.1.weight", r[0, :64])
-            grads.put_copy(f"{name}.conv_3_1.1.bias", r[1, :64])
-            grads.put_copy(f"{name}.conv_5_1.1.weight", r[0, 64:])
-            grads.put_copy(f"{name}.conv_5_1.1.bias", r[1, 64:])
-            del g2
-            if self.debug is not None:
-                self.debug[f"msrb{i}.dz1"] = g1.clone()
-            DZ31, DZ51 = Act(g1, 128, 0, 64, amax=am_g1), Act(g1, 128, 64, 64, amax=am_g1)
-            self._wgrad(c, s.X, DZ31, blk.conv_3_1[0], grads, f"{name}.conv_3_1.0", True)
-            self._wgrad(c, s.X, DZ51, blk.conv_5_1[0], grads, f"{name}.conv_5_1.0", True)
-            dx = buf(64)
-            self._dgrad(c, DZ31, blk.conv_3_1[0], 0, 64, dx, 64, 0, res=dpre)
-            virtual = s.X.scale is not None
-            am = new_amax()
-            self._dgrad(c, DZ51, blk.conv_5_1[0], 0, 64, dx, 64, 0, res=Act(dx, 64, 0, 64), mask=s.X, bn=virtual,
-                        out_amax=None if virtual else am)
-            dpre = Act(dx, 64, 0, 64, amax=am)
-            del g1
+            dpre = self._msrb_bwd(c, c.blocks[i], m.patternFeatureExtra_layer[i], f"patternFeatureExtra_layer.{i}", dpre,
+                                  grads, new_amax, buf, tag=f"msrb{i}")
         # X of block 0 is the fuse conv's relu(bn(zf)): finish its BN backward -> dzf
         r = self._bn_bwd(c, dpre.buf, 64, 0, Act(c.zf, 64, 0, 64), 0, 64, c.bnf, None, grads, "", out_amax=dpre.amax)
         grads.put_copy("inputContact_layer.1.weight", r[0])
@@ -624,3 +656,97 @@ class TactileSRTrainFn(torch.autograd.Function):
         if missing:
             raise _lib.TactileSRHipError(f"backward produced no gradient for {missing[:4]}...")
         return (None, None, None) + tuple(grads[n] for n in ctx.names)
+
+
+class BlockEngine(TrainEngine):
+    """Train-mode forward / backward of ONE standalone ``MSRB`` or ``ResBlock`` module on an NCHW tensor (reference
+    model/tactileSR_model.py:196-206,222-225 are callable modules): the same kernels and the same per-block code as the
+    whole-network engine, with NCHW <-> CB16 conversion at the boundary and the gradient w.r.t. the block input
+    returned unmasked."""
+
+    def __init__(self, block, kind: str):
+        super().__init__(None)
+        assert kind in ("msrb", "res")
+        self.block, self.kind = block, kind
+
+    def _mfma_convs(self):
+        b = self.block
+        if self.kind == "msrb":
+            return [b.conv_3_1[0], b.conv_5_1[0], b.conv_3_2[0], b.conv_5_2[0], b.confusion]
+        return [b.conv1, b.conv2]
+
+    def _amax_pool(self, c, dev):
+        pool = torch.zeros(64, dtype=torch.float32, device=dev) if self.f16 else None
+        state = [0]
+
+        def new():
+            if pool is None:
+                return None
+            i = state[0]
+            state[0] += 1
+            return pool[i:i + 1]
+        return new
+
+    def forward(self, x: torch.Tensor):
+        from .tactileSR_model import to_cb16, from_cb16
+        B, C, H, W = x.shape
+        dev = x.device
+        c = self._new_ctx(B, H, W, dev)
+        self._weight_scales(c)
+        new_amax = self._amax_pool(c, dev)
+
+        def buf(ch):
+            return torch.empty(B * ch * H * W, dtype=torch.float32, device=dev)
+
+        am_x = new_amax()
+        if am_x is not None:
+            am_x.copy_(x.abs().amax())          # device-side: the operand scale of the first convs
+        X = Act(to_cb16(x), 64, 0, 64, amax=am_x)
+        out, am_o = buf(64), new_amax()
+        fwd = self._msrb_fwd if self.kind == "msrb" else self._res_fwd
+        c.s = fwd(c, self.block, X, out, 64, 0, am_o, new_amax, buf)
+        self.last_ctx = c if self.keep_ctx else None
+        return from_cb16(out, B, 64, H, W), c
+
+    def backward(self, c: _Ctx, dout: torch.Tensor):
+        from ..ddp import GradSink
+        from .tactileSR_model import to_cb16, from_cb16
+        dev = dout.device
+        B, H, W = c.B, c.H, c.W
+        grads = GradSink(self, dict(self.block.named_parameters()), dev)
+        new_amax = self._amax_pool(c, dev)
+
+        def buf(ch):
+            return torch.empty(B * ch * H * W, dtype=torch.float32, device=dev)
+
+        # gradient w.r.t. the block output BEFORE its ReLU (in the whole-network engine the consumer's dgrad epilogue
+        # applies this mask; here it is one elementwise pass over the boundary tensor)
+        d = to_cb16(dout.contiguous().float()) * (c.s.Y.buf > 0)
+        am = new_amax()
+        if am is not None:
+            am.copy_(d.abs().amax())
+        dpre = Act(d, 64, 0, 64, amax=am)
+        if self.kind == "msrb":
+            dx = self._msrb_bwd(c, c.s, self.block, "", dpre, grads, new_amax, buf, mask_input=False)
+        else:
+            dx = self._res_bwd(c, c.s, self.block, "", dpre, grads, new_amax, buf, mask_input=False)
+        return from_cb16(dx.buf, B, 64, H, W), grads.finalize()
+
+
+class BlockTrainFn(torch.autograd.Function):
+    """y = block(x) for a standalone MSRB / ResBlock in train mode; gradients for x and the block's parameters."""
+
+    @staticmethod
+    def forward(ctx, engine: BlockEngine, names, x, *params):
+        out, c = engine.forward(x)
+        ctx.engine, ctx.c, ctx.names = engine, c, names
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dx, grads = ctx.engine.backward(ctx.c, dout)
+        ctx.c = None
+        missing = [n for n in ctx.names if n not in grads]
+        if missing:
+            raise _lib.TactileSRHipError(f"backward produced no gradient for {missing[:4]}...")
+        return (None, None, dx) + tuple(grads[n] for n in ctx.names)

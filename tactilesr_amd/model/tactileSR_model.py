@@ -38,9 +38,57 @@ def _reference_init(root: nn.Module) -> None:
             nn.init.constant_(m.bias, 0.1)
 
 
-class MSRB(nn.Module):
-    """Multi-scale residual block container (reference model/tactileSR_model.py:157-214):
+class _StandaloneBlock(nn.Module):
+    """Shared forward of the standalone ``MSRB`` / ``ResBlock`` modules (the whole-network engine of ``TactileSR`` runs
+    the same kernels on its own buffers): ``block(x)`` with x ``(B, 64, H, W)`` fp32 NCHW on a ROCm device.  Eval mode
+    runs the inference launches (fp16x3 by default: stage-1 pair kernel, fused 1x1) and returns a plain tensor; train
+    mode runs batch-statistics BatchNorm through ``model/_train.py`` and is differentiable (x and parameters)."""
+    _kind = ""
+    _profile = None
+
+    def _standalone_init(self):
+        import os
+        self.conv_impl = os.environ.get("TSR_CONV_IMPL", "fp16x3")
+        self._plan = self._plan_key = self._block_engine = None
+
+    def _param_key(self):
+        return (self.conv_impl, _lib.param_epoch()) + tuple((t.data_ptr(), t._version)
+                                                            for t in list(self.parameters()) + list(self.buffers()))
+
+    def _get_plan(self):
+        key = self._param_key()
+        if self._plan is None or key != self._plan_key:
+            self._plan, self._plan_key = self._build_plan(), key
+        return self._plan
+
+    def block_engine(self):
+        if self._block_engine is None:
+            from ._train import BlockEngine
+            self._block_engine = BlockEngine(self, self._kind)
+        return self._block_engine
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise _lib.TactileSRHipError(f"{type(self).__name__} (tactilesr_amd) runs on MI355X only: move the module and "
+                                         "its input to a ROCm device (no CPU fallback)")
+        assert x.dim() == 4 and x.shape[1] == 64, "MSRB / ResBlock take (B, 64, H, W) feature maps"
+        if self.conv_impl not in ("fp16x3", "bf16x6", "f32"):
+            raise _lib.TactileSRHipError(f"standalone {type(self).__name__}: conv_impl {self.conv_impl!r} is not available "
+                                         "(fp16x3, bf16x6, f32)")
+        if self.training:
+            from ._train import BlockTrainFn
+            named = list(self.named_parameters())
+            xin = x.float().contiguous()
+            return BlockTrainFn.apply(self.block_engine(), [n for n, _ in named], xin, *[p for _, p in named])
+        x = x.detach().float().contiguous()
+        with torch.no_grad():
+            return self._eval_forward(x)
+
+
+class MSRB(_StandaloneBlock):
+    """Multi-scale residual block (reference model/tactileSR_model.py:157-214):
     {3x3,5x5}@64 -> cat128 -> {3x3,5x5}@128 -> cat256 -> 1x1 -> +x -> ReLU."""
+    _kind = "msrb"
 
     def __init__(self, n_feats: int = 64):
         super().__init__()
@@ -51,21 +99,77 @@ class MSRB(nn.Module):
         self.confusion = nn.Conv2d(4 * n_feats, n_feats, 1, padding=0, stride=1)
         self.relu = nn.ReLU(inplace=True)
         _reference_init(self)
+        self._standalone_init()
 
-    def forward(self, x):  # pragma: no cover - the fused engine runs whole networks
-        raise _lib.TactileSRHipError("MSRB is executed by TactileSR's fused HIP engine, not standalone")
+    def _build_plan(self):
+        ns = CONV_IMPLS[self.conv_impl]
+        if ns == -2:
+            pair = _PackedPair(self.conv_3_1, self.conv_5_1)
+            halves = tuple(_PackedHalf(self.confusion.weight.detach()[:, o:o + 128], ns) for o in (0, 128))
+            return (pair, None, _PackedConv(self.conv_3_2[0], self.conv_3_2[1], ns, cin_perm=pair.perm),
+                    _PackedConv(self.conv_5_2[0], self.conv_5_2[1], ns, cin_perm=pair.perm),
+                    _PackedConv(self.confusion, None, ns), halves)
+        return (_PackedConv(self.conv_3_1[0], self.conv_3_1[1], ns), _PackedConv(self.conv_5_1[0], self.conv_5_1[1], ns),
+                _PackedConv(self.conv_3_2[0], self.conv_3_2[1], ns), _PackedConv(self.conv_5_2[0], self.conv_5_2[1], ns),
+                _PackedConv(self.confusion, None, ns), None)
+
+    def _eval_forward(self, x):
+        c31, c51, c32, c52, conf, halves = self._get_plan()
+        B, _, H, W = x.shape
+        dev = x.device
+        f16 = CONV_IMPLS[self.conv_impl] == -2
+        am = torch.zeros(4, dtype=torch.float32, device=dev) if f16 else None
+        s_x, s_c1, s_c2, s_o = (am[i:i + 1] for i in range(4)) if f16 else (None,) * 4
+        if f16:
+            s_x.copy_(x.abs().amax())
+        xa = to_cb16(x)
+        cat1 = torch.empty(B * 128 * H * W, dtype=torch.float32, device=dev)
+        out = torch.empty(B * 64 * H * W, dtype=torch.float32, device=dev)
+        if halves is not None:
+            p1 = torch.empty_like(out)
+            TactileSR._conv_pair(self, c31, xa, cat1, B, H, W, s_x, s_c1)
+            TactileSR._conv_fused(self, c32, halves[0], conf.shift, cat1, p1, 64, 0, xa, 64, 0, False, None, s_c1, B, H, W)
+            TactileSR._conv_fused(self, c52, halves[1], None, cat1, out, 64, 0, p1, 64, 0, True, s_o, s_c1, B, H, W)
+        else:
+            cat2 = torch.empty(B * 256 * H * W, dtype=torch.float32, device=dev)
+            TactileSR._conv(self, c31, xa, 64, 0, cat1, 128, 0, True, B, H, W, amax_in=s_x, amax_out=s_c1)
+            TactileSR._conv(self, c51, xa, 64, 0, cat1, 128, 64, True, B, H, W, amax_in=s_x, amax_out=s_c1)
+            TactileSR._conv(self, c32, cat1, 128, 0, cat2, 256, 0, True, B, H, W, amax_in=s_c1, amax_out=s_c2)
+            TactileSR._conv(self, c52, cat1, 128, 0, cat2, 256, 128, True, B, H, W, amax_in=s_c1, amax_out=s_c2)
+            TactileSR._conv(self, conf, cat2, 256, 0, out, 64, 0, True, B, H, W, res=xa, r_ctot=64, r_coff=0,
+                            amax_in=s_c2, amax_out=s_o)
+        return from_cb16(out, B, 64, H, W)
 
 
-class ResBlock(nn.Module):
-    """relu(x + conv2(relu(conv1(x)))) container (reference model/tactileSR_model.py:216-225)."""
+class ResBlock(_StandaloneBlock):
+    """relu(x + conv2(relu(conv1(x)))) (reference model/tactileSR_model.py:216-225)."""
+    _kind = "res"
 
     def __init__(self, n_feats: int = 64):
         super().__init__()
         self.conv1 = nn.Conv2d(n_feats, n_feats, kernel_size=3, padding=1)
         self.conv2 = nn.Conv2d(n_feats, n_feats, kernel_size=3, padding=1)
+        self._standalone_init()
 
-    def forward(self, x):  # pragma: no cover
-        raise _lib.TactileSRHipError("ResBlock is executed by TactileSR's fused HIP engine, not standalone")
+    def _build_plan(self):
+        ns = CONV_IMPLS[self.conv_impl]
+        return _PackedConv(self.conv1, None, ns), _PackedConv(self.conv2, None, ns)
+
+    def _eval_forward(self, x):
+        c1, c2 = self._get_plan()
+        B, _, H, W = x.shape
+        dev = x.device
+        f16 = CONV_IMPLS[self.conv_impl] == -2
+        am = torch.zeros(3, dtype=torch.float32, device=dev) if f16 else None
+        s_x, s_1, s_o = (am[i:i + 1] for i in range(3)) if f16 else (None,) * 3
+        if f16:
+            s_x.copy_(x.abs().amax())
+        xa = to_cb16(x)
+        f1, out = torch.empty_like(xa), torch.empty_like(xa)
+        TactileSR._conv(self, c1, xa, 64, 0, f1, 64, 0, True, B, H, W, amax_in=s_x, amax_out=s_1)
+        TactileSR._conv(self, c2, f1, 64, 0, out, 64, 0, True, B, H, W, res=xa, r_ctot=64, r_coff=0, amax_in=s_1,
+                        amax_out=s_o)
+        return from_cb16(out, B, 64, H, W)
 
 
 CONV_IMPLS = {"f32": 0, "bf16x6": 3, "bf16x3": 2, "bf16": 1, "fp16x3": -2}   # name -> split planes (0 = fp32 MFMA,
@@ -245,6 +349,15 @@ class TactileSR(nn.Module):
         """Pack weights / fold eval-mode BN once per parameter version."""
         plan: Dict[str, object] = {}
         ns = CONV_IMPLS[self.conv_impl]
+        if self.head_impl is not None and self.head_impl not in CONV_IMPLS:
+            raise _lib.TactileSRHipError(f"head_impl {self.head_impl!r}: expected one of {sorted(CONV_IMPLS)}")
+        if self.conv_impl == "bf16" and self.head_impl not in (None, "bf16"):
+            # the bf16-storage path hands bf16 CB16 buffers (half the bytes) to every kernel: an fp32-activation kernel
+            # for output_layer.0 would read past them
+            raise _lib.TactileSRHipError("head_impl cannot be combined with conv_impl='bf16' (bf16 activation storage): "
+                                         "every launch of that path reads and writes bf16 tensors")
+        if self.conv_impl != "bf16" and self.head_impl == "bf16":
+            raise _lib.TactileSRHipError("head_impl='bf16' needs conv_impl='bf16' (it reads bf16 activation tensors)")
         stems = []
         for seq in self.inputLayer_pattern_list:
             s1, sh1 = _fold(None, seq[2], 64, seq[1].weight.device)

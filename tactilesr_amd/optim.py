@@ -33,14 +33,16 @@ class Adam(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._tables = {}           # key -> (device table, n_chunks, tensors kept alive)
+        self._tables = {}           # key -> (device table, n_chunks, the tensors the table points into)
         self.launches = 0           # kernel launches issued so far (tests: one per step)
+        self.table_builds = 0       # device tables built so far (steady state with the gradient arena: exactly one)
 
     def _table(self, items):
-        key = tuple((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), p.numel()) for p, g, st in items)
+        key = tuple((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+                    for p, g, st in items)
         hit = self._tables.get(key)
         if hit is not None:
-            return hit
+            return hit[:2]
         recs = []
         for p, g, st in items:
             n = p.numel()
@@ -53,8 +55,12 @@ class Adam(torch.optim.Optimizer):
         dev = host.to(items[0][0].device)
         if len(self._tables) > 8:
             self._tables.clear()
-        self._tables[key] = (dev, len(recs))
-        return self._tables[key]
+        # the cached table holds raw device addresses: keep every tensor it points into alive with it, so that an address
+        # in the key can never be recycled for another tensor while the entry exists
+        keep = [t for p, g, st in items for t in (p, g, st["exp_avg"], st["exp_avg_sq"])]
+        self._tables[key] = (dev, len(recs), keep)
+        self.table_builds += 1
+        return self._tables[key][:2]
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -98,6 +98,12 @@ class LRWarmupScheduler:
 
     # ------------------------------------------------------------------ helpers
     @property
+    def _is_plateau(self) -> bool:
+        """Read by the reference's LRUpdateHook.after_epoch on every epoch (cpu/hooks/lr_update_hook.py:33;
+        the reference class exposes it as a property too, cpu/lr_scheduler.py:93-95)."""
+        return self._plateau
+
+    @property
     def _groups(self):
         # looked up on every use: optimizer.load_state_dict() replaces the param_group dicts
         return self.torch_scheduler.optimizer.param_groups

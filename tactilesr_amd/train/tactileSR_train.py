@@ -36,15 +36,26 @@ def train_cal_loss(model, batch, config):
     return loss, {"total_loss": loss}
 
 
-def train_one_iter(model, optimizer, batch, config, grad_sync=None):
+def train_one_iter(model, optimizer, batch, config, grad_sync=None, check_finite=False, cur_iter=None):
     """zero_grad -> backward -> step, the order of cpu/trainer.py:352-361.  ``grad_sync`` (optional)
-    is called between backward and step (data-parallel gradient averaging: tactilesr_amd.ddp)."""
+    is called between backward and step (data-parallel gradient averaging: tactilesr_amd.ddp).
+
+    ``check_finite=True`` reproduces the reference trainer's per-iteration failure check
+    (``Trainer._log_iter_metrics``, cpu/trainer.py:259,280-284): the loss is read back (a host sync, like the
+    reference's ``loss.detach().cpu().item()``) and a NaN / Inf raises ``FloatingPointError`` with the reference's
+    message.  Off by default so that a step enqueues without a device round trip."""
     losses, loss_dict = train_cal_loss(model, batch, config)
     optimizer.zero_grad()
     losses.backward()
     if grad_sync is not None:
         grad_sync()
     optimizer.step()
+    if check_finite:
+        import math
+        value = float(losses.detach())
+        if not math.isfinite(value):
+            raise FloatingPointError(f"Loss became infinite or NaN at iteration={cur_iter}! "
+                                     f"loss_dict={ {k: float(v.detach()) for k, v in loss_dict.items()} }.")
     return loss_dict
 
 

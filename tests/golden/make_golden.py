@@ -150,6 +150,49 @@ def gen_eval():
     np.savez_compressed(os.path.join(HERE, "eval.npz"), **out)
 
 
+def gen_eval_init():
+    """configs[4] shape (scale_factor=25, seqsCnt=8) with the reference's OWN parameters: `_init_network` under
+    torch.manual_seed(42) (model/tactileSR_model.py:92-98; config/default.py:10), BatchNorm running statistics moved
+    off (0, 1) by two train-mode passes of the reference itself, then an eval forward in fp32 and fp64.  The fixture
+    stores the input, the moved running statistics (the weights are reproduced from the seed on the test side: the
+    drop-in's constructor is bit-identical, tests/test_host_cpu.py) and the outputs.  Same for the shipped shape
+    (sf=10, T=1) as `init_t1`."""
+    out = {}
+    for tag, cfg, B in (("init_sf25t8", dict(scale_factor=25, seqsCnt=8), 2), ("init_t1", dict(), 4)):
+        torch.manual_seed(42)
+        m = TactileSR(**cfg)
+        T, sf = cfg.get("seqsCnt", 1), cfg.get("scale_factor", 10)
+        out[f"{tag}/sha256_init"] = np.array(sd_hash(m.state_dict()))
+        g = torch.Generator().manual_seed(4242)
+        m.train()
+        with torch.no_grad():
+            for _ in range(2):
+                m(torch.rand(B, 3 * T, 4, 4, generator=g) * 8)
+        m.eval()
+        sd = m.state_dict()
+        for k, v in sd.items():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                out[f"{tag}/stat/{k}"] = v.numpy().copy()
+        LR = torch.rand(B, 3 * T, 4, 4, generator=g) * 8
+        stages = {}
+        hs = stage_hooks(m, stages)
+        with torch.no_grad():
+            y = m(LR)
+        for h in hs:
+            h.remove()
+        with torch.no_grad():
+            y64 = m.double()(LR.double())
+        m.float()
+        out[f"{tag}/ref32_vs_f64"] = np.float64(((y.double() - y64).abs().max() / y64.abs().max()).item())
+        out[f"{tag}/LR"] = LR.numpy()
+        out[f"{tag}/out"] = y.numpy()
+        out[f"{tag}/out64"] = y64.numpy()
+        for name, t in stages.items():
+            flat(f"{tag}/stage/{name}", probe(t), out)
+        print(tag, "out", tuple(y.shape), float(y.abs().max()), "ref32_vs_f64", out[f"{tag}/ref32_vs_f64"])
+    np.savez_compressed(os.path.join(HERE, "eval_init.npz"), **out)
+
+
 def gen_train():
     """F3: train-mode fwd + bwd + one Adam(L2) step with the reference's own step
     semantics (train/tactileSR_train.py:41-51, cpu/trainer.py:346-362)."""

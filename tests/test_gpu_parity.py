@@ -158,16 +158,148 @@ def test_model_eval_forward_vs_reference_golden(T, golden, tag, impl):
 
 
 @pytest.mark.parametrize("impl", ["fp16x3", "f32", "bf16x6"])
-def test_model_eval_forward_sf25_T8_documented_exception(T, golden, impl):
-    """DOCUMENTED EXCEPTION.  The configs[4] parametrisation (scale_factor=25, seqsCnt=8; not a
-    shipped reference config) with this fixture's randomised BN gains makes the final 128->1 conv cancellation-heavy:
-    the reference's OWN fp32 CPU run is 5.2e-6 of the output max away from its fp64 run, so two faithful fp32
-    evaluations can differ by more than north_star's 1e-5 here.  Every stage tensor still meets 1e-5 (checked inside
-    _golden_eval); the final image is measured at 0.8-1.4e-5 for all three arithmetics, the strict fp32-MFMA fma chain
-    included (r02: fp16x3 1.03e-5 / 0.83e-5, f32 1.03e-5 / 0.94e-5, bf16x6 1.32e-5 / 1.41e-5 vs ref32 / vs fp64).
-    The bar is a stated 1.5e-5, not derived from the fixture."""
-    e32, e64 = _golden_eval(T, golden, "sf25t8", impl)
-    assert e32 < 1.5e-5 and e64 < 1.5e-5
+def test_model_eval_forward_sf25_T8_randomised_fixture_relative_bar(T, golden, impl):
+    """The configs[4] parametrisation (scale_factor=25, seqsCnt=8) with RANDOMISED BatchNorm gains (tests/golden/eval.npz
+    `sf25t8`): the final 128->1 conv is cancellation-heavy there -- the reference's OWN fp32 CPU run is `ref32_vs_f64`
+    = 5.2e-6 of the output max away from its fp64 run, so two faithful fp32 evaluations can differ by more than 1e-5.
+    Every stage tensor still meets the flat 1e-5 (checked inside _golden_eval).  The final image is held to bars that
+    come from the FIXTURE's conditioning, not from a measurement of this build:
+      * strict fp32-MFMA path: within 2 x ref32_vs_f64 of the fp64 run (as close to exact arithmetic as twice the
+        reference's own fp32 distance) and, by the triangle inequality, within 3 x of the reference's fp32 run;
+      * fp16x3 (default) and bf16x6 (cross-check): no further from either reference run than the strict fp32 path
+        measured in the same process, + 1e-6 (fp16x3) / + 5e-6 (bf16x6) -- the split paths can never drift away from
+        fp32-MFMA arithmetic unnoticed.
+    The well-conditioned configs[4] fixture (the reference's own seed-42 parameters) is held to the flat 1e-5 in
+    test_model_eval_forward_reference_init_fixture."""
+    g = golden("eval")
+    yard = float(g["sf25t8/ref32_vs_f64"])
+    e32_f, e64_f = _golden_eval(T, golden, "sf25t8", "f32")
+    assert e64_f <= 2 * yard and e32_f <= 3 * yard, (e32_f, e64_f, yard)
+    if impl != "f32":
+        slack = 1e-6 if impl == "fp16x3" else 5e-6
+        e32, e64 = _golden_eval(T, golden, "sf25t8", impl)
+        assert e32 <= e32_f + slack and e64 <= e64_f + slack, (impl, e32, e64, e32_f, e64_f)
+
+
+INIT_CFG = {"init_t1": dict(), "init_sf25t8": dict(scale_factor=25, seqsCnt=8)}
+
+
+def _init_fixture_model(T, g, tag):
+    """The reference's own parameters: seed-42 construction (bit-identical to the reference's, tests/test_host_cpu.py and
+    the sha256 below) + the BatchNorm running statistics its two train-mode passes produced (tests/golden/eval_init.npz)."""
+    import hashlib
+    torch.manual_seed(42)
+    m = T.TactileSR(**INIT_CFG[tag])
+    h = hashlib.sha256()
+    sd = m.state_dict()
+    for k in sd:
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().numpy().tobytes())
+    assert h.hexdigest() == str(g[f"{tag}/sha256_init"])
+    sd = {k: (torch.from_numpy(g[f"{tag}/stat/{k}"]) if f"{tag}/stat/{k}" in g.files else v.clone()) for k, v in sd.items()}
+    m.load_state_dict(sd, strict=True)
+    return m, sd
+
+
+@pytest.mark.parametrize("impl", ["fp16x3", "f32", "bf16x6"])
+@pytest.mark.parametrize("tag", ["init_t1", "init_sf25t8"])
+def test_model_eval_forward_reference_init_fixture(T, golden, tag, impl):
+    """configs[4] shape (sf=25, T=8; and the shipped sf=10, T=1) with the REFERENCE'S OWN parameters -- `_init_network`
+    under seed 42 (model/tactileSR_model.py:92-98), running statistics moved by two train-mode passes of the reference
+    -- flat 1e-5 per stage and on the final image, against the reference's fp32 output and its fp64 run."""
+    g = golden("eval_init")
+    m, _ = _init_fixture_model(T, g, tag)
+    m = m.cuda().eval()
+    m.conv_impl = impl
+    y, stages = m.forward_with_stages(torch.from_numpy(g[f"{tag}/LR"]).cuda())
+    for name, t in stages.items():
+        assert relerr(probe(t), torch.from_numpy(g[f"{tag}/stage/{name}/probe"])) < TOL, name
+    e32, e64 = relerr(y, torch.from_numpy(g[f"{tag}/out"])), relerr(y, torch.from_numpy(g[f"{tag}/out64"]))
+    print(f"[parity {impl}] {tag}: hip-vs-ref32 {e32:.2e}  hip-vs-f64 {e64:.2e}  ref32-vs-f64 {float(g[f'{tag}/ref32_vs_f64']):.2e}")
+    assert e32 < TOL and e64 < TOL
+
+
+@pytest.mark.parametrize("impl", ["fp16x3", "f32", "bf16x6"])
+def test_batch4096_distinct_frames_wide_amplitude_per_frame_error(T, golden, impl):
+    """B = 4096 with 256 DISTINCT frames whose taxel amplitudes span 2^8 (frame k: rand * 8 * 2^-(k mod 9)), tiled 16x,
+    loud and quiet frames side by side in the same workgroups.  The fp16x3 operand scale is a tensor-wide max|x|, so a
+    quiet frame shares its scale with a loud one: the error is measured PER FRAME against the CPU oracle (fp32 and
+    fp64 runs) on the 256 distinct frames -- the whole-tensor max-norm of the other tests is blind to a quiet frame.
+      * quiet classes (amplitude <= 2^-5, 113 frames): 1e-5 relative to the frame's OWN output maximum;
+      * every frame: 1e-5 relative to max(own maximum, half the median frame maximum).  The floor is there because the
+        absolute error of a faithful fp32 evaluation is uniform over the frames (it is set by the magnitude of the
+        128 x 9 terms the last conv sums, not by their sum), while a few LOUD frames end in a final ReLU that cancels
+        their output to 2-40 % of the usual magnitude (five to all zeros): relative to such a frame's own maximum the
+        ORACLE's fp32 run is itself 4e-5 away from its fp64 run (frame 27).  The unfloored figure is printed;
+      * frames whose reference output is all zero: absolute error <= 1e-5 of the batch maximum."""
+    g = golden("eval_init")
+    m, sd = _init_fixture_model(T, g, "init_t1")
+    m = m.cuda().eval()
+    m.conv_impl = impl
+    gen = torch.Generator().manual_seed(2024)
+    base = torch.rand(256, 3, 4, 4, generator=gen) * 8
+    cls = torch.arange(256) % 9
+    base = base * (2.0 ** -cls.float()).view(-1, 1, 1, 1)
+    amp = base.abs().amax(dim=(1, 2, 3))
+    assert float(amp.max() / amp.min()) >= 2 ** 8 * 0.5
+    LR = base.repeat(16, 1, 1, 1)
+    assert LR.shape[0] == 4096
+    y = m(LR.cuda()).view(16, 256, 1, 40, 40)
+    assert torch.equal(y, y[:1].expand_as(y))
+    with torch.no_grad():
+        ref = O.tactilesr_forward(sd, base).double()
+        ref64 = O.tactilesr_forward({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, base.double())
+    got = y[0].cpu().double()
+    fmax = ref64.abs().amax(dim=(1, 2, 3))
+    live = fmax > 1e-3 * float(fmax.max())
+    a32, a64 = (got - ref).abs().amax(dim=(1, 2, 3)), (got - ref64).abs().amax(dim=(1, 2, 3))
+    own = fmax.clamp_min(1e-30)
+    floored = torch.maximum(fmax, 0.5 * fmax[live].median())
+    quiet = live & (cls >= 5)
+    print(f"[wide amplitude {impl}] {int(live.sum())} live frames, {int(quiet.sum())} quiet; per-frame error relative to the own "
+          f"maximum: quiet classes {float((a32 / own)[quiet].max()):.2e} (fp32 oracle) / {float((a64 / own)[quiet].max()):.2e} (fp64), "
+          f"all live frames {float((a32 / own)[live].max()):.2e} / {float((a64 / own)[live].max()):.2e} (oracle fp32 vs fp64: "
+          f"{float(((ref - ref64).abs().amax(dim=(1, 2, 3)) / own)[live].max()):.2e}); with the half-median floor "
+          f"{float((a32 / floored).max()):.2e} / {float((a64 / floored).max()):.2e}")
+    assert int(quiet.sum()) >= 100
+    assert float((a32 / own)[quiet].max()) < TOL and float((a64 / own)[quiet].max()) < TOL
+    assert float((a32 / floored).max()) < TOL and float((a64 / floored).max()) < TOL
+    assert float(a32[~live].max() if (~live).any() else 0.0) <= TOL * float(fmax.max())
+
+
+def test_non_finite_taxels_stay_in_their_frame_and_reach_the_loss(T, golden):
+    """A NaN taxel and an Inf taxel (reference: NaN / Inf propagate through conv, BN and torch's NaN-propagating ReLU
+    to the output of THEIR frame; frames are independent in eval mode, model/tactileSR_model.py:67-84; the trainer
+    raises FloatingPointError on the non-finite loss, cpu/trainer.py:280-284).  Here: the poisoned frames' outputs are
+    non-finite, every other frame of the batch -- including the ones sharing a workgroup with a poisoned frame -- still
+    meets 1e-5 against the oracle, and the MSE loss over the batch is non-finite.  (The kernels' ReLU is a select, not
+    v_max_f32; padding is a select, not a multiply by 0; non-finite maxima are kept out of the operand scales.)"""
+    from tactilesr_amd import functional as Fh
+    g = golden("eval_init")
+    m, sd = _init_fixture_model(T, g, "init_t1")
+    m = m.cuda().eval()
+    gen = torch.Generator().manual_seed(77)
+    LR = torch.rand(9, 3, 4, 4, generator=gen) * 8
+    with torch.no_grad():
+        ref_clean = O.tactilesr_forward(sd, LR)
+    bad = LR.clone()
+    bad[2, 1, 0, 0] = float("nan")          # frame 2 shares its workgroups with frame 3, frame 5 with frame 4
+    bad[5, 0, 3, 2] = float("inf")
+    bad[6, 2, 1, 1] = float("-inf")
+    for impl in ("fp16x3", "f32", "bf16"):
+        m.conv_impl = impl
+        y = m(bad.cuda()).cpu()
+        for b in (2, 5, 6):
+            assert not torch.isfinite(y[b]).all(), (impl, b)
+        ok = [0, 1, 3, 4, 7, 8]
+        assert torch.isfinite(y[ok]).all(), impl
+        assert relerr(y[ok], ref_clean[ok]) < (TOL if impl != "bf16" else 5e-2), impl
+        loss = Fh.mse_loss(y.cuda(), torch.zeros_like(y).cuda())
+        assert not torch.isfinite(loss), impl
+    # torch's own answer on the poisoned batch (what the reference computes): same frames non-finite
+    with torch.no_grad():
+        ref_bad = O.tactilesr_forward(sd, bad)
+    assert [bool(torch.isfinite(ref_bad[b]).all()) for b in range(9)] == [b not in (2, 5, 6) for b in range(9)]
 
 
 def test_model_eval_forward_vs_oracle_odd_batch(T):
@@ -408,6 +540,72 @@ def test_model_eval_forward_bf16_storage_vs_reference_golden(T, golden, tag):
     print(f"[bf16 storage] {tag}: final {e:.2e}, worst stage {worst:.2e}")
     assert e < 5e-2          # measured 2.1-3.2e-2: ~30 layers of 8-bit significands in front of a cancellation-heavy head
     assert torch.equal(y, m(LR))
+
+
+def _bf16_ulp(ref):
+    """Spacing of bf16 at |ref| (8 significand bits): 2^(floor(log2|ref|) - 7); the smallest normal spacing for 0."""
+    a = ref.abs().double().clamp_min(2.0 ** -126)
+    return torch.pow(2.0, torch.floor(torch.log2(a)) - 7)
+
+
+@pytest.mark.parametrize("tag", ["t1", "t7", "t1_l2"])
+def test_model_eval_forward_bf16_storage_vs_bf16_emulating_oracle(T, golden, tag):
+    """conv_impl = 'bf16' against the oracle's restatement of ITS arithmetic (`emulate="bf16"`: bf16 rounding of every
+    stored activation and of the conv weights, exact products, wide accumulation, fp32 epilogues) -- the reference has
+    no bf16 numerics, so this is the check that no tap, halo column or channel is dropped in the bf16 kernels, which a
+    3e-2 bar against fp32 cannot see.
+
+    (1) TEACHER-FORCED, per stage: the oracle evaluates every stage on the DEVICE's input of that stage.  Device and
+        oracle then differ only where an fp32 pre-rounding value sits within accumulation-order noise (~1e-6 relative)
+        of a bf16 rounding boundary and the two round to neighbouring bf16 values (probability ~2e-4 per element and
+        rounding), plus -- inside an MSRB, which rounds four times (cat1, the two stage-2 tiles, the partial sum) before
+        its output is stored -- the few-layer cascade of such flips through the 1x1 (|w| ~ 0.2):
+          * >= 99 % of the elements are IDENTICAL (a dropped tap or halo column changes essentially all of them);
+          * >= 99.9 % lie within one bf16 ulp of the oracle's value (+ 2e-4 of the stage maximum);
+          * every element lies within 1e-2 of the stage maximum and the relative L2 error is <= 1e-3.
+    (2) END TO END (flips cascade through ~30 layers): relative L2 error <= 2e-3 per stage and on the final image --
+        the bar VERDICT r02 asked for, in the norm that a handful of one-ulp flips at the tensor maximum (2^-8 .. 2^-7
+        each) does not dominate; the max-norm is held to 2^-6 (two ulps at the maximum).
+    The old 3e-2-vs-fp32 figure is printed for information."""
+    g = golden("eval")
+    cfg = GOLD_CFG[tag]
+    sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), int(g[f"{tag}/seed"]))
+    m = T.TactileSR(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    m.conv_impl = "bf16"
+    LRc = torch.from_numpy(g[f"{tag}/LR"])
+    y, stages = m.forward_with_stages(LRc.cuda())
+    y = y.cpu()
+    dev = {k: v.cpu() for k, v in stages.items()}
+    assert all(torch.equal(v, v.to(torch.bfloat16).float()) for v in dev.values())
+    forced, free = {}, {}
+    with torch.no_grad():
+        yf = O.tactilesr_forward(sd, LRc, cfg.get("scale_factor", 10), stages=forced, emulate="bf16", teacher=dev)
+        ye = O.tactilesr_forward(sd, LRc, cfg.get("scale_factor", 10), stages=free, emulate="bf16")
+    w_same = w_ulp = w_max = w_l2 = 0.0
+    for name, ref in list(forced.items()) + [("out", yf)]:
+        got = (y if name == "out" else dev[name]).double()
+        d = (got - ref.double()).abs()
+        mx = float(ref.abs().max())
+        if name == "out":      # fp32 head output on the device's head0: no rounding, only accumulation-order noise
+            assert float(d.max()) <= 1e-5 * mx, name
+            continue
+        differ = float((d > 0).double().mean())
+        beyond = float((d > _bf16_ulp(ref) * 1.001 + 2e-4 * mx).double().mean())
+        l2 = float(d.norm() / ref.double().norm())
+        w_same, w_ulp, w_max, w_l2 = max(w_same, differ), max(w_ulp, beyond), max(w_max, float(d.max()) / mx), max(w_l2, l2)
+        assert differ < 1e-2 and beyond < 1e-3 and float(d.max()) <= 1e-2 * mx and l2 <= 1e-3, (name, differ, beyond, float(d.max()) / mx, l2)
+    e2e_l2 = e2e_max = 0.0
+    for name, ref in list(free.items()) + [("out", ye)]:
+        got = (y if name == "out" else dev[name]).double()
+        l2 = float((got - ref.double()).norm() / ref.double().norm())
+        mx = float((got - ref.double()).abs().max() / ref.abs().max())
+        e2e_l2, e2e_max = max(e2e_l2, l2), max(e2e_max, mx)
+        assert l2 <= 2e-3 and mx <= 2.0 ** -6, (name, l2, mx)
+    print(f"[bf16 vs bf16-oracle] {tag}: teacher-forced worst share of differing elements {w_same:.2e}, beyond one ulp "
+          f"{w_ulp:.2e}, worst max-norm {w_max:.2e}, worst rel-L2 {w_l2:.2e}; end-to-end worst rel-L2 {e2e_l2:.2e}, worst "
+          f"max-norm {e2e_max:.2e}; vs the reference's fp32 output (information) {relerr(y, torch.from_numpy(g[f'{tag}/out'])):.2e}")
 
 
 def test_bf16_storage_batch4096_tiling_invariance(T):

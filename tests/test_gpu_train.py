@@ -411,6 +411,32 @@ def test_bf16_train_mode_is_a_reduced_precision_of_the_same_step(T, golden, monk
         assert cos > 0.98, (k, cos)
 
 
+def test_non_finite_loss_raises_like_the_reference_trainer(T):
+    """cpu/trainer.py:280-284: a NaN / Inf loss raises FloatingPointError.  A NaN taxel, an Inf taxel and a diverged (NaN)
+    weight must each reach the loss through the train-mode path (batch statistics couple every frame, so the whole
+    batch goes non-finite -- as in the reference); `train_one_iter(check_finite=True)` raises with the reference's text."""
+    from tactilesr_amd import optim
+    from tactilesr_amd.train import tactileSR_train as TR
+    conf = TR.default_config()
+    g = torch.Generator().manual_seed(5)
+    LR, HR = torch.rand(6, 3, 4, 4, generator=g) * 8, torch.rand(6, 1, 100, 100, generator=g) * 250
+    for case in ("nan_taxel", "inf_taxel", "nan_weight"):
+        torch.manual_seed(3)
+        m = T.TactileSR(patternFeatureExtraLayerCnt=1).cuda().train()
+        opt = optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-2)
+        assert torch.isfinite(TR.train_one_iter(m, opt, (LR, HR), conf, check_finite=True, cur_iter=0)["total_loss"])
+        bad = LR.clone()
+        if case == "nan_taxel":
+            bad[3, 1, 2, 2] = float("nan")
+        elif case == "inf_taxel":
+            bad[0, 2, 0, 3] = float("inf")
+        else:
+            with torch.no_grad():
+                m.patternFeatureExtra_layer[0].conv_5_2[0].weight[7, 3, 2, 2] = float("nan")
+        with pytest.raises(FloatingPointError, match="Loss became infinite or NaN at iteration=1"):
+            TR.train_one_iter(m, opt, (bad, HR), conf, check_finite=True, cur_iter=1)
+
+
 def test_multi_step_loss_trajectory_tracks_the_oracle(T):
     """Ten Adam(L2) steps on a fixed batch: the loss curve of the HIP path follows the CPU oracle's step by step.
     Two faithful fp32 implementations drift apart slowly (ReLU-mask flips, Adam's sign sensitivity near zero
@@ -604,6 +630,6 @@ def test_gradient_arena_and_inbackward_bucket_allreduce_on_the_hip_engine(T):
         F.mse_loss(m(LR), HR).backward()
         sync.finish()
         opt.step()
-        assert len(opt._tables) == n_tables == 1 and opt.launches == 2
+        assert len(opt._tables) == n_tables == 1 and opt.launches == 2 and opt.table_builds == 1
     finally:
         dist.destroy_process_group()

@@ -54,6 +54,66 @@ def test_eval_forward_matches_reference(golden, tag):
             <= 1e-5 * float(g[f"{tag}/stage/{name}/abssum"]), name
 
 
+INIT_CFGS = {"init_t1": dict(), "init_sf25t8": dict(scale_factor=25, seqsCnt=8)}
+
+
+def init_fixture_state(g, tag):
+    """Parameters of the `eval_init` fixtures: the drop-in's constructor under seed 42 (bit-identical to the reference's
+    `_init_network`, checked by sha256 against the reference's own state_dict) + the running statistics the reference's
+    two train-mode passes left behind (stored in the fixture)."""
+    import tactilesr_amd
+    torch.manual_seed(42)
+    sd = {k: v.detach().clone() for k, v in tactilesr_amd.TactileSR(**INIT_CFGS[tag]).state_dict().items()}
+    assert sd_hash(sd) == str(g[f"{tag}/sha256_init"]), "seeded construction differs from the reference's"
+    for k in sd:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            sd[k] = torch.from_numpy(g[f"{tag}/stat/{k}"])
+    return sd
+
+
+@pytest.mark.parametrize("tag", ["init_t1", "init_sf25t8"])
+def test_eval_forward_reference_init_fixture(golden, tag):
+    """The reference's own seed-42 parameters with moved BatchNorm statistics (configs[4] shape and the shipped shape)."""
+    g = golden("eval_init")
+    sd = init_fixture_state(g, tag)
+    stages = {}
+    with torch.no_grad():
+        y = O.tactilesr_forward(sd, torch.from_numpy(g[f"{tag}/LR"]), INIT_CFGS[tag].get("scale_factor", 10),
+                                stages=stages)
+    assert relerr(y.numpy(), g[f"{tag}/out"]) < 1e-6
+    for name, t in stages.items():
+        assert relerr(probe(t), g[f"{tag}/stage/{name}/probe"]) < 1e-6, name
+
+
+def test_bf16_emulation_hooks(golden):
+    """`emulate="bf16"` (the restatement of the build's bf16 activation-storage arithmetic): every recorded stage holds
+    bf16-representable values, the result stays within the stated 3e-2 of the reference's fp32 output, feeding the
+    oracle's own stages back as `teacher` changes nothing, and a perturbed teacher tensor changes only what follows."""
+    g = golden("eval")
+    cfg = CFGS["t1_l2"]
+    sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), int(g["t1_l2/seed"]))
+    LR = torch.from_numpy(g["t1_l2/LR"])
+    st = {}
+    with torch.no_grad():
+        y = O.tactilesr_forward(sd, LR, stages=st, emulate="bf16")
+        y32 = O.tactilesr_forward(sd, LR)
+    assert torch.equal(y32, torch.from_numpy(g["t1_l2/out"])) or relerr(y32.numpy(), g["t1_l2/out"]) < 1e-6
+    for name, t in st.items():
+        assert torch.equal(t, t.to(torch.bfloat16).float()), name
+    assert 1e-4 < relerr(y.numpy(), y32.numpy()) < 3e-2
+    st2 = {}
+    with torch.no_grad():
+        y2 = O.tactilesr_forward(sd, LR, stages=st2, emulate="bf16", teacher=st)
+    assert torch.equal(y, y2) and all(torch.equal(st[k], st2[k]) for k in st)
+    bad = dict(st)
+    bad["msrb0"] = st["msrb0"] * 1.5
+    st3 = {}
+    with torch.no_grad():
+        O.tactilesr_forward(sd, LR, stages=st3, emulate="bf16", teacher=bad)
+    assert torch.equal(st3["msrb0"], st["msrb0"]) and torch.equal(st3["fuse"], st["fuse"])
+    assert not torch.equal(st3["msrb1"], st["msrb1"])
+
+
 def test_train_step_matches_reference(golden):
     g = golden("train")
     cfg = dict(patternFeatureExtraLayerCnt=2)

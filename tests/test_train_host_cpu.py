@@ -98,6 +98,38 @@ def test_lr_warmup_resume_mid_schedule_continues_the_reference_sequence(golden, 
     assert np.array_equal(np.array(lrs), ref)
 
 
+def test_scheduler_driven_the_way_the_reference_lr_update_hook_does():
+    """LRUpdateHook (cpu/hooks/lr_update_hook.py:32-43): after_iter -> iter_update(); after_epoch reads
+    `lr_scheduler._is_plateau` and calls epoch_update(metric) for ReduceLROnPlateau, epoch_update() otherwise."""
+    import torch
+    from tactilesr_amd.train.lr_scheduler import LRWarmupScheduler
+
+    def after_epoch(sch, metric):
+        if sch._is_plateau:
+            sch.epoch_update(metric)
+        else:
+            sch.epoch_update()
+
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-3)
+    sch = LRWarmupScheduler(torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.5), epoch_len=3)
+    assert sch._is_plateau is False
+    for _ in range(3):
+        opt.step()
+        sch.iter_update()
+    after_epoch(sch, None)
+    assert abs(opt.param_groups[0]["lr"] - 5e-4) < 1e-12
+    opt2 = torch.optim.Adam([p], lr=1e-3)
+    sch2 = LRWarmupScheduler(torch.optim.lr_scheduler.ReduceLROnPlateau(opt2, factor=0.1, patience=0), epoch_len=3)
+    assert sch2._is_plateau is True
+    for metric in (1.0, 2.0):            # a worse metric after the first epoch -> lr * 0.1
+        for _ in range(3):
+            opt2.step()
+            sch2.iter_update()
+        after_epoch(sch2, metric)
+    assert abs(opt2.param_groups[0]["lr"] - 1e-4) < 1e-12
+
+
 def test_checkpoint_layout_roundtrip(tmp_path):
     import tactilesr_amd
     torch.manual_seed(0)
