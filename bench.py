@@ -11,6 +11,12 @@ sample with no data-path collective ("weak" scaling, 4096 frames per GPU).
 
 `--gpus N` without a torchrun environment starts the N ranks itself (child processes, one per GPU).
 
+The default run (`python bench.py`, N = 1, mode infer) prints the headline line AND, under "legs", short runs of every
+other BASELINE configuration with the same fields (value, ms_per_step, roofline of the leg's dominant kernel,
+cpu_baseline): train B=2048 (x5 steps) and B=8192 (x2, configs[3] per-GPU batch), bf16-storage eval (x10) and bf16
+train B=8192 (x2; configs[2]), tPSFNet train + forward (x20; configs[2]), tactileSRSeqs eval / train (x3; configs[4]
+shape).  `--no-legs` prints the headline only.
+
 One JSON line on rank 0 carries the contract fields plus
   roofline     - the dominant kernel (5x5 128->128 conv, 54 % of all FLOPs), timed live
                  with HIP events on the launch stream inside the timed region;
@@ -118,6 +124,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="headline only (skip the short legs of the other configurations)")
+    ap.add_argument("--broadcast-buffers", action="store_true",
+                    help="train, N > 1: rank 0's BatchNorm statistics before every forward (torch-DDP default semantics)")
     ap.add_argument("--impl", choices=["fp16x3", "bf16x6", "f32", "bf16x3", "bf16"], default="fp16x3",
                     help="conv arithmetic of the timed path (all accumulate in fp32): fp16x3 = fp32 operands scaled by "
                          "powers of two and split into 2 fp16 planes, 3 f16-MFMA products (fp32-grade, default); "
@@ -135,11 +144,6 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) != max(1, args.gpus) and "WORLD_SIZE" in os.environ:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: the launcher's world size is used",
               file=sys.stderr)
-    if args.mode == "train":
-        return main_train(args)
-    if args.mode == "tpsf":
-        return main_tpsf(args)
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -155,7 +159,59 @@ def main():
             dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
         else:
             dist.init_process_group(backend=backend, init_method="env://")
+    run = {"infer": run_infer, "train": run_train, "tpsf": run_tpsf}[args.mode]
+    res = run(args, world, rank, dev)
+    if rank == 0 and world == 1 and args.mode == "infer" and not args.no_legs and not args.seqs and not args.impl_given \
+            and args.batch == 4096:
+        res["legs"] = run_legs(args, dev)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
+
+def run_legs(args, dev):
+    """Short runs of the other BASELINE configurations, each reported like its own bench line (see module docstring)."""
+    import copy
+    import gc
+    legs = {}
+
+    def leg(name, fn, **over):
+        a = copy.copy(args)
+        a.seqs, a.impl, a.impl_given, a.batch = False, "fp16x3", False, 4096
+        for k, v in over.items():
+            setattr(a, k, v)
+        saved = os.environ.get("TSR_TRAIN_IMPL")
+        t0 = time.perf_counter()
+        try:
+            r = fn(a, 1, 0, dev)
+            r["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+            legs[name] = r
+        except Exception as e:        # a leg must never take the headline down with it
+            legs[name] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            if saved is None:
+                os.environ.pop("TSR_TRAIN_IMPL", None)
+            else:
+                os.environ["TSR_TRAIN_IMPL"] = saved
+            gc.collect()
+            torch.cuda.empty_cache()
+
+    leg("train_b2048", run_train, mode="train", steps=5, warmup=2)
+    leg("train_b8192", run_train, mode="train", batch=8192, steps=2, warmup=1, no_cpu_baseline=True)
+    leg("eval_bf16_storage", run_infer, impl="bf16", impl_given=True, steps=10, warmup=2, no_cpu_baseline=True)
+    leg("train_bf16_b8192", run_train, mode="train", impl="bf16", impl_given=True, batch=8192, steps=2, warmup=1,
+        no_cpu_baseline=True)
+    leg("tpsf_b8192", run_tpsf, mode="tpsf", steps=20, warmup=3)
+    leg("seqs_eval_b512", run_infer, seqs=True, steps=3, warmup=1)
+    leg("seqs_train_b256", run_train, mode="train", seqs=True, steps=3, warmup=1)
+    return legs
+
+
+def run_infer(args, world, rank, dev):
+    if world > 1:
+        import torch.distributed as dist
     import tactilesr_amd
     torch.manual_seed(42)
     model, cin_lr, side, _, fwd_flop = make_model(args)
@@ -193,7 +249,7 @@ def main():
 
     # secondary measurement: the strict fp32-MFMA path (v_mfma_f32_32x32x2_f32), 2 steps, same inputs
     f32_ref = None
-    if args.impl != "f32" and not args.seqs:
+    if args.impl != "f32" and not args.seqs and not args.impl_given:
         model.conv_impl = "f32"
         model(LR)
         barrier()
@@ -265,37 +321,27 @@ def main():
         }
         if f32_ref is not None:
             res["f32_mfma_path"] = f32_ref
-        if world == 1 and not args.no_cpu_baseline and not args.seqs:
-            res.update(cpu_baseline_and_psnr(model, dev))
-        print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        if world == 1 and not args.no_cpu_baseline:
+            res.update(cpu_seqs_baseline(model) if args.seqs else cpu_baseline_and_psnr(model, dev))
+        return res
+    return None
 
 
-def main_train(args):
+def run_train(args, world, rank, dev):
     """One step = Trainer_tactileSR.train_cal_loss + zero_grad/backward/Adam (reference
     train/tactileSR_train.py:41-51, cpu/trainer.py:346-362) on a per-GPU shard of `--batch` frames;
     N>1 adds the bucketed RCCL all-reduce of the 18.33 MB gradient, issued from inside backward (tactilesr_amd.ddp)."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     from tactilesr_amd import ddp, optim
     from tactilesr_amd.train import tactileSR_train as TR
     import tactilesr_amd
-    local = local % torch.cuda.device_count()
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        ddp.init_distributed(os.environ.get("TSR_BENCH_DIST_BACKEND", "nccl"))
     torch.manual_seed(42)
-    if args.impl_given:
-        os.environ["TSR_TRAIN_IMPL"] = args.impl        # read when the model builds its train engine
+    os.environ["TSR_TRAIN_IMPL"] = args.impl if args.impl_given else os.environ.get("TSR_TRAIN_IMPL", "fp16x3")
     model, cin_lr, side, cfg_over, fwd_flop = make_model(args)
     model = model.to(dev).train()
     opt = optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-2)
-    sync = ddp.GradSync(model) if world > 1 else None
+    sync = ddp.GradSync(model, broadcast_buffers=args.broadcast_buffers) if world > 1 else None
     if sync:
         sync.broadcast_parameters(0)
     B = args.batch if args.batch != 4096 else (256 if args.seqs else 2048)
@@ -320,10 +366,14 @@ def main_train(args):
     barrier()
     dt = time.perf_counter() - t0
     prof, eng.profile = eng.profile, None
+    losses_all = [float(ld["total_loss"].detach())]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        lt = [torch.zeros(1, device=dev, dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(lt, ld["total_loss"].detach().reshape(1).float())
+        losses_all = [float(x) for x in lt]
     if rank == 0:
         value = B * world * args.steps / dt
         impl = os.environ.get("TSR_TRAIN_IMPL", "fp16x3")
@@ -377,12 +427,16 @@ def main_train(args):
                            "ms_per_step_by_family": {k: round(v, 2) for k, v in sorted(fam.items())}},
             "loss": float(ld["total_loss"].detach()),
         }
-        if world == 1 and not args.no_cpu_baseline and not args.seqs:
-            res["cpu_baseline"] = cpu_train_baseline()
-        print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_seqs_baseline(model, train=True)["cpu_baseline"] if args.seqs else cpu_train_baseline()
+        if sync is not None:
+            # where in backward each gradient bucket left and how long the step then waited for the wire: the exposed
+            # communication of the LAST timed step, on this rank (device clock when the tensors are on the GPU)
+            res["ddp"] = sync.stats()
+            res["comm_wait_ms"] = res["ddp"]["comm_wait_ms"]
+        res["loss_all_ranks"] = losses_all
+        return res
+    return None
 
 
 def cpu_train_baseline(steps=3):
@@ -418,23 +472,16 @@ def tpsf_traffic(B):
     return d["hbm_bytes_per_launch"] if d and d.get("samples_per_launch") == B else None
 
 
-def main_tpsf(args):
+def run_tpsf(args, world, rank, dev):
     """tPSFNet (reference model/tPSFNet.py:78-141): one step = Trainer_tPSF.train_cal_loss + backward + Adam
     (train/tPSFNet_train.py:180-190) on `--batch` samples (default 8192, BASELINE configs[2]); the forward-only
     rate (the dataset-generator use, data/SRdataset/depth2tactile.py:104-160) is reported beside it.  Single GPU
     or independent replicas (no gradient exchange is timed here; the MLP has 0.54 M parameters)."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     import tactilesr_amd
     from tactilesr_amd import optim
     from tactilesr_amd.train import tPSFNet_train as TP
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        from tactilesr_amd import ddp
-        ddp.init_distributed(os.environ.get("TSR_BENCH_DIST_BACKEND", "nccl"))
     torch.manual_seed(42)
     net = tactilesr_amd.tPSFNet(gama=1.4, perception_scale=None).to(dev).train()
     opt = optim.Adam(net.parameters(), lr=1e-3, weight_decay=0.0)
@@ -480,7 +527,7 @@ def main_tpsf(args):
         value = B * world * args.steps / dt
         vf = B * world * args.steps / dtf
         fwd_bytes = 4 * (10000 + 10000 + 9801 + 16 + 48 + 3)      # depth in; HR, psf, LR_degrade out
-        print(json.dumps({
+        return {
             "metric": "tPSFNet train samples/sec (depth 100x100 -> HR 100x100 + 4x4 taxels)", "value": round(value, 1),
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -495,10 +542,8 @@ def main_tpsf(args):
                          "kernel": "tpsf_fwd_mfma_kernel (+ the MLP launches: forward-only rate x %d algorithmic bytes/sample)" % fwd_bytes},
             "loss": float(loss.detach()),
             **({"cpu_baseline": cpu_tpsf_baseline()} if world == 1 and not args.no_cpu_baseline else {}),
-        }), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        }
+    return None
 
 
 def cpu_tpsf_baseline(n=32):
@@ -522,6 +567,34 @@ def cpu_tpsf_baseline(n=32):
     return {"value": round(n / ts[1], 2), "unit": "samples/s", "cores": torch.get_num_threads(),
             "cpu_model": cpu_model_string(), "kind": "port",
             "sample": "oracle tPSFNet train_cal_loss + backward (per-sample direct 99x99 conv), B=%d fp32, median of 3" % n}
+
+
+def cpu_seqs_baseline(model, train=False, n=4):
+    """tactileSRSeqs shape (scale_factor=25, seqsCnt=8; 102 GFLOP per sample forward): the CPU oracle on a bounded
+    sample of n frames -- eval forward, or the trainer step (loss + backward + Adam L2) when `train`."""
+    from oracle import tactilesr_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    sf, T = model.scale_factor, model.seqsCnt
+    g = torch.Generator().manual_seed(42)
+    LR = torch.rand(n, 3 * T, 4, 4, generator=g) * 8
+    HR = torch.rand(n, 1, 100, 100, generator=g) * 250
+    ts = []
+    state = {}
+    for i in range(3):
+        t0 = time.perf_counter()
+        if train:
+            O.train_one_iter(sd, state, i + 1, LR, HR, seqsCnt=T, scale_factor=sf)
+        else:
+            with torch.no_grad():
+                O.tactilesr_forward(sd, LR, sf)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return {"cpu_baseline": {"value": round(n / ts[1], 2), "unit": "samples/s", "cores": torch.get_num_threads(),
+                             "cpu_model": cpu_model_string(), "kind": "port",
+                             "sample": "oracle %s, tactileSRSeqs shape (sf=%d, T=%d), B=%d fp32, median of 3"
+                                       % ("trainer step (loss + backward + Adam L2)" if train else "eval forward", sf, T, n)}}
 
 
 def cpu_baseline_and_psnr(model, dev):

@@ -132,6 +132,9 @@ class GradSink:
         self.first = arena is None
         self.direct = arena is not None and all(p.grad is None for p in named_params.values())
         self.arena = arena if self.direct else None
+        sync = getattr(owner, "grad_sync", None)
+        if sync is not None:
+            sync.backward_started("first" if self.first else ("direct" if self.direct else "accum"), device)
         if self.direct:
             arena.begin()
         self.out: Dict[str, torch.Tensor] = {}
@@ -169,15 +172,34 @@ class GradSink:
 
 
 class GradSync:
-    """Gradient averaging for a replicated model whose backward fills a ``GradArena``."""
+    """Gradient averaging for a replicated model whose backward fills a ``GradArena``.
 
-    def __init__(self, module: torch.nn.Module, group=None, engine=None):
+    Gradient accumulation over micro-batches: run every backward but the last under ``with sync.no_sync():`` (nothing is
+    put on the wire; autograd accumulates in place into the arena views), then ``finish()`` after the last one.  A second
+    backward while bucket all-reduces of an earlier one are in flight would add local gradients on top of partially
+    reduced ones -- that raises instead of silently averaging the wrong thing.
+
+    ``broadcast_buffers=True`` reproduces torch-DDP's default: before every forward (``pre_forward()``, called by
+    ``train_one_iter``) rank 0's buffers -- the BatchNorm running statistics and counters -- are broadcast, so every
+    rank evaluates / checkpoints with the same statistics; ``False`` (default) keeps them rank-local after the start-up
+    broadcast, i.e. rank r's running statistics describe rank r's shards."""
+
+    def __init__(self, module: torch.nn.Module, group=None, engine=None, broadcast_buffers: bool = False):
         self.module = module
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.arena: Optional[GradArena] = None
+        self.broadcast_buffers = bool(broadcast_buffers)
         self._works: Dict[int, object] = {}
+        self._defer = False
         self.events: List[Tuple[str, int]] = []      # ("enqueue", bucket) / ("finish", n): the tests read the order
+        # timing of the last step (see stats()): where in backward each bucket left, how long finish() waited
+        self._t0 = None
+        self._ev0 = None
+        self._enq: List[Tuple[int, float, object]] = []      # (bucket, host ms since backward start, device event | None)
+        self._wait_host_ms = 0.0
+        self._wait_ev = None
+        self.buffer_broadcasts = 0
         if engine is None and hasattr(module, "train_engine"):
             engine = module.train_engine()           # tactilesr_amd.TactileSR: its HIP backward engine
         if engine is not None:
@@ -191,19 +213,80 @@ class GradSync:
         self.arena = arena
         arena.on_bucket_ready = self._bucket_ready
 
+    def no_sync(self):
+        """Context manager: backward passes inside it put nothing on the wire (micro-batches of an accumulated step)."""
+        sync = self
+
+        class _NoSync:
+            def __enter__(self_):
+                self_.prev, sync._defer = sync._defer, True
+
+            def __exit__(self_, *exc):
+                sync._defer = self_.prev
+                return False
+        return _NoSync()
+
+    def backward_started(self, mode: str, device) -> None:
+        """Called by the GradSink at the start of every backward (mode: first / direct / accum)."""
+        if self._works:
+            raise RuntimeError(
+                "GradSync: a backward pass started while the bucket all-reduces of a previous backward are still in "
+                "flight -- with gradient accumulation run every micro-batch but the last under `with sync.no_sync():` "
+                "(or call finish() after each backward)")
+        import time
+        self._t0 = time.perf_counter()
+        self._enq = []
+        self._ev0 = None
+        if torch.device(device).type == "cuda":
+            self._ev0 = torch.cuda.Event(enable_timing=True)
+            self._ev0.record()
+
+    def _mark_enqueue(self, k: int, t: torch.Tensor) -> None:
+        import time
+        ev = None
+        if t.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+        self._enq.append((k, (time.perf_counter() - self._t0) * 1e3 if self._t0 is not None else 0.0, ev))
+
     def _bucket_ready(self, k: int, flat_slice: torch.Tensor) -> None:
-        if self.world == 1:
+        if self.world == 1 or self._defer:
             return
         self.events.append(("enqueue", k))
+        self._mark_enqueue(k, flat_slice)
         self._works[k] = dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     # ---- per step --------------------------------------------------------------------------------------------
+    def pre_forward(self) -> None:
+        """torch-DDP ``broadcast_buffers=True`` semantics: rank 0's buffers before every forward (3 coalesced
+        broadcasts: floating-point buffers, integer counters)."""
+        if self.world == 1 or not self.broadcast_buffers:
+            return
+        with torch.no_grad():
+            bufs = list(self.module.buffers())
+            for kind in (True, False):
+                ts = [b for b in bufs if b.is_floating_point() == kind]
+                if not ts:
+                    continue
+                flat = torch.cat([t.reshape(-1).to(ts[0].dtype) for t in ts])
+                dist.broadcast(flat, 0, group=self.group)
+                off = 0
+                for t in ts:
+                    t.copy_(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
+        self.buffer_broadcasts += 1
+        from . import _lib
+        _lib.bump_param_epoch()       # eval-mode weight packs fold the running statistics
+
     def finish(self) -> None:
         """grad <- mean over ranks.  Call between backward() and optimizer.step().  Buckets that were not issued
-        from inside backward (first step: the arena is built at its end; or gradients accumulated into existing
-        .grad tensors) are reduced here."""
+        from inside backward (first step: the arena is built at its end; gradients accumulated over micro-batches
+        under no_sync(); gradients accumulated into foreign tensors) are reduced here."""
         if self.world == 1 or self.arena is None:
             return
+        if self._defer:
+            raise RuntimeError("GradSync.finish() inside no_sync(): leave the context before the last micro-batch")
+        import time
         arena = self.arena
         named = dict(self.module.named_parameters())
         stale = [n for n in arena.names if n in named and named[n].grad is not None
@@ -215,10 +298,23 @@ class GradSync:
         for k in range(len(arena.buckets)):
             if k not in self._works:
                 self.events.append(("enqueue_late", k))
+                self._mark_enqueue(k, arena.flat)
                 self._works[k] = dist.all_reduce(arena.bucket(k), op=dist.ReduceOp.SUM, group=self.group,
                                                  async_op=True)
+        # exposed communication: how long the step waits here for collectives that did not finish under backward --
+        # on the device (events around the stream-side waits: RCCL's wait() parks the compute stream, not the host) and
+        # on the host (gloo: wait() blocks the caller)
+        ev_a = ev_b = None
+        if arena.flat.is_cuda:
+            ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev_a.record()
+        t_w = time.perf_counter()
         for k in sorted(self._works):
             self._works[k].wait()
+        self._wait_host_ms = (time.perf_counter() - t_w) * 1e3
+        if ev_a is not None:
+            ev_b.record()
+            self._wait_ev = (ev_a, ev_b)
         self._works.clear()
         arena.flat.div_(self.world)
         for n in arena.names:
@@ -228,6 +324,28 @@ class GradSync:
         self.events.append(("finish", len(arena.buckets)))
 
     __call__ = finish
+
+    def stats(self) -> Dict[str, object]:
+        """Timing of the LAST step (synchronises the device to read its events): per bucket the offset from the start of
+        backward at which its all-reduce was enqueued (host clock and device clock), and the time finish() waited for
+        collectives (``comm_wait_ms``: device stall when the tensors are on a GPU, host stall otherwise)."""
+        out: Dict[str, object] = {"world": self.world, "buckets": len(self.arena.buckets) if self.arena else 0,
+                                  "broadcast_buffers": self.broadcast_buffers}
+        dev_wait = None
+        if self._wait_ev is not None:
+            self._wait_ev[1].synchronize()
+            dev_wait = self._wait_ev[0].elapsed_time(self._wait_ev[1])
+        out["comm_wait_ms"] = round(dev_wait if dev_wait is not None else self._wait_host_ms, 4)
+        out["comm_wait_host_ms"] = round(self._wait_host_ms, 4)
+        enq = []
+        for k, host_ms, ev in self._enq:
+            d = None
+            if ev is not None and self._ev0 is not None:
+                ev.synchronize()
+                d = round(self._ev0.elapsed_time(ev), 3)
+            enq.append({"bucket": k, "host_ms": round(host_ms, 3), "device_ms": d})
+        out["bucket_enqueue_offsets"] = enq
+        return out
 
     # ---- start-up --------------------------------------------------------------------------------------------
     def broadcast_parameters(self, src: int = 0) -> None:

@@ -44,6 +44,8 @@ def train_one_iter(model, optimizer, batch, config, grad_sync=None, check_finite
     (``Trainer._log_iter_metrics``, cpu/trainer.py:259,280-284): the loss is read back (a host sync, like the
     reference's ``loss.detach().cpu().item()``) and a NaN / Inf raises ``FloatingPointError`` with the reference's
     message.  Off by default so that a step enqueues without a device round trip."""
+    if grad_sync is not None and hasattr(grad_sync, "pre_forward"):
+        grad_sync.pre_forward()          # broadcast_buffers=True: rank 0's BatchNorm statistics, like torch DDP
     losses, loss_dict = train_cal_loss(model, batch, config)
     optimizer.zero_grad()
     losses.backward()

@@ -159,6 +159,53 @@ def _worker(rank, world, port, q):
     got3 = torch.cat([named[n].grad.flatten() for n in sorted(local2)])
     res["step3_ok"] = bool(torch.allclose(got3, expect_mean(acc_local), atol=1e-6))
     res["accum_is_sum"] = bool(all(torch.allclose(acc_local[n], prev[n] + local2[n], atol=1e-6) for n in local2))
+    st = sync.stats()
+    res["stats_ok"] = (st["world"] == world and st["buckets"] == 3 and st["comm_wait_ms"] >= 0
+                       and [e["bucket"] for e in st["bucket_enqueue_offsets"]] == [0, 1, 2]
+                       and all(e["host_ms"] >= 0 for e in st["bucket_enqueue_offsets"]))
+    # step 4: the USUAL accumulation loop -- zero_grad(); backward (micro-batch 1, under no_sync); backward (micro-batch
+    # 2); finish() -- must give mean over ranks of (g1 + g2); nothing may leave before the last micro-batch
+    xs = [x[a:b], x[a:b] * 0.5 + 1.0]
+    refs = []
+    for xm in xs:
+        rm = _Toy()
+        rm.load_state_dict(model.state_dict())
+        rm._engine.grad_sync = None
+        rm(xm).pow(2).mean().backward()
+        refs.append({n: p.grad.detach().clone() for n, p in rm.named_parameters() if p.grad is not None})
+    want = {n: refs[0][n] + refs[1][n] for n in refs[0]}
+    for p in model.parameters():
+        p.grad = None
+    sync.events.clear()
+    with sync.no_sync():
+        model(xs[0]).pow(2).mean().backward()
+    res["nosync_events"] = [e for e in sync.events if e[0].startswith("enqueue")]
+    model(xs[1]).pow(2).mean().backward()
+    sync.finish()
+    got4 = torch.cat([named[n].grad.flatten() for n in sorted(want)])
+    res["step4_ok"] = bool(torch.allclose(got4, expect_mean(want), atol=1e-6))
+    # step 5: the same loop WITHOUT no_sync: micro-batch 1 puts its buckets on the wire from inside backward, so the
+    # second backward must refuse to add local gradients on top of them
+    for p in model.parameters():
+        p.grad = None
+    model(xs[0]).pow(2).mean().backward()
+    try:
+        model(xs[1]).pow(2).mean().backward()
+        res["step5_raised"] = False
+    except RuntimeError as e:
+        res["step5_raised"] = "no_sync" in str(e)
+    sync.finish()                       # drain the collectives of micro-batch 1 on both ranks
+    # broadcast_buffers=True (torch-DDP default): rank 0's BatchNorm statistics before every forward
+    with torch.no_grad():
+        model.bn.running_mean.fill_(10.0 + rank)
+        model.bn.running_var.fill_(2.0 + rank)
+        model.bn.num_batches_tracked.fill_(3 + rank)
+    sync.pre_forward()                  # broadcast_buffers=False: stays rank-local
+    res["bb_off"] = (float(model.bn.running_mean[0]), int(model.bn.num_batches_tracked))
+    sync.broadcast_buffers = True
+    sync.pre_forward()
+    res["bb_on"] = (float(model.bn.running_mean[0]), float(model.bn.running_var[0]), int(model.bn.num_batches_tracked),
+                    sync.buffer_broadcasts)
     q.put(res)
     dist.barrier()
     dist.destroy_process_group()
@@ -192,6 +239,11 @@ def test_gradsync_gloo_world2_overlapped_buckets_and_broadcast():
         assert ev == [("enqueue", 0), ("enqueue", 1), ("enqueue", 2), ("backward_end", -1)], ev
         # accumulation step: nothing issued from inside backward
         assert [e[0] for e in r["accum_events"]] == ["backward_end"]
+        assert r["stats_ok"]
+        # zero_grad; backward under no_sync; backward; finish == mean(g1 + g2), nothing on the wire during micro-batch 1
+        assert r["step4_ok"] and r["nosync_events"] == []
+        assert r["step5_raised"] is True
+        assert r["bb_off"] == (10.0 + r["rank"], 3 + r["rank"]) and r["bb_on"] == (10.0, 2.0, 3, 1)
 
 
 def test_shard_batch_covers_everything():

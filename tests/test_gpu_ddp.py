@@ -91,3 +91,37 @@ def test_two_rank_engine_gradsync_on_one_gpu():
         assert r["events"][0] == []                                              # first step: arena laid out at its end
         assert r["events"][1] == [("enqueue", k) for k in range(nb)], r["events"] # then: all buckets from inside backward
         assert r["same_weights"] and r["moved"]
+
+
+def test_bench_train_two_ranks_fresh_subprocess_gloo():
+    """`python bench.py --gpus 2 --mode train --batch 64` as a FRESH process (the way the driver starts it, outside
+    torchrun): bench.py spawns its two ranks itself, both run the real HIP engine on this box's one GPU, gradients go
+    over gloo (TSR_BENCH_DIST_BACKEND=gloo; RCCL needs one GPU per rank).  Checks the contract line: n_gpus == 2, both
+    ranks' losses finite, the data-parallel timing fields the first multi-GPU run will be read by (dist_world_size,
+    comm_wait_ms, per-bucket enqueue offsets inside backward), return code 0."""
+    import json
+    import math
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TSR_BENCH_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--mode", "train", "--batch", "64",
+                        "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--broadcast-buffers"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["dist_world_size"] == 2 and d["config"]["dist_backend"] == "gloo"
+    assert d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak" and d["value"] > 0
+    assert len(d["loss_all_ranks"]) == 2 and all(math.isfinite(v) for v in d["loss_all_ranks"])
+    assert d["loss_all_ranks"][0] != d["loss_all_ranks"][1]          # per-rank data shards (seed 42 + rank)
+    ddp = d["ddp"]
+    assert ddp["world"] == 2 and ddp["broadcast_buffers"] is True and d["comm_wait_ms"] >= 0
+    enq = ddp["bucket_enqueue_offsets"]
+    assert len(enq) == ddp["buckets"] >= 2 and [e["bucket"] for e in enq] == list(range(len(enq)))
+    assert all(e["device_ms"] is not None and e["device_ms"] >= 0 for e in enq)
+    assert enq[0]["device_ms"] < enq[-1]["device_ms"]               # buckets leave as backward produces them
