@@ -184,7 +184,9 @@ typedef struct tsr_conv_desc {
   const float* mask_scale; const float* mask_shift;
   const float* bn_a; const float* bn_b;
   float* slab; float* slab_cnt;
-  int nsplit;   /* 0: fp32 MFMA, w_packed from tsr_pack_conv_weight[_dgrad]; 1..3: split-bf16 MFMA (3 = fp32-equivalent),
+  int nsplit;   /* -1: plain bf16 operands AND bf16 CB16 tensors (in / res / mask / out address bf16 elements; w_packed as
+                   for 1): the train step with bf16 activation storage;
+                   0: fp32 MFMA, w_packed from tsr_pack_conv_weight[_dgrad]; 1..3: split-bf16 MFMA (3 = fp32-equivalent),
                    w_packed from tsr_pack_conv_weight[_dgrad]_bf16s; -2: fp16 two-plane split ("fp16x3"), w_packed from
                    tsr_pack_conv_weight[_dgrad]_f16s, needs in_amax and w_inv_scale below */
   const float* in_amax;   /* device scalar max|in| (of the raw tensor; a fused input transform is bounded in-kernel) */
@@ -225,7 +227,9 @@ int tsr_conv2d_wgrad(const float* a, int a_ctot, int a_coff, int cin,
 /* Same on the 16-bit matrix cores with split operands: planes = 3 -> three bf16 planes, six products
  * (fp32-equivalent; a_amax/dz_amax unused); planes = 1 -> plain bf16 operands (reduced precision: the "bf16"
  * configurations, never the parity path); planes = -2 -> two power-of-two-scaled fp16 planes, three products,
- * scales derived from the device scalars a_amax = max|a| (raw tensor) and dz_amax = max|dz|. */
+ * scales derived from the device scalars a_amax = max|a| (raw tensor) and dz_amax = max|dz|;
+ * planes = -1 -> plain bf16 operands read from bf16 CB16 TENSORS (`a`, `dz` then address bf16 elements): the train step
+ * with bf16 activation storage (BASELINE configs[2] / [4], "bf16"; reference switch: cpu/trainer.py:96,203,346-362). */
 int tsr_conv2d_wgrad_bf16s(const float* a, int a_ctot, int a_coff, int cin,
                            const float* a_scale, const float* a_shift,
                            const float* dz, int dz_ctot, int dz_coff, int cout, int ks, int planes,
@@ -269,6 +273,19 @@ int tsr_stem_wgrad(const float* lr, int lr_ctot, int lr_coff, int hin, int win, 
 int tsr_head_bwd(const float* dout, const float* out, const float* h0, int h_ctot, int cin,
                  const float* w_oihw, float* dz_h0, int dz_ctot, float* wslab, int nsplit,
                  int B, int H, int W, float* dz_amax /* optional: max|dz_h0| */, void* stream);
+
+/* The same four kernels on bf16 CB16 tensors -- the train step with bf16 ACTIVATION STORAGE (tsr_conv_desc.nsplit = -1,
+ * tsr_conv2d_wgrad_bf16s planes = -1): every stored activation / gradient tensor is bf16, arithmetic and the
+ * statistics / weight-gradient slabs stay fp32.  Pointers typed void* address bf16 elements. */
+int tsr_cb16_stats_b16(const void* z, int z_ctot, int z_coff, int B, int HW, float* slab, float* slab_cnt,
+                       void* stream);
+int tsr_bn_bwd_apply_b16(void* g, int g_ctot, int g_coff, const void* z, int z_ctot, int z_coff,
+                         const float* c1, const float* c2, const float* c3, int C, int B, int HW, void* stream);
+int tsr_stem_wgrad_b16(const float* lr, int lr_ctot, int lr_coff, int hin, int win, int sf,
+                       const void* dz, int dz_ctot, int dz_coff, float* slab, int nsplit, int B, void* stream);
+int tsr_head_bwd_b16(const float* dout, const float* out, const void* h0, int h_ctot, int cin,
+                     const float* w_oihw, void* dz_h0, int dz_ctot, float* wslab, int nsplit,
+                     int B, int H, int W, void* stream);
 
 /* HR.float()/HR_scale_num + F.interpolate(size=(H,W), bilinear) (train/tactileSR_train.py:44-45). */
 int tsr_target_prep(const float* hr_raw, float* out, float inv_scale, int B, int hin, int win, int H, int W,

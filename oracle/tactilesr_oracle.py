@@ -219,8 +219,37 @@ def _conv_q(x, w, bias, pad, emulate):
     return y if bias is None else y + bias.view(1, -1, 1, 1)
 
 
-def _conv_bn_relu(p, prefix_conv, prefix_bn, x, pad, training, new_stats, tap=None, emulate=None):
-    y = _conv_q(x, p[prefix_conv + ".weight"], p.get(prefix_conv + ".bias"), pad, emulate)
+def _bn_train_stored(p: Params, prefix: str, z: torch.Tensor, bias, new_stats, emulate, stats_from_stored=False):
+    """Train-mode BatchNorm as the build's bf16-storage train path evaluates it: `z` is the bias-free conv output in
+    fp32; the batch statistics come from the fp32 accumulator (`stats_from_stored`: from the stored, rounded tensor --
+    the stem, whose statistics are a separate pass over what it wrote), the normalisation is applied to the STORED
+    (rounded) z as fma(zq, scale, shift) with scale = gamma * invstd, shift = beta - mean * scale; the conv bias only
+    shifts running_mean."""
+    zq = _q(z, emulate)
+    src = zq if stats_from_stored else z
+    mean = src.mean(dim=(0, 2, 3))
+    var = src.var(dim=(0, 2, 3), unbiased=False)
+    scale = p[prefix + ".weight"] / torch.sqrt(var + BN_EPS)
+    shift = p[prefix + ".bias"] - mean * scale
+    if new_stats is not None:
+        n = z.numel() // z.shape[1]
+        mz = mean.detach() + (bias.detach() if bias is not None else 0.0)
+        new_stats[prefix + ".running_mean"] = (1 - BN_MOMENTUM) * p[prefix + ".running_mean"] + BN_MOMENTUM * mz
+        new_stats[prefix + ".running_var"] = ((1 - BN_MOMENTUM) * p[prefix + ".running_var"]
+                                              + BN_MOMENTUM * var.detach() * (n / max(n - 1, 1)))
+        new_stats[prefix + ".num_batches_tracked"] = p[prefix + ".num_batches_tracked"] + 1
+    return zq * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+
+
+def _conv_bn_relu(p, prefix_conv, prefix_bn, x, pad, training, new_stats, tap=None, emulate=None,
+                  fp32_conv=False, stats_from_stored=False):
+    """conv (+bias) -> BatchNorm -> ReLU.  `fp32_conv`: the stem's 3 -> 64 conv keeps fp32 operands in the emulated
+    paths too (it is fused with the bilinear upsample of the fp32 taxels)."""
+    w, b = p[prefix_conv + ".weight"], p.get(prefix_conv + ".bias")
+    if emulate is not None and training:
+        z = F.conv2d(x, w, None, padding=pad) if fp32_conv else _conv_q(x, w, None, pad, emulate)
+        return _q(_relu(tap, prefix_bn, _bn_train_stored(p, prefix_bn, z, b, new_stats, emulate, stats_from_stored)), emulate)
+    y = F.conv2d(x, w, b, padding=pad) if fp32_conv else _conv_q(x, w, b, pad, emulate)
     return _q(_relu(tap, prefix_bn, _bn(p, prefix_bn, y, training, new_stats)), emulate)
 
 
@@ -291,7 +320,8 @@ def tactilesr_forward(p: Params, x: torch.Tensor, scale_factor=10, axisCnt=3,
         pre = f"inputLayer_pattern_list.{t}"
         u = bilinear_resize(x[:, axisCnt * t:axisCnt * (t + 1)], size)
         # (the stem kernel fuses the upsample with its fp32 3->64 conv: fp32 operands, only its OUTPUT is stored)
-        h = _q(_conv_bn_relu(p, f"{pre}.1", f"{pre}.2", u, 1, training, new_stats, tap), emulate)
+        h = _conv_bn_relu(p, f"{pre}.1", f"{pre}.2", u, 1, training, new_stats, tap, emulate, fp32_conv=True,
+                          stats_from_stored=True)
         h = _conv_bn_relu(p, f"{pre}.4", f"{pre}.5", h, 1, training, new_stats, tap, emulate)
         feats.append(rec(f"stem{t}", h))
     h = torch.cat(feats, 1) if seqsCnt > 1 else feats[0]
@@ -328,11 +358,11 @@ def prepare_target(HR_raw: torch.Tensor, HR_scale_num=10.0, scale_factor=10) -> 
 
 def train_cal_loss(p: Params, LR: torch.Tensor, HR_raw: torch.Tensor, seqsCnt=1, axisCnt=3,
                    HR_scale_num=10.0, scale_factor=10, training=True,
-                   new_stats: Optional[Params] = None) -> torch.Tensor:
+                   new_stats: Optional[Params] = None, emulate=None) -> torch.Tensor:
     """Trainer_tactileSR.train_cal_loss, train/tactileSR_train.py:41-51."""
     HR = prepare_target(HR_raw, HR_scale_num, scale_factor)
     x = LR.type(torch.float32)[:, :seqsCnt * axisCnt]
-    out = tactilesr_forward(p, x, scale_factor, axisCnt, training, new_stats)
+    out = tactilesr_forward(p, x, scale_factor, axisCnt, training, new_stats, emulate=emulate)
     return F.mse_loss(out, HR)
 
 

@@ -22,7 +22,7 @@ __device__ __forceinline__ void quad_transpose(float& t0, float& t1, float& t2, 
 
 // accmul: exact power-of-two factor undoing the operand scaling of the fp16-split path (1 otherwise).
 // WN = waves across C_out (2: each wave owns C_out/2 of one of 2 images; 1: each wave owns all C_out of one of 4).
-// IO16: output and residual tensors are bf16 CB16 (inference epilogue only).
+// IO16: output, residual and mask tensors are bf16 CB16 (the "bf16" configurations: inference and training epilogues).
 template <int COUT, bool EXT, int WN = 2, bool IO16 = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2][COUT / (32 * WN)], int bid, int b0,
                                               int y0, int x0, int wm, int wn, int h, int li, int HW,
@@ -40,12 +40,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
   for (int nb = 0; nb < NB; ++nb) {
     const int n = wn * (COUT / WN) + nb * 32 + li;
     const int oc = a.out_coff + n;
-    float* obase = a.out + (((size_t)bsafe * out_blocks + (oc >> 4)) * HW) * 16 + (oc & 15);
-    const float* rbase = nullptr;
-    if (a.res) {
-      const int rc = a.res_coff + n;
-      rbase = a.res + (((size_t)bsafe * res_blocks + (rc >> 4)) * HW) * 16 + (rc & 15);
-    }
     if (!EXT || a.epi_mode == 0) {
       // y = acc*scale + shift (+ residual) (ReLU) -> channel slice of out.
       // The accumulator holds (lane = channel, register = pixel); a 4x4 transpose inside every lane quad (registers
@@ -60,15 +54,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
       if (a.shift) sh4 = *(const f32x4*)(a.shift + nq);
       if (EXT && a.res_scale) { rsc4 = *(const f32x4*)(a.res_scale + nq); rsh4 = *(const f32x4*)(a.res_shift + nq); }
       const size_t oidx4 = (((size_t)bsafe * out_blocks + (oq >> 4)) * HW) * 16 + (oq & 15);
-      float* ob4 = a.out + oidx4;
       const float* rb4 = nullptr;
       size_t ridx4 = 0;
       if (a.res) {
         const int rq = a.res_coff + nq;
         ridx4 = (((size_t)bsafe * res_blocks + (rq >> 4)) * HW) * 16 + (rq & 15);
-        rb4 = a.res + ridx4;
+        rb4 = a.res;
       }
-      typedef __bf16 ep_bf16x4 __attribute__((ext_vector_type(4)));
       const int gx = x0 + j + 4 * h;
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
@@ -84,14 +76,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = (v[c] * accmul) * sc4[c] + sh4[c];
             if (rb4) {
-              f32x4 rv;
-              if (IO16) {
-                const ep_bf16x4 r16 = *(const ep_bf16x4*)((const __bf16*)a.res + ridx4 + po);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) rv[c] = (float)r16[c];
-              } else {
-                rv = *(const f32x4*)(rb4 + po);
-              }
+              f32x4 rv = tsr_ld4<IO16>(a.res, ridx4 + po);
               if (EXT && a.res_scale) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) rv[c] = tsr_relu(fmaf(rv[c], rsc4[c], rsh4[c]));
@@ -104,14 +89,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
               if (a.relu) v[c] = tsr_relu(v[c]);
               amax = fmaxf(amax, fabsf(v[c]));
             }
-            if (IO16) {
-              ep_bf16x4 o16;
-#pragma unroll
-              for (int c = 0; c < 4; ++c) o16[c] = (__bf16)v[c];
-              *(ep_bf16x4*)((__bf16*)a.out + oidx4 + po) = o16;
-            } else {
-              *(f32x4*)(ob4 + po) = v;
-            }
+            tsr_st4<IO16>(a.out, oidx4 + po, v);
           }
         }
       }
@@ -163,7 +141,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
       {   // raw accumulator -> out, as 16-B stores after the quad transpose (see mode 0)
         const int k4 = li >> 2, j = li & 3;
         const int oq = a.out_coff + wn * (COUT / WN) + nb * 32 + 4 * k4;
-        float* ob4 = a.out + (((size_t)bsafe * out_blocks + (oq >> 4)) * HW) * 16 + (oq & 15);
+        const size_t oidx4 = (((size_t)bsafe * out_blocks + (oq >> 4)) * HW) * 16 + (oq & 15);
         const int gx = x0 + j + 4 * h;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -173,7 +151,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
                   t3 = acc[mb][nb][4 * g + 3];
             quad_transpose(t0, t1, t2, t3, j);
             const int gy = y0 + 4 * mb + g;
-            if (img_ok && gy < a.H && gx < a.W) *(f32x4*)(ob4 + (size_t)(gy * a.W + gx) * 16) = (f32x4){t0, t1, t2, t3};
+            if (img_ok && gy < a.H && gx < a.W)
+              tsr_st4<IO16>(a.out, oidx4 + (size_t)(gy * a.W + gx) * 16, (f32x4){t0, t1, t2, t3});
           }
       }
     } else if (EXT) {
@@ -183,12 +162,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
       const int k4 = li >> 2, j = li & 3;
       const int nq = wn * (COUT / WN) + nb * 32 + 4 * k4;
       const int oq = a.out_coff + nq, mq = a.mask_coff + nq;
-      float* ob4 = a.out + (((size_t)bsafe * out_blocks + (oq >> 4)) * HW) * 16 + (oq & 15);
-      const float* mb4 = a.mask + (((size_t)bsafe * mask_blocks + (mq >> 4)) * HW) * 16 + (mq & 15);
-      const float* rb4 = nullptr;
+      const size_t oidx4 = (((size_t)bsafe * out_blocks + (oq >> 4)) * HW) * 16 + (oq & 15);
+      const size_t midx4 = (((size_t)bsafe * mask_blocks + (mq >> 4)) * HW) * 16 + (mq & 15);
+      size_t ridx4 = 0;
       if (a.res) {
         const int rq = a.res_coff + nq;
-        rb4 = a.res + (((size_t)bsafe * res_blocks + (rq >> 4)) * HW) * 16 + (rq & 15);
+        ridx4 = (((size_t)bsafe * res_blocks + (rq >> 4)) * HW) * 16 + (rq & 15);
       }
       f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
       const f32x4 sc4 = a.scale ? *(const f32x4*)(a.scale + nq) : one4;
@@ -209,9 +188,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
           if (img_ok && gy < a.H && gx < a.W) {
             const size_t po = (size_t)(gy * a.W + gx) * 16;
             f32x4 v = {t0, t1, t2, t3};
-            const f32x4 mv = *(const f32x4*)(mb4 + po);
+            const f32x4 mv = tsr_ld4<IO16>(a.mask, midx4 + po);
             f32x4 rv = zero4;
-            if (rb4) rv = *(const f32x4*)(rb4 + po);
+            if (a.res) rv = tsr_ld4<IO16>(a.res, ridx4 + po);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               float x = (v[c] * accmul) * sc4[c] + rv[c];
@@ -221,7 +200,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
               s1[c] += x;
               s2[c] = fmaf(x, fmaf(mv[c], ba4[c], bb4[c]), s2[c]);
             }
-            *(f32x4*)(ob4 + po) = v;
+            tsr_st4<IO16>(a.out, oidx4 + po, v);
           }
         }
       if (a.bn_a) {

@@ -314,7 +314,7 @@ extern "C" int tsr_conv2d_slab_entries(int B, int H, int W) {
 // 3x3 / 5x5 kernels (tsr_conv_f16s_images: 4 images, 2 for the 1x1 and TSR_CONV_K32_256) and every one-plane 3x3 / 5x5 kernel put 4 images in a
 // workgroup, everything else 2 (must match launch_bf16s in conv_mfma_split16.hip).
 extern "C" int tsr_conv2d_slab_entries_ex(int B, int H, int W, int cout, int ks, int nsplit) {
-  const int img = nsplit == -2 ? tsr_conv_f16s_images(cout, ks) : ((ks > 1 && nsplit == 1) ? 4 : 2);
+  const int img = nsplit == -2 ? tsr_conv_f16s_images(cout, ks) : ((ks > 1 && (nsplit == 1 || nsplit == -1)) ? 4 : 2);
   return ((B + img - 1) / img) * ((W + 7) / 8) * ((H + 7) / 8) * img;
 }
 
@@ -346,7 +346,7 @@ extern "C" int tsr_conv2d_ex(const tsr_conv_desc* d, void* stream) {
   a.mask_scale = d->mask_scale; a.mask_shift = d->mask_shift;
   a.bn_a = d->bn_a; a.bn_b = d->bn_b;
   a.slab = d->slab; a.slab_cnt = d->slab_cnt;
-  if (d->nsplit != -2 && (d->nsplit < 0 || d->nsplit > 3)) return TSR_ERR_ARG;
+  if (d->nsplit != -2 && d->nsplit != -1 && (d->nsplit < 0 || d->nsplit > 3)) return TSR_ERR_ARG;
   a.in_amax = d->in_amax; a.w_inv_scale = d->w_inv_scale; a.out_amax = d->out_amax; a.w_amax = d->w_amax;
   if (d->nsplit == -2 && (!d->in_amax || (!d->w_amax && !(d->w_inv_scale > 0.f)))) return TSR_ERR_ARG;
   if (d->nsplit != 0) return tsr_conv2d_ex_bf16s(a, d->cout, d->ks, d->nsplit, (hipStream_t)stream);

@@ -99,7 +99,7 @@ constexpr int row_slots(int hh, int pixs, int rmod) {
 // workgroup (conv_fuse1x1.h); out / res then describe the 64-channel result.
 template <int KS, int COUT, int NS, bool EXT, bool F16, int WN, bool DBH = false, bool IO16 = false, bool FUSE2 = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArgs a) {
-  static_assert(!IO16 || (NS == 1 && !F16 && !EXT), "bf16 activation storage: plain bf16 operands, inference epilogue");
+  static_assert(!IO16 || (NS == 1 && !F16), "bf16 activation storage: plain bf16 operands");
   static_assert(!FUSE2 || (!EXT && COUT == 128 && ((NS == 2 && F16 && WN == 2 && !IO16) || (NS == 1 && IO16 && WN == 1))),
                 "fused 1x1: 128 channels, inference; fp16x3 (2 images / workgroup) or bf16 storage (4 images)");
   typedef typename Plane<F16>::T PT;
@@ -263,7 +263,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
     if (IO16) {
 #pragma unroll
       for (int k = 0; k < NIT; ++k)
-        if (st_dst[k] >= 0) *(float2*)(halo + hb * HALO_B + st_dst[k]) = make_float2(hv[k][0], hv[k][1]);
+        if (st_dst[k] >= 0) {
+          if (EXT && a.in_scale && st_src[k] >= 0) {
+            // producer's train-mode BN + ReLU on the stored bf16 pre-activation, fp32 arithmetic, rounded to the bf16
+            // MFMA operand (training with bf16 activation storage)
+            const bf16x4 zq = __builtin_bit_cast(bf16x4, make_float2(hv[k][0], hv[k][1]));
+            const int cq = c * 16 + ((tid + k * 256) & 3) * 4;
+            const f32x4 sc = *(const f32x4*)(a.in_scale + cq);
+            const f32x4 sh = *(const f32x4*)(a.in_shift + cq);
+            bf16x4 aq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) aq[j] = (__bf16)tsr_relu(fmaf((float)zq[j], sc[j], sh[j]));
+            *(bf16x4*)(halo + hb * HALO_B + st_dst[k]) = aq;
+          } else {
+            *(float2*)(halo + hb * HALO_B + st_dst[k]) = make_float2(hv[k][0], hv[k][1]);
+          }
+        }
       return;
     }
 #pragma unroll
@@ -648,8 +663,36 @@ extern "C" int tsr_pack_conv_weight_dgrad_f16s(const float* w_oihw, void* w_pack
   return tsr_check_launch();
 }
 
+// Training launches with bf16 ACTIVATION STORAGE (tsr_conv_desc.nsplit == -1): in / res / mask / out are bf16 CB16 tensors,
+// one bf16 plane, fp32 accumulation, the training epilogues (statistics from the fp32 accumulator, bf16 stores).
+template <int KS, int COUT>
+static int launch_b16_ex(const ConvArgs& a, hipStream_t st) {
+  if constexpr (KS > 1) {          // 4 images per workgroup, wave = image x all C_out (as launch_b16 / the NS = 1 train form)
+    const int grid4 = ((a.B + 3) / 4) * a.tiles_x * a.tiles_y;
+    hipLaunchKernelGGL((conv_mfma_split16_kernel<KS, COUT, 1, true, false, 1, false, true>), dim3(grid4), dim3(256), 0, st, a);
+    return tsr_check_launch();
+  }
+  const int grid = ((a.B + 1) / 2) * a.tiles_x * a.tiles_y;
+  hipLaunchKernelGGL((conv_mfma_split16_kernel<KS, COUT, 1, true, false, 2, false, true>), dim3(grid), dim3(256), 0, st, a);
+  return tsr_check_launch();
+}
+
+static int dispatch_b16_ex(const ConvArgs& a, int cout, int ks, hipStream_t st) {
+  if (cout == 64) {
+    if (ks == 1) return launch_b16_ex<1, 64>(a, st);
+    if (ks == 3) return launch_b16_ex<3, 64>(a, st);
+    if (ks == 5) return launch_b16_ex<5, 64>(a, st);
+  } else if (cout == 128) {
+    if (ks == 1) return launch_b16_ex<1, 128>(a, st);
+    if (ks == 3) return launch_b16_ex<3, 128>(a, st);
+    if (ks == 5) return launch_b16_ex<5, 128>(a, st);
+  }
+  return TSR_ERR_ARG;
+}
+
 // tsr_conv2d_ex with nsplit != 0 lands here (argument checks were done by the caller)
 int tsr_conv2d_ex_bf16s(const ConvArgs& a, int cout, int ks, int nsplit, hipStream_t st) {
+  if (nsplit == -1) return dispatch_b16_ex(a, cout, ks, st);                    // bf16 storage + bf16 operands
   if (nsplit == -2) return dispatch_bf16s<2, true, true>(a, cout, ks, st);      // fp16x3
   if (nsplit == 3) return dispatch_bf16s<3, true>(a, cout, ks, st);
   if (nsplit == 2) return dispatch_bf16s<2, true>(a, cout, ks, st);

@@ -152,6 +152,7 @@ extern "C" int tsr_bn_bwd_finalize(const float* slab, int entries, int C, double
 }
 
 // g[:, gcoff:gcoff+C] = c1*g + c2*z[:, zcoff:zcoff+C] + c3   (BN backward, elementwise, CB16, in place)
+template <bool B16>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g, int g_ctot, int g_coff,
                                                            const float* __restrict__ z, int z_ctot, int z_coff,
                                                            const float* __restrict__ c1, const float* __restrict__ c2,
@@ -165,16 +166,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g
     const int blk = r % (C >> 4);
     const int b = r / (C >> 4);
     const int c = blk * 16 + q * 4;
-    f32x4* gp = (f32x4*)(g + (((size_t)b * (g_ctot >> 4) + ((g_coff + c) >> 4)) * HW + pix) * 16 + q * 4);
-    const f32x4 zv = *(const f32x4*)(z + (((size_t)b * (z_ctot >> 4) + ((z_coff + c) >> 4)) * HW + pix) * 16 + q * 4);
+    const size_t gi = (((size_t)b * (g_ctot >> 4) + ((g_coff + c) >> 4)) * HW + pix) * 16 + q * 4;
+    const f32x4 zv = tsr_ld4<B16>(z, (((size_t)b * (z_ctot >> 4) + ((z_coff + c) >> 4)) * HW + pix) * 16 + q * 4);
     const f32x4 k1 = *(const f32x4*)(c1 + c), k2 = *(const f32x4*)(c2 + c), k3 = *(const f32x4*)(c3 + c);
-    f32x4 gv = *gp;
+    f32x4 gv = tsr_ld4<B16>(g, gi);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       gv[j] = fmaf(k1[j], gv[j], fmaf(k2[j], zv[j], k3[j]));
       amax = fmaxf(amax, fabsf(gv[j]));
     }
-    *gp = gv;
+    tsr_st4<B16>(g, gi, gv);
   }
   if (out_amax) {
 #pragma unroll
@@ -191,8 +192,22 @@ extern "C" int tsr_bn_bwd_apply(float* g, int g_ctot, int g_coff, const float* z
     return TSR_ERR_ARG;
   const size_t total4 = (size_t)B * C * HW / 4;
   const size_t grid = (total4 + 255) / 256;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid > 16384 ? 16384 : (int)grid), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid > 16384 ? 16384 : (int)grid), dim3(256), 0, (hipStream_t)stream,
                      g, g_ctot, g_coff, z, z_ctot, z_coff, c1, c2, c3, C, HW, total4, out_amax);
+  return tsr_check_launch();
+}
+
+// the same on bf16 CB16 tensors (training with bf16 activation storage): fp32 arithmetic, bf16 load / store
+extern "C" int tsr_bn_bwd_apply_b16(void* g, int g_ctot, int g_coff, const void* z, int z_ctot, int z_coff,
+                                    const float* c1, const float* c2, const float* c3, int C, int B, int HW,
+                                    void* stream) {
+  if (!g || !z || !c1 || !c2 || !c3 || (C & 15) || (g_ctot & 15) || (g_coff & 15) || (z_ctot & 15) || (z_coff & 15) ||
+      g_coff + C > g_ctot || z_coff + C > z_ctot)
+    return TSR_ERR_ARG;
+  const size_t total4 = (size_t)B * C * HW / 4;
+  const size_t grid = (total4 + 255) / 256;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid > 16384 ? 16384 : (int)grid), dim3(256), 0, (hipStream_t)stream,
+                     (float*)g, g_ctot, g_coff, (const float*)z, z_ctot, z_coff, c1, c2, c3, C, HW, total4, (float*)nullptr);
   return tsr_check_launch();
 }
 
@@ -209,6 +224,7 @@ __device__ __forceinline__ void bilin_src_t(int dst, float scale, int n_in, int&
 }
 
 // one workgroup per image-split; thread = (co = tid&63, pixel phase = tid>>6)
+template <bool B16>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ lr, int lr_ctot, int lr_coff,
                                                          int hin, int win, int sf, const float* __restrict__ dz,
                                                          int dz_ctot, int dz_coff, float* __restrict__ slab, int B,
@@ -245,9 +261,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
       up[i] = v;
     }
     __syncthreads();
-    const float* dzp = dz + (((size_t)b * (dz_ctot >> 4) + (oc >> 4)) * HW) * 16 + (oc & 15);
+    const size_t dzo = (((size_t)b * (dz_ctot >> 4) + (oc >> 4)) * HW) * 16 + (oc & 15);
     for (int p = ph; p < HW; p += 4) {
-      const float d = dzp[(size_t)p * 16];
+      const float d = tsr_ld1<B16>(dz, dzo + (size_t)p * 16);
       const int y = p / W, x = p - y * W;
 #pragma unroll
       for (int c = 0; c < 3; ++c)
@@ -268,9 +284,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
     slab[(size_t)blockIdx.x * 64 * 27 + i] = (red[i] + red[64 * 27 + i]) + (red[2 * 64 * 27 + i] + red[3 * 64 * 27 + i]);
 }
 
-extern "C" int tsr_stem_wgrad(const float* lr, int lr_ctot, int lr_coff, int hin, int win, int sf,
-                              const float* dz, int dz_ctot, int dz_coff, float* slab, int nsplit, int B,
-                              void* stream) {
+static int stem_wgrad_impl(const float* lr, int lr_ctot, int lr_coff, int hin, int win, int sf,
+                           const float* dz, int dz_ctot, int dz_coff, float* slab, int nsplit, int B,
+                           void* stream, bool b16) {
   if (!lr || !dz || !slab || nsplit <= 0 || B <= 0 || (dz_ctot & 15) || (dz_coff & 15) || dz_coff + 64 > dz_ctot)
     return TSR_ERR_ARG;
   const int H = hin * sf, W = win * sf;
@@ -279,12 +295,30 @@ extern "C" int tsr_stem_wgrad(const float* lr, int lr_ctot, int lr_coff, int hin
   if (fl * 4 > 160 * 1024) return TSR_ERR_ARG;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)stem_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)stem_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)stem_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nsplit), dim3(256), fl * 4, (hipStream_t)stream, lr, lr_ctot, lr_coff,
-                     hin, win, sf, dz, dz_ctot, dz_coff, slab, B, nsplit);
+  if (b16)
+    hipLaunchKernelGGL(stem_wgrad_kernel<true>, dim3(nsplit), dim3(256), fl * 4, (hipStream_t)stream, lr, lr_ctot, lr_coff,
+                       hin, win, sf, dz, dz_ctot, dz_coff, slab, B, nsplit);
+  else
+    hipLaunchKernelGGL(stem_wgrad_kernel<false>, dim3(nsplit), dim3(256), fl * 4, (hipStream_t)stream, lr, lr_ctot, lr_coff,
+                       hin, win, sf, dz, dz_ctot, dz_coff, slab, B, nsplit);
   return tsr_check_launch();
+}
+
+extern "C" int tsr_stem_wgrad(const float* lr, int lr_ctot, int lr_coff, int hin, int win, int sf,
+                              const float* dz, int dz_ctot, int dz_coff, float* slab, int nsplit, int B,
+                              void* stream) {
+  return stem_wgrad_impl(lr, lr_ctot, lr_coff, hin, win, sf, dz, dz_ctot, dz_coff, slab, nsplit, B, stream, false);
+}
+
+// dz is a bf16 CB16 tensor (training with bf16 activation storage)
+extern "C" int tsr_stem_wgrad_b16(const float* lr, int lr_ctot, int lr_coff, int hin, int win, int sf,
+                                  const void* dz, int dz_ctot, int dz_coff, float* slab, int nsplit, int B,
+                                  void* stream) {
+  return stem_wgrad_impl(lr, lr_ctot, lr_coff, hin, win, sf, (const float*)dz, dz_ctot, dz_coff, slab, nsplit, B, stream, true);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -292,6 +326,7 @@ extern "C" int tsr_stem_wgrad(const float* lr, int lr_ctot, int lr_coff, int hin
 //   dpre = dout*[out>0];  dh0[c,q] = sum_tap dpre[q - tap + 1]*w[c][tap];  dz_h0 = dh0*[h0>0]
 //   dW[c][tap] = sum_{b,q} dpre[q - tap + 1]*h0[c][q]  (flipped correlation: out pixel p = q - (tap-1))
 // ------------------------------------------------------------------------------------------
+template <bool B16>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                        const float* __restrict__ h0, int h_ctot, int cin,
                                                        const float* __restrict__ w, float* __restrict__ dz,
@@ -329,7 +364,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       }
     const size_t eo = (((size_t)b * (h_ctot >> 4) + blk) * HW + q) * 16 + qd * 4;
     const size_t zo = (((size_t)b * (dz_ctot >> 4) + blk) * HW + q) * 16 + qd * 4;
-    const f32x4 hv = *(const f32x4*)(h0 + eo);
+    const f32x4 hv = tsr_ld4<B16>(h0, eo);
     f32x4 r;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -340,7 +375,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
       r[j] = hv[j] > 0.f ? s : 0.f;
       amax = fmaxf(amax, fabsf(r[j]));
     }
-    *(f32x4*)(dz + zo) = r;
+    tsr_st4<B16>(dz, zo, r);
   }
   if (out_amax) {
 #pragma unroll
@@ -350,6 +385,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 }
 
 // thread = channel c (cin <= 256 => one thread per channel, remaining threads idle), grid = splits
+template <bool B16>
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                          const float* __restrict__ h0, int h_ctot, int cin,
                                                          float* __restrict__ slab, int B, int H, int W, int nsplit) {
@@ -374,9 +410,9 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
     }
     __syncthreads();
     if (ph < ngrp) {
-      const float* hp = h0 + (((size_t)b * (h_ctot >> 4) + (c >> 4)) * HW) * 16 + (c & 15);
+      const size_t ho = (((size_t)b * (h_ctot >> 4) + (c >> 4)) * HW) * 16 + (c & 15);
       for (int q = ph; q < HW; q += ngrp) {
-        const float hv = hp[(size_t)q * 16];
+        const float hv = tsr_ld1<B16>(h0, ho + (size_t)q * 16);
         const int y = q / W, x = q - y * W;
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
@@ -399,23 +435,38 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
   }
 }
 
-extern "C" int tsr_head_bwd(const float* dout, const float* out, const float* h0, int h_ctot, int cin,
-                            const float* w_oihw, float* dz_h0, int dz_ctot, float* wslab, int nsplit,
-                            int B, int H, int W, float* dz_amax, void* stream) {
+template <bool B16>
+static int head_bwd_impl(const float* dout, const float* out, const float* h0, int h_ctot, int cin,
+                         const float* w_oihw, float* dz_h0, int dz_ctot, float* wslab, int nsplit,
+                         int B, int H, int W, float* dz_amax, void* stream) {
   if (!dout || !out || !h0 || !w_oihw || !dz_h0 || !wslab || nsplit <= 0 || (cin & 15) || cin > 256 || cin > h_ctot ||
       cin > dz_ctot || (h_ctot & 15) || (dz_ctot & 15))
     return TSR_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int items = H * W * (cin >> 4) * 4;
-  hipLaunchKernelGGL(head_bwd_kernel, dim3((items + 255) / 256, B), dim3(256), (size_t)9 * cin * 4, st, dout, out,
+  hipLaunchKernelGGL(head_bwd_kernel<B16>, dim3((items + 255) / 256, B), dim3(256), (size_t)9 * cin * 4, st, dout, out,
                      h0, h_ctot, cin, w_oihw, dz_h0, dz_ctot, B, H, W, dz_amax);
   size_t fl = (size_t)(H + 2) * (W + 2);
   const size_t redf = (size_t)(256 / cin) * cin * 9;
   if (fl < redf) fl = redf;
   if (fl * 4 > 64 * 1024) return TSR_ERR_ARG;
-  hipLaunchKernelGGL(head_wgrad_kernel, dim3(nsplit), dim3(256), fl * 4, st, dout, out, h0, h_ctot, cin, wslab, B, H,
+  hipLaunchKernelGGL(head_wgrad_kernel<B16>, dim3(nsplit), dim3(256), fl * 4, st, dout, out, h0, h_ctot, cin, wslab, B, H,
                      W, nsplit);
   return tsr_check_launch();
+}
+
+extern "C" int tsr_head_bwd(const float* dout, const float* out, const float* h0, int h_ctot, int cin,
+                            const float* w_oihw, float* dz_h0, int dz_ctot, float* wslab, int nsplit,
+                            int B, int H, int W, float* dz_amax, void* stream) {
+  return head_bwd_impl<false>(dout, out, h0, h_ctot, cin, w_oihw, dz_h0, dz_ctot, wslab, nsplit, B, H, W, dz_amax, stream);
+}
+
+// h0 and dz_h0 are bf16 CB16 tensors (training with bf16 activation storage); dout / out stay fp32 NCHW
+extern "C" int tsr_head_bwd_b16(const float* dout, const float* out, const void* h0, int h_ctot, int cin,
+                                const float* w_oihw, void* dz_h0, int dz_ctot, float* wslab, int nsplit,
+                                int B, int H, int W, void* stream) {
+  return head_bwd_impl<true>(dout, out, (const float*)h0, h_ctot, cin, w_oihw, (float*)dz_h0, dz_ctot, wslab, nsplit, B, H,
+                             W, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -576,6 +627,7 @@ extern "C" int tsr_adam_l2_multi(const tsr_adam_chunk* chunks, int n_chunks, flo
 // Welford batch statistics of a CB16 channel slice (for the VALU stem, which has no stats
 // epilogue): entry = (image, 64-pixel chunk); slab/slab_cnt in the tsr_conv2d_ex epi_mode-1 format.
 // ------------------------------------------------------------------------------------------
+template <bool B16>
 __global__ __launch_bounds__(256) void cb16_stats_kernel(const float* __restrict__ z, int z_ctot, int z_coff,
                                                          int HW, int chunks, float* __restrict__ slab,
                                                          float* __restrict__ slab_cnt) {
@@ -583,14 +635,14 @@ __global__ __launch_bounds__(256) void cb16_stats_kernel(const float* __restrict
   const int tid = threadIdx.x, c = tid & 63, pg = tid >> 6;
   const int e = blockIdx.x, b = e / chunks, ch = e - b * chunks;
   const int oc = z_coff + c;
-  const float* zp = z + (((size_t)b * (z_ctot >> 4) + (oc >> 4)) * HW) * 16 + (oc & 15);
+  const size_t zo = (((size_t)b * (z_ctot >> 4) + (oc >> 4)) * HW) * 16 + (oc & 15);
   float v[16];
   float cnt = 0.f, sum = 0.f;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const int p = ch * 64 + pg * 16 + k;
     v[k] = 0.f;
-    if (p < HW) { v[k] = zp[(size_t)p * 16]; cnt += 1.f; sum += v[k]; }
+    if (p < HW) { v[k] = tsr_ld1<B16>(z, zo + (size_t)p * 16); cnt += 1.f; sum += v[k]; }
   }
   const float mean = cnt > 0.f ? sum / cnt : 0.f;
   float m2 = 0.f;
@@ -625,8 +677,18 @@ extern "C" int tsr_cb16_stats(const float* z, int z_ctot, int z_coff, int B, int
                               void* stream) {
   if (!z || !slab || !slab_cnt || (z_ctot & 15) || (z_coff & 15) || z_coff + 64 > z_ctot || B <= 0) return TSR_ERR_ARG;
   const int chunks = (HW + 63) / 64;
-  hipLaunchKernelGGL(cb16_stats_kernel, dim3(B * chunks), dim3(256), 0, (hipStream_t)stream, z, z_ctot, z_coff, HW,
+  hipLaunchKernelGGL(cb16_stats_kernel<false>, dim3(B * chunks), dim3(256), 0, (hipStream_t)stream, z, z_ctot, z_coff, HW,
                      chunks, slab, slab_cnt);
+  return tsr_check_launch();
+}
+
+// z is a bf16 CB16 tensor (training with bf16 activation storage: the stem's stored pre-activation)
+extern "C" int tsr_cb16_stats_b16(const void* z, int z_ctot, int z_coff, int B, int HW, float* slab, float* slab_cnt,
+                                  void* stream) {
+  if (!z || !slab || !slab_cnt || (z_ctot & 15) || (z_coff & 15) || z_coff + 64 > z_ctot || B <= 0) return TSR_ERR_ARG;
+  const int chunks = (HW + 63) / 64;
+  hipLaunchKernelGGL(cb16_stats_kernel<true>, dim3(B * chunks), dim3(256), 0, (hipStream_t)stream, (const float*)z, z_ctot,
+                     z_coff, HW, chunks, slab, slab_cnt);
   return tsr_check_launch();
 }
 

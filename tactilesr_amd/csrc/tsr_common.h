@@ -47,6 +47,32 @@ __device__ __forceinline__ float tsr_relu(float v) { return v < 0.f ? 0.f : v; }
 // power-of-two operand scale that multiplies the value next (staging loops of the split-operand kernels).
 __device__ __forceinline__ float tsr_relu_x2(float t) { return t + fabsf(t); }
 
+// 4 consecutive channels of a CB16 tensor whose storage type is fp32 (B16 = false) or bf16 (B16 = true, the
+// activation-storage format of the "bf16" configurations); `idx` counts ELEMENTS in both cases.
+typedef __bf16 tsr_bf16x4 __attribute__((ext_vector_type(4)));
+template <bool B16> __device__ __forceinline__ f32x4 tsr_ld4(const void* base, size_t idx) {
+  if constexpr (B16) {
+    const tsr_bf16x4 v = *(const tsr_bf16x4*)((const __bf16*)base + idx);
+    return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  } else {
+    return *(const f32x4*)((const float*)base + idx);
+  }
+}
+template <bool B16> __device__ __forceinline__ void tsr_st4(void* base, size_t idx, f32x4 v) {
+  if constexpr (B16) {
+    tsr_bf16x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = (__bf16)v[c];
+    *(tsr_bf16x4*)((__bf16*)base + idx) = o;
+  } else {
+    *(f32x4*)((float*)base + idx) = v;
+  }
+}
+template <bool B16> __device__ __forceinline__ float tsr_ld1(const void* base, size_t idx) {
+  if constexpr (B16) return (float)((const __bf16*)base)[idx];
+  else return ((const float*)base)[idx];
+}
+
 __device__ __forceinline__ size_t cb16_index(int b, int c, int pix, int C, int HW) {
   return (((size_t)b * (C >> 4) + (c >> 4)) * HW + pix) * 16 + (c & 15);
 }

@@ -320,7 +320,10 @@ extern "C" int tsr_conv2d_wgrad_bf16s(const float* a, int a_ctot, int a_coff, in
   // planes = 3: bf16 (fp32-equivalent, a_amax/dz_amax unused); planes = 1: plain bf16 operands (reduced
   // precision, the "bf16" configurations); planes = -2: fp16 two-plane split with the
   // power-of-two scales derived from the device scalars a_amax = max|a| (raw) and dz_amax = max|dz|
-  if (!a || !dz || !slab || B <= 0 || H <= 0 || W <= 0 || nsplit <= 0 || (planes != 3 && planes != 1 && planes != -2))
+  // planes = -1: plain bf16 operands read from bf16 CB16 TENSORS (`a`, `dz` address bf16 elements): training with bf16
+  // activation storage
+  if (!a || !dz || !slab || B <= 0 || H <= 0 || W <= 0 || nsplit <= 0 ||
+      (planes != 3 && planes != 1 && planes != -2 && planes != -1))
     return TSR_ERR_ARG;
   if (planes == -2 && (!a_amax || !dz_amax)) return TSR_ERR_ARG;
   if ((cin & 63) || (cout & 63) || (a_ctot & 15) || (a_coff & 15) || (dz_ctot & 15) || (dz_coff & 15) ||
@@ -330,7 +333,7 @@ extern "C" int tsr_conv2d_wgrad_bf16s(const float* a, int a_ctot, int a_coff, in
   // default: the transposed-LDS-read GEMM form (wgrad_mfma_tr16.hip); TSR_WGRAD_OLD=1 keeps the register-transpose
   // kernel below for A/B measurements
   static const bool use_old = getenv("TSR_WGRAD_OLD") != nullptr;
-  if (!use_old)
+  if (!use_old || planes == -1)
     return tsr_conv2d_wgrad_tr16(a, a_ctot, a_coff, cin, a_scale, a_shift, dz, dz_ctot, dz_coff, cout, ks, planes, a_amax,
                                  dz_amax, slab, bias_slab, nsplit, B, H, W, (hipStream_t)stream);
   WgradBArgs g;

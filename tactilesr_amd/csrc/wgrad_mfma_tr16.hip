@@ -95,8 +95,11 @@ struct WgradTGeom {
 // 4-wave tiles: the matrix pipe is theirs alone), waves [NWAVE, 2 NWAVE) only stage (global loads, fp32 -> fp16-plane
 // conversion, LDS writes) one item ahead.  In the symmetric form the two waves of a SIMD run the same code in
 // lockstep and its VALU time (32 %) adds to its MFMA time (59 %); with different programs they overlap.
-template <int KS, int KHW, int CO, int CI, int WM, int NS, bool F16, bool SPEC = false>
+// IO16 (NS = 1, bf16): `a` and `dz` are bf16 CB16 tensors (training with bf16 activation storage): staging copies 8-B
+// quads as they are (dz, and `a` without a fused transform) or applies relu(a*scale+shift) in fp32 and rounds back.
+template <int KS, int KHW, int CO, int CI, int WM, int NS, bool F16, bool SPEC = false, bool IO16 = false>
 __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) void wgrad_tr16_kernel(const WgradTArgs g) {
+  static_assert(!IO16 || (NS == 1 && !F16 && !SPEC), "bf16 tensors: one bf16 plane");
   typedef WgradTGeom<KS, KHW, CO, CI, WM, NS, F16> G;
   typedef typename TPlane<F16>::T PT;
   typedef typename TPlane<F16>::V8 PV8;
@@ -241,20 +244,34 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
       ntx = 0;
       if (++nty == g.tiles_y) { nty = 0; ++nb; }
     }
-    const float* dzb = g.dz + (((size_t)b * dz_blocks + (dz_c0 >> 4)) * HW + y0 * g.W + x0) * 16;
-    const float* ab = g.a + (((size_t)b * a_blocks + (a_c0 >> 4)) * HW + y0 * g.W + x0) * 16;
+    const size_t dzo = (((size_t)b * dz_blocks + (dz_c0 >> 4)) * HW + y0 * g.W + x0) * 16;
+    const size_t ao = (((size_t)b * a_blocks + (a_c0 >> 4)) * HW + y0 * g.W + x0) * 16;
+    const float* dzb = g.dz + dzo;
+    const float* ab = g.a + ao;
+    const __bf16* dzb16 = (const __bf16*)g.dz + dzo;
+    const __bf16* ab16 = (const __bf16*)g.a + ao;
     okd = oka = 0;
 #pragma unroll
     for (int j = 0; j < G::NIT_DZ; ++j) {
       const bool ok = (y0 + (rcd[j] >> 8) < g.H) & (x0 + (rcd[j] & 255) < g.W);
-      hd[j] = *(const f32x4*)(dzb + (ok ? offd[j] : safed[j]));
+      if constexpr (IO16) {      // 4 bf16 = 8 B, carried in the low half of the slot
+        const float2 t = *(const float2*)(dzb16 + (ok ? offd[j] : safed[j]));
+        hd[j][0] = t.x; hd[j][1] = t.y;
+      } else {
+        hd[j] = *(const f32x4*)(dzb + (ok ? offd[j] : safed[j]));
+      }
       okd |= (unsigned)ok << j;
     }
 #pragma unroll
     for (int j = 0; j < G::NIT_A; ++j) {
       const int gy = y0 + (rca[j] >> 8) + kh0 - P, gx = x0 + (rca[j] & 255) - P;
       const bool ok = (gy >= 0) & (gy < g.H) & (gx >= 0) & (gx < g.W);
-      ha[j] = *(const f32x4*)(ab + (ok ? offa[j] : safea[j]));
+      if constexpr (IO16) {
+        const float2 t = *(const float2*)(ab16 + (ok ? offa[j] : safea[j]));
+        ha[j][0] = t.x; ha[j][1] = t.y;
+      } else {
+        ha[j] = *(const f32x4*)(ab + (ok ? offa[j] : safea[j]));
+      }
       oka |= (unsigned)ok << j;
     }
   };
@@ -278,6 +295,40 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
   auto store_item = [&](int buf) {
     char* dzt = lds + buf * G::BUFB;
     char* at = dzt + NS * G::DZ_PLANEB;
+    if constexpr (IO16) {
+      typedef __bf16 io_bf16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int j = 0; j < G::NIT_DZ; ++j) {
+        if ((j + 1) * NT <= G::N_DZ || tid + j * NT < G::N_DZ) {
+          const bool ok = (okd >> j) & 1;
+          const float2 raw = ok ? make_float2(hd[j][0], hd[j][1]) : make_float2(0.f, 0.f);
+          if (do_bias) {
+            const io_bf16x4 q = __builtin_bit_cast(io_bf16x4, raw);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bsum[j][c] += (float)q[c];
+          }
+          *(float2*)(dzt + ldsd[j]) = raw;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < G::NIT_A; ++j) {
+        if ((j + 1) * NT <= G::N_A || tid + j * NT < G::N_A) {
+          const bool ok = (oka >> j) & 1;
+          float2 raw = ok ? make_float2(ha[j][0], ha[j][1]) : make_float2(0.f, 0.f);
+          if (g.a_scale && ok) {      // relu(bn(z)) of the stored bf16 pre-activation, fp32 arithmetic, back to bf16
+            const io_bf16x4 zq = __builtin_bit_cast(io_bf16x4, raw);
+            const int cq = ((ldsa[j] / G::A_BLKB) * 16) + ((ldsa[j] >> 1) & 12);
+            const f32x4 sc = *(const f32x4*)(tsc + cq), sh = *(const f32x4*)(tsc + CI + cq);
+            io_bf16x4 aq;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) aq[c] = (__bf16)tsr_relu(fmaf((float)zq[c], sc[c], sh[c]));
+            raw = __builtin_bit_cast(float2, aq);
+          }
+          *(float2*)(at + ldsa[j]) = raw;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < G::NIT_DZ; ++j) {
       if ((j + 1) * NT <= G::N_DZ || tid + j * NT < G::N_DZ) {
@@ -843,7 +894,7 @@ static bool tr16_m32() {       // TSR_WGRAD_M32=1: the 32x32x16 kernel for the f
   return on;
 }
 
-template <int KS, int NS, bool F16>
+template <int KS, int NS, bool F16, bool IO16 = false>
 static int launch_tr16(const WgradTArgs& g, hipStream_t st) {
   typedef WgradTCfg<KS, NS> C;
   if constexpr (F16 && NS == 2) {
@@ -871,12 +922,12 @@ static int launch_tr16(const WgradTArgs& g, hipStream_t st) {
   if (tr16_big(g.cout, g.cin, C::CI_BIG)) {
     typedef WgradTGeom<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG, NS, F16> G;
     const int grid = g.nsplit * G::NKG * (g.cout / 128) * (g.cin / C::CI_BIG);
-    hipLaunchKernelGGL((wgrad_tr16_kernel<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG, NS, F16>), dim3(grid), dim3(G::NT), 0, st, g);
+    hipLaunchKernelGGL((wgrad_tr16_kernel<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG, NS, F16, false, IO16>), dim3(grid), dim3(G::NT), 0, st, g);
     return tsr_check_launch();
   }
   typedef WgradTGeom<KS, C::KHW_SMALL, 64, 64, 32, NS, F16> G;
   const int grid = g.nsplit * G::NKG * (g.cout / 64) * (g.cin / 64);
-  hipLaunchKernelGGL((wgrad_tr16_kernel<KS, C::KHW_SMALL, 64, 64, 32, NS, F16>), dim3(grid), dim3(G::NT), 0, st, g);
+  hipLaunchKernelGGL((wgrad_tr16_kernel<KS, C::KHW_SMALL, 64, 64, 32, NS, F16, false, IO16>), dim3(grid), dim3(G::NT), 0, st, g);
   return tsr_check_launch();
 }
 
@@ -934,6 +985,11 @@ int tsr_conv2d_wgrad_tr16(const float* a, int a_ctot, int a_coff, int cin, const
     if (ks == 1) return launch_tr16<1, 1, false>(g, st);
     if (ks == 3) return launch_tr16<3, 1, false>(g, st);
     return launch_tr16<5, 1, false>(g, st);
+  }
+  if (planes == -1) {       // bf16 tensors (activation storage of the "bf16" configurations), one bf16 plane
+    if (ks == 1) return launch_tr16<1, 1, false, true>(g, st);
+    if (ks == 3) return launch_tr16<3, 1, false, true>(g, st);
+    return launch_tr16<5, 1, false, true>(g, st);
   }
   if (ks == 1) return launch_tr16<1, 2, true>(g, st);
   if (ks == 3) return launch_tr16<3, 2, true>(g, st);

@@ -86,6 +86,8 @@ def conv_ex(*, B, H, W, src: Act, w, cout, ks, out, out_ctot, out_coff, scale=No
 
 
 def _pack(w, cout, cin, ks, nsplit=0, w_amax=None):
+    if nsplit == -1:          # bf16 activation storage: the weights are the one-plane bf16 pack
+        nsplit = 1
     if nsplit == -2:
         n = _lib.load().tsr_conv_weight_bf16s_elems(cout, cin, ks, 2)
         wp = torch.empty(n, dtype=torch.float16, device=w.device)
@@ -102,6 +104,8 @@ def _pack(w, cout, cin, ks, nsplit=0, w_amax=None):
 
 
 def _pack_dgrad(w, cout, cin, ks, ci0, nprime, nsplit=0, w_amax=None):
+    if nsplit == -1:
+        nsplit = 1
     if nsplit == -2:
         n = _lib.load().tsr_conv_weight_bf16s_elems(nprime, cout, ks, 2)
         wp = torch.empty(n, dtype=torch.float16, device=w.device)
@@ -141,9 +145,14 @@ class TrainEngine:
         import os
         # conv arithmetic of the train path: 0 = fp32 MFMA, 3 = split-bf16 (six products, fp32-equivalent),
         # -2 = two scaled fp16 planes (three products; operand scales from device-side max|.| scalars),
-        # 1 = plain bf16 operands with fp32 accumulation (reduced precision: BASELINE's "bf16" configurations only)
-        self.nsplit = {"f32": 0, "bf16x6": 3, "fp16x3": -2, "bf16": 1}[os.environ.get("TSR_TRAIN_IMPL", "fp16x3")]
+        # -1 = "bf16": BASELINE's "bf16" configurations -- every stored activation / gradient tensor is bf16 CB16 (saved
+        #      pre-activations z, dz, dgrad outputs), plain bf16 MFMA operands, fp32 accumulation, fp32 master weights,
+        #      BatchNorm statistics, weight gradients and Adam (the reference's reduced-precision switch is the unused
+        #      fp16 autocast of cpu/trainer.py:96,203,346-362); 1 = "bf16op": bf16 operands on fp32 tensors (A/B only)
+        self.nsplit = {"f32": 0, "bf16x6": 3, "fp16x3": -2, "bf16": -1, "bf16op": 1}[os.environ.get("TSR_TRAIN_IMPL", "fp16x3")]
         self.f16 = self.nsplit == -2
+        self.io16 = self.nsplit == -1
+        self.act_dtype = torch.bfloat16 if self.io16 else torch.float32
 
     def _timed(self, key):
         """Context manager: bracket the launches inside with two HIP events when profiling is on."""
@@ -207,6 +216,15 @@ class TrainEngine:
              ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), ptr(c.work), stream())
         bn.num_batches_tracked.add_(1)
         return vec   # rows: scale, shift, xhat_a, xhat_b
+
+    def _stem(self, x, ctot_in, coff, A, hin, win, sf, w, dst, relu, B, am):
+        """bilinear x sf + conv 3 -> 64 (raw or ReLU'd) into a 64-channel CB16 buffer of the engine's storage type."""
+        if self.io16:
+            call("tsr_stem_fwd_b16", ptr(x), _I(ctot_in), _I(coff), _I(A), _I(hin), _I(win), _I(sf), ptr(w), ptr(None),
+                 ptr(None), ptr(dst), _I(64), _I(0), _I(relu), _I(B), stream())
+        else:
+            call("tsr_stem_fwd", ptr(x), _I(ctot_in), _I(coff), _I(A), _I(hin), _I(win), _I(sf), ptr(w), ptr(None),
+                 ptr(None), ptr(dst), _I(64), _I(0), _I(relu), _I(B), ptr(am), stream())
 
     def _entries(self, c, cout, ks):
         """Statistics-slab entries the conv launch (cout, ks) of this engine's arithmetic writes."""
@@ -300,7 +318,7 @@ class TrainEngine:
         st_entries = c.st_entries
 
         def buf(ch):
-            return torch.empty(B * ch * HW, dtype=torch.float32, device=dev)
+            return torch.empty(B * ch * HW, dtype=self.act_dtype, device=dev)
 
         self._weight_scales(c)
         new_amax = self._amax_pool(c, dev)
@@ -313,10 +331,9 @@ class TrainEngine:
         for t, seq in enumerate(m.inputLayer_pattern_list):
             z1 = buf(64)
             am = new_amax()
-            call("tsr_stem_fwd", ptr(x), _I(ctot_in), _I(A * t), _I(A), _I(hin), _I(win), _I(sf),
-                 ptr(seq[1].weight.detach()), ptr(None), ptr(None), ptr(z1), _I(64), _I(0), _I(0), _I(B), ptr(am),
-                 stream())
-            call("tsr_cb16_stats", ptr(z1), _I(64), _I(0), _I(B), _I(HW), ptr(c.slab), ptr(c.slab_cnt), stream())
+            self._stem(x, ctot_in, A * t, A, hin, win, sf, seq[1].weight.detach(), z1, 0, B, am)
+            call("tsr_cb16_stats_b16" if self.io16 else "tsr_cb16_stats", ptr(z1), _I(64), _I(0), _I(B), _I(HW),
+                 ptr(c.slab), ptr(c.slab_cnt), stream())
             v1 = self._bn_finalize(c, None, seq[2], c.slab, c.slab_cnt, st_entries, 64)
             c.z1.append(z1)
             c.bn1.append(v1)
@@ -348,9 +365,7 @@ class TrainEngine:
         # ---- force branch
         c.f0 = buf(64)
         am_f0 = new_amax()
-        call("tsr_stem_fwd", ptr(x), _I(ctot_in), _I(0), _I(A), _I(hin), _I(win), _I(sf),
-             ptr(m.input_layer_force[1].weight.detach()), ptr(None), ptr(None), ptr(c.f0), _I(64), _I(0), _I(1),
-             _I(B), ptr(am_f0), stream())
+        self._stem(x, ctot_in, 0, A, hin, win, sf, m.input_layer_force[1].weight.detach(), c.f0, 1, B, am_f0)
         F0 = Act(c.f0, 64, 0, 64, amax=am_f0)
         c.res = []
         n_res = len(m.forceFeatureExtra_layer)
@@ -370,8 +385,8 @@ class TrainEngine:
         conv_ex(B=B, H=H, W=W, src=Act(c.hcat, 128, 0, 128, amax=c.am_hcat), w=wh, cout=128, ks=3, out=c.h0,
                 out_ctot=128, out_coff=0, relu=1, nsplit=self.nsplit, w_amax=wish)
         out = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
-        call("tsr_head_fwd", ptr(c.h0), _I(128), _I(128), ptr(m.output_layer[2].weight.detach()), ptr(out), _I(1),
-             _I(B), _I(H), _I(W), stream())
+        call("tsr_head_fwd_b16" if self.io16 else "tsr_head_fwd", ptr(c.h0), _I(128), _I(128),
+             ptr(m.output_layer[2].weight.detach()), ptr(out), _I(1), _I(B), _I(H), _I(W), stream())
         c.out = out
         self.last_ctx = c if self.keep_ctx else None
         return out, c
@@ -479,8 +494,12 @@ class TrainEngine:
         call("tsr_bn_bwd_finalize", ptr(c.slab), _I(c.last_entries), _I(C), _D(float(c.B * c.HW)),
              ptr(bn_vec[0]), ptr(bn_vec[2]), ptr(bn_vec[3]), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]),
              ptr(out[4]), ptr(c.work), stream())
-        call("tsr_bn_bwd_apply", ptr(g_buf), _I(g_ctot), _I(g_coff), ptr(z.buf), _I(z.ctot), _I(z.coff + zoff),
-             ptr(out[2]), ptr(out[3]), ptr(out[4]), _I(C), _I(c.B), _I(c.HW), ptr(out_amax), stream())
+        if self.io16:
+            call("tsr_bn_bwd_apply_b16", ptr(g_buf), _I(g_ctot), _I(g_coff), ptr(z.buf), _I(z.ctot), _I(z.coff + zoff),
+                 ptr(out[2]), ptr(out[3]), ptr(out[4]), _I(C), _I(c.B), _I(c.HW), stream())
+        else:
+            call("tsr_bn_bwd_apply", ptr(g_buf), _I(g_ctot), _I(g_coff), ptr(z.buf), _I(z.ctot), _I(z.coff + zoff),
+                 ptr(out[2]), ptr(out[3]), ptr(out[4]), _I(C), _I(c.B), _I(c.HW), ptr(out_amax), stream())
         return out   # rows 0,1 = dgamma, dbeta
 
     def _res_bwd(self, c, s, rb, name, dpre: Act, grads, new_amax, buf, mask_input=True):
@@ -556,7 +575,7 @@ class TrainEngine:
         grads = GradSink(self, dict(m.named_parameters()), dev)
 
         def buf(ch):
-            return torch.empty(B * ch * HW, dtype=torch.float32, device=dev)
+            return torch.empty(B * ch * HW, dtype=self.act_dtype, device=dev)
 
         new_amax = self._amax_pool(c, dev)      # a gradient tensor consumed by an MFMA launch carries max|.|
         dout = dout.contiguous().float()
@@ -565,9 +584,14 @@ class TrainEngine:
         dz_h0 = buf(128)
         am_dzh0 = new_amax()
         wslab = torch.empty(ns * 128 * 9, dtype=torch.float32, device=dev)
-        call("tsr_head_bwd", ptr(dout), ptr(c.out), ptr(c.h0), _I(128), _I(128),
-             ptr(m.output_layer[2].weight.detach()), ptr(dz_h0), _I(128), ptr(wslab), _I(ns), _I(B), _I(H), _I(W),
-             ptr(am_dzh0), stream())
+        if self.io16:
+            call("tsr_head_bwd_b16", ptr(dout), ptr(c.out), ptr(c.h0), _I(128), _I(128),
+                 ptr(m.output_layer[2].weight.detach()), ptr(dz_h0), _I(128), ptr(wslab), _I(ns), _I(B), _I(H), _I(W),
+                 stream())
+        else:
+            call("tsr_head_bwd", ptr(dout), ptr(c.out), ptr(c.h0), _I(128), _I(128),
+                 ptr(m.output_layer[2].weight.detach()), ptr(dz_h0), _I(128), ptr(wslab), _I(ns), _I(B), _I(H), _I(W),
+                 ptr(am_dzh0), stream())
         gw = grads.dest("output_layer.2.weight", m.output_layer[2].weight.shape)
         call("tsr_reduce_splits", ptr(wslab), ptr(gw), _L(128 * 9), _I(ns), _F(1.0), stream())
         grads.put("output_layer.2.weight", gw)
@@ -589,8 +613,8 @@ class TrainEngine:
                                  new_amax, buf)
         ns = max(1, min(B, 2048))     # image splits: ~8 resident workgroups per CU hide the load latency
         sslab = torch.empty(ns * 64 * 27, dtype=torch.float32, device=dev)
-        call("tsr_stem_wgrad", ptr(c.x), _I(c.x.shape[1]), _I(0), _I(c.hin), _I(c.win), _I(m.scale_factor),
-             ptr(dpre.buf), _I(dpre.ctot), _I(dpre.coff), ptr(sslab), _I(ns), _I(B), stream())
+        call("tsr_stem_wgrad_b16" if self.io16 else "tsr_stem_wgrad", ptr(c.x), _I(c.x.shape[1]), _I(0), _I(c.hin),
+             _I(c.win), _I(m.scale_factor), ptr(dpre.buf), _I(dpre.ctot), _I(dpre.coff), ptr(sslab), _I(ns), _I(B), stream())
         gw = grads.dest("input_layer_force.1.weight", m.input_layer_force[1].weight.shape)
         call("tsr_reduce_splits", ptr(sslab), ptr(gw), _L(64 * 27), _I(ns), _F(1.0), stream())
         grads.put("input_layer_force.1.weight", gw)
@@ -630,8 +654,8 @@ class TrainEngine:
             grads.put_copy(name + ".2.bias", r[1])
             ns = max(1, min(B, 2048))     # image splits: ~8 resident workgroups per CU hide the load latency
             sslab = torch.empty(ns * 64 * 27, dtype=torch.float32, device=dev)
-            call("tsr_stem_wgrad", ptr(c.x), _I(c.x.shape[1]), _I(m.axisCnt * t), _I(c.hin), _I(c.win),
-                 _I(m.scale_factor), ptr(g1), _I(64), _I(0), ptr(sslab), _I(ns), _I(B), stream())
+            call("tsr_stem_wgrad_b16" if self.io16 else "tsr_stem_wgrad", ptr(c.x), _I(c.x.shape[1]), _I(m.axisCnt * t),
+                 _I(c.hin), _I(c.win), _I(m.scale_factor), ptr(g1), _I(64), _I(0), ptr(sslab), _I(ns), _I(B), stream())
             gw = grads.dest(name + ".1.weight", seq[1].weight.shape)
             call("tsr_reduce_splits", ptr(sslab), ptr(gw), _L(64 * 27), _I(ns), _F(1.0), stream())
             grads.put(name + ".1.weight", gw)
@@ -696,12 +720,12 @@ class BlockEngine(TrainEngine):
         new_amax = self._amax_pool(c, dev)
 
         def buf(ch):
-            return torch.empty(B * ch * H * W, dtype=torch.float32, device=dev)
+            return torch.empty(B * ch * H * W, dtype=self.act_dtype, device=dev)
 
         am_x = new_amax()
         if am_x is not None:
             am_x.copy_(x.abs().amax())          # device-side: the operand scale of the first convs
-        X = Act(to_cb16(x), 64, 0, 64, amax=am_x)
+        X = Act(to_cb16(x).to(self.act_dtype), 64, 0, 64, amax=am_x)
         out, am_o = buf(64), new_amax()
         fwd = self._msrb_fwd if self.kind == "msrb" else self._res_fwd
         c.s = fwd(c, self.block, X, out, 64, 0, am_o, new_amax, buf)
@@ -717,11 +741,11 @@ class BlockEngine(TrainEngine):
         new_amax = self._amax_pool(c, dev)
 
         def buf(ch):
-            return torch.empty(B * ch * H * W, dtype=torch.float32, device=dev)
+            return torch.empty(B * ch * H * W, dtype=self.act_dtype, device=dev)
 
         # gradient w.r.t. the block output BEFORE its ReLU (in the whole-network engine the consumer's dgrad epilogue
         # applies this mask; here it is one elementwise pass over the boundary tensor)
-        d = to_cb16(dout.contiguous().float()) * (c.s.Y.buf > 0)
+        d = (to_cb16(dout.contiguous().float()) * (c.s.Y.buf > 0)).to(self.act_dtype)
         am = new_amax()
         if am is not None:
             am.copy_(d.abs().amax())

@@ -411,6 +411,89 @@ def test_bf16_train_mode_is_a_reduced_precision_of_the_same_step(T, golden, monk
         assert cos > 0.98, (k, cos)
 
 
+def _emulated_step(sd, LR, HR, **kw):
+    """Loss, gradients and new running statistics of the oracle's bf16-emulating train forward (`emulate="bf16"`)."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if O.is_trainable(k)}
+    full = dict(sd)
+    full.update(leaves)
+    ns = {}
+    out = O.tactilesr_forward(full, LR, training=True, new_stats=ns, emulate="bf16", **kw)
+    loss = F.mse_loss(out, HR)
+    gl = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
+    grads = {k: (g if g is not None else torch.zeros_like(leaves[k])) for k, g in zip(leaves, gl)}
+    return float(loss), grads, ns, out.detach()
+
+
+@pytest.mark.parametrize("cfg,B,seed", [(dict(patternFeatureExtraLayerCnt=2), 4, 211),
+                                        (dict(seqsCnt=2, patternFeatureExtraLayerCnt=1), 3, 977),
+                                        (dict(seqsCnt=8, scale_factor=25, patternFeatureExtraLayerCnt=1), 2, 1977)])
+def test_train_step_bf16_storage_vs_bf16_emulating_oracle(T, cfg, B, seed, monkeypatch):
+    """TSR_TRAIN_IMPL=bf16 -- BASELINE's "bf16" train configurations: every stored activation / gradient tensor is bf16
+    CB16 (saved pre-activations z, dz, dgrad outputs), bf16 MFMA operands, fp32 accumulation, fp32 master weights /
+    BatchNorm statistics / weight gradients -- against the oracle's restatement of THAT arithmetic in the forward pass
+    (bf16 rounding of every stored tensor and of the conv weights, statistics from the fp32 accumulator, fp32 epilogues;
+    the reference has no bf16 numerics): loss within 2e-3, output max-norm within 2^-6 (two bf16 evaluations decorrelate
+    to about one ulp RMS, see the eval test), running statistics within 2e-3, every parameter gradient pointing the same way as the
+    emulated one (cosine >= 0.995; the oracle's backward keeps fp32 gradient tensors, the device rounds them to bf16)."""
+    monkeypatch.setenv("TSR_TRAIN_IMPL", "bf16")
+    sf, Tn = cfg.get("scale_factor", 10), cfg.get("seqsCnt", 1)
+    sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    LR = torch.rand(B, 3 * Tn, 4, 4, generator=g) * 8
+    HR = torch.rand(B, 1, 4 * sf, 4 * sf, generator=g) * 25
+    l_e, g_e, ns_e, out_e = _emulated_step(sd, LR, HR, scale_factor=sf)
+    m = T.TactileSR(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    eng = _debug_engine(m)
+    assert eng.io16 and eng.act_dtype == torch.bfloat16
+    out = m(LR.cuda())
+    ctx = eng.last_ctx
+    assert all(t.dtype == torch.bfloat16 for t in (ctx.hcat, ctx.h0, ctx.zf, ctx.catT, ctx.blocks[0].cat1, ctx.blocks[0].cat2))
+    loss = F.mse_loss(out, HR.cuda())
+    e_out = relerr(out, out_e)
+    assert e_out <= 2.0 ** -6 and abs(loss.item() - l_e) <= 2e-3 * abs(l_e), (e_out, loss.item(), l_e)
+    loss.backward()
+    new_sd = m.state_dict()
+    for k, v in ns_e.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert relerr(new_sd[k], v) < 2e-3, k
+    worst = 1.0
+    for k, p in m.named_parameters():
+        ref = g_e[k].double().flatten()
+        got = p.grad.detach().cpu().double().flatten()
+        if float(ref.abs().max()) < 1e-6 * float(max(v.abs().max() for v in g_e.values())):
+            continue                                    # conv bias in front of a train-mode BN: gradient == 0 + noise
+        cos = float(got @ ref / (got.norm() * ref.norm()).clamp_min(1e-30))
+        worst = min(worst, cos)
+        assert cos >= 0.995, (k, cos)
+        assert abs(float(got.norm() / ref.norm()) - 1.0) < 5e-2, (k, float(got.norm() / ref.norm()))
+    print(f"[bf16-storage train vs bf16 oracle {cfg} B={B}] out {e_out:.2e}, loss {abs(loss.item() - l_e) / abs(l_e):.2e}, "
+          f"worst gradient cosine {worst:.5f}")
+
+
+def test_bf16_storage_train_step_tiling_invariance(T, monkeypatch):
+    """Larger batch through the bf16-storage train path (B = 512 = 32 frames x 16): replicas bit-identical, loss equal to
+    the oracle's emulated loss on the 32 base frames within 2e-3."""
+    monkeypatch.setenv("TSR_TRAIN_IMPL", "bf16")
+    torch.manual_seed(5)
+    m = T.TactileSR(patternFeatureExtraLayerCnt=2)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(6)
+    LRb, HRb = torch.rand(32, 3, 4, 4, generator=g) * 8, torch.rand(32, 1, 40, 40, generator=g) * 25
+    m = m.cuda().train()
+    out = m(LRb.repeat(16, 1, 1, 1).cuda())
+    loss = F.mse_loss(out, HRb.repeat(16, 1, 1, 1).cuda())
+    loss.backward()
+    o = out.view(16, 32, -1)
+    assert torch.equal(o, o[:1].expand_as(o))
+    l_e, g_e, _, _ = _emulated_step(sd, LRb, HRb)
+    assert abs(loss.item() - l_e) <= 2e-3 * abs(l_e)
+    k = "patternFeatureExtra_layer.1.conv_5_2.0.weight"
+    got, ref = dict(m.named_parameters())[k].grad.cpu().double().flatten(), g_e[k].double().flatten()
+    assert float(got @ ref / (got.norm() * ref.norm())) >= 0.995
+
+
 def test_non_finite_loss_raises_like_the_reference_trainer(T):
     """cpu/trainer.py:280-284: a NaN / Inf loss raises FloatingPointError.  A NaN taxel, an Inf taxel and a diverged (NaN)
     weight must each reach the loss through the train-mode path (batch statistics couple every frame, so the whole
