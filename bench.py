@@ -424,7 +424,9 @@ def run_train(args, world, rank, dev):
                            "frac_of_peak": round(value / world * train_flop / peak, 4),
                            "mfma_pipe_util": round(value / world * train_flop * nprod / peak, 4),
                            "algorithmic_vs_f32_mfma_peak": round(value / world * train_flop / PEAK_F32_MFMA, 4),
-                           "ms_per_step_by_family": {k: round(v, 2) for k, v in sorted(fam.items())}},
+                           "ms_per_step_by_family": {k: round(v, 2) for k, v in sorted(fam.items())},
+                           "ms_per_launch": {"%s_k%d_co%d_ci%d" % k: round(sum(a.elapsed_time(b) for a, b in v) / max(1, len(v)), 3)
+                                             for k, v in sorted(prof.items())}},
             "loss": float(ld["total_loss"].detach()),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -351,7 +351,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
   }
 
   // ---- prologue: halo(0), W(0), W(1) in LDS; W(2) in flight
-  constexpr bool WDMA = !EXT;       // (LDS-DMA in the training instantiations: neutral here, -5 ms/step in the K = 32 kernel)
+#ifdef TSR_EXP_B16_EXT_NODMA
+  constexpr bool WDMA = !EXT;
+#else
+  // (LDS-DMA in the fp32-storage training instantiations: neutral here, -5 ms/step in the K = 32 kernel; the one-plane
+  // bf16-storage training form moves 3x the weight bytes per MFMA and gains from it like its inference form does)
+  constexpr bool WDMA = !EXT || IO16;
+#endif
   f32x4 hv[NIT], wreg[WDMA ? 1 : WV];
   load_halo(0, hv);
   if constexpr (WDMA) {
