@@ -322,9 +322,11 @@ int tsr_psnr_ssim(const float* a, const float* b, int B, int n, double psnr_div,
 int tpsf_forward(const float* depth, const float* alpha_beta, float* HR, float* LR_deg, float* psf,
                  int B, void* stream);
 /* d loss / d (alpha, beta, gamma) (B,3) given d loss / d LR_deg (B,16); plateau pixels carry no
- * gradient, depth carries none (autograd of :118-125 as used by train/tPSFNet_train.py:180-190). */
-int tpsf_backward(const float* depth, const float* alpha_beta, const float* dLR_deg, float* d_alpha_beta,
-                  int B, void* stream);
+ * gradient, depth carries none (autograd of :118-125 as used by train/tPSFNet_train.py:180-190).  HR = the forward
+ * output of the same (depth, alpha_beta) (tpsf_forward: the reductions over it are not recomputed); work: B*100*100
+ * floats of scratch (the per-pixel dL/dHR between the two kernels). */
+int tpsf_backward(const float* depth, const float* alpha_beta, const float* HR, const float* dLR_deg,
+                  float* d_alpha_beta, float* work, int B, void* stream);
 /* C[i][j] = act(sum_k A(i,k)B(k,j) + bias[j]), A(i,k)=A[i*sa0+k*sa1], B(k,j)=B[k*sb0+j*sb1]; act 0 none,
  * 1 ReLU, 2 Softplus: the nn.Linear layers of MLP_layer (:26-36) and their backward GEMMs. */
 int tsr_sgemm(const float* A, long long sa0, long long sa1, const float* B, long long sb0, long long sb1,

@@ -69,7 +69,7 @@ SIGNATURES = {
     "tsr_adam_l2_multi": [_P, _I, _F, c_double, c_double, _F, _F, _I, _P],
     "tsr_psnr_ssim": [_P, _P, _I, _I, c_double, c_double, c_double, c_double, _P, _P, _P],
     "tpsf_forward": [_P, _P, _P, _P, _P, _I, _P],
-    "tpsf_backward": [_P, _P, _P, _P, _I, _P],
+    "tpsf_backward": [_P, _P, _P, _P, _P, _P, _I, _P],
     "tsr_sgemm": [_P, _L, _L, _P, _L, _L, _P, _P, _I, _I, _I, _I, _P],
     "tsr_sgemm_splitk": [_P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _I, _P],
     "tsr_act_bwd": [_P, _P, _L, _I, _P],

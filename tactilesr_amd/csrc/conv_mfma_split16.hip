@@ -669,6 +669,105 @@ extern "C" int tsr_pack_conv_weight_dgrad_f16s(const float* w_oihw, void* w_pack
   return tsr_check_launch();
 }
 
+// 1x1 convolution on bf16 CB16 tensors as a STREAMING GEMM (training with bf16 activation storage: the MSRB `confusion`
+// forward, 256 -> 64 with a virtual input and a residual, and its two dgrad launches, 64 -> 128 with the ReLU-mask /
+// BatchNorm-sum epilogue).  The layer is HBM-bound (0.1 ms of MFMA work against 2-2.5 GB per launch at B = 2048) and the
+// tiled kernel above spends its time on barriers: one K = 16 step of 8 MFMAs per (slab staging, LDS round trip,
+// __syncthreads) -- 2.6 TB/s.  Here nothing but the weights touches LDS: a CB16 line of bf16 is 32 B, so the A fragment
+// of v_mfma_f32_32x32x16_bf16 (lane = (pixel, k half), 8 consecutive channels) IS one 16-B global load per lane, the
+// 32 lanes of a patch row pair cover 256-B runs, and a wave keeps all its loads of a 4-block chunk in flight.  Persistent
+// workgroups (the packed weight matrix is staged once), wave = one image x 8x8 patch x ALL C_out, so the shared
+// epilogue (conv_epilogue<COUT, true, 1, true>) applies unchanged with 4 images per slab group.
+template <int COUT>
+__global__ __launch_bounds__(256, 2) void conv1x1_b16_ex_kernel(const ConvArgs a) {
+  constexpr int NB = COUT / 32;
+  extern __shared__ __attribute__((aligned(16))) char lds1[];      // [cin/16][2][COUT][8] bf16, then (scale, shift)[cin]
+  const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+  const int h = lane >> 5, li = lane & 31;
+  const int nblk = a.cin >> 4;
+  const int wbytes = a.cin * COUT * 2;
+  for (int i = tid * 16; i < wbytes; i += 256 * 16) *(f32x4*)(lds1 + i) = *(const f32x4*)((const char*)a.wp + i);
+  float* tsc = (float*)(lds1 + wbytes);
+  if (a.in_scale)
+    for (int c = tid; c < a.cin; c += 256) { tsc[c] = a.in_scale[c]; tsc[a.cin + c] = a.in_shift[c]; }
+  __syncthreads();
+
+  const int HW = a.H * a.W, tpi = a.tiles_x * a.tiles_y;
+  const int in_blocks = a.in_ctot >> 4;
+  const int total = ((a.B + 3) >> 2) * tpi;
+  const bf16x8* wl = (const bf16x8*)lds1 + (h * COUT + li);          // + blk * 2 * COUT + nb * 32
+  for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    const int ig = t / tpi, trem = t - ig * tpi;
+    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const int y0 = ty * 8, x0 = tx * 8, b0 = ig * 4;
+    const int b = b0 + wm < a.B ? b0 + wm : a.B - 1;       // rows of an absent image / pixel compute on valid data and
+    int pix[2];                                            // are never stored (the epilogue tests the real coordinates)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      int gy = y0 + 4 * mb + (li >> 3), gx = x0 + (li & 7);
+      gy = gy < a.H ? gy : a.H - 1;
+      gx = gx < a.W ? gx : a.W - 1;
+      pix[mb] = gy * a.W + gx;
+    }
+    const __bf16* inb = (const __bf16*)a.in + ((size_t)b * in_blocks + (a.in_coff >> 4)) * HW * 16 + h * 8;
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+    for (int c0 = 0; c0 < nblk; c0 += 4) {                 // chunks of 4 channel blocks: 8 loads in flight per lane
+      bf16x8 fa[4][2];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const int c = c0 + k < nblk ? c0 + k : nblk - 1;
+          fa[k][mb] = *(const bf16x8*)(inb + ((size_t)c * HW + pix[mb]) * 16);
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (c0 + k < nblk) {
+          const int c = c0 + k;
+          if (a.in_scale) {      // producer's train-mode BN + ReLU on the stored pre-activation, fp32, back to the bf16 operand
+            const f32x4 s0 = *(const f32x4*)(tsc + c * 16 + h * 8), s1 = *(const f32x4*)(tsc + c * 16 + h * 8 + 4);
+            const f32x4 t0 = *(const f32x4*)(tsc + a.cin + c * 16 + h * 8), t1 = *(const f32x4*)(tsc + a.cin + c * 16 + h * 8 + 4);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const float sc = j < 4 ? s0[j & 3] : s1[j & 3], sh = j < 4 ? t0[j & 3] : t1[j & 3];
+                fa[k][mb][j] = (__bf16)tsr_relu(fmaf((float)fa[k][mb][j], sc, sh));
+              }
+          }
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const bf16x8 fb = wl[(size_t)c * 2 * COUT + nb * 32];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) acc[mb][nb] = Plane<false>::mfma(fa[k][mb], fb, acc[mb][nb]);
+          }
+        }
+      }
+    }
+    conv_epilogue<COUT, true, 1, true>(a, acc, t, b0, y0, x0, wm, 0, h, li, HW, 1.f);
+  }
+}
+
+template <int COUT>
+static int launch_1x1_b16_ex(const ConvArgs& a, hipStream_t st) {
+  const int total = ((a.B + 3) / 4) * a.tiles_x * a.tiles_y;
+  const size_t smem = (size_t)a.cin * COUT * 2 + (size_t)a.cin * 8;
+  if (smem > 72 * 1024) return TSR_ERR_ARG;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv1x1_b16_ex_kernel<COUT>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv1x1_b16_ex_kernel<COUT>), dim3(total < 512 ? total : 512), dim3(256), smem, st, a);
+  return tsr_check_launch();
+}
+
 // Training launches with bf16 ACTIVATION STORAGE (tsr_conv_desc.nsplit == -1): in / res / mask / out are bf16 CB16 tensors,
 // one bf16 plane, fp32 accumulation, the training epilogues (statistics from the fp32 accumulator, bf16 stores).
 template <int KS, int COUT>
@@ -677,6 +776,14 @@ static int launch_b16_ex(const ConvArgs& a, hipStream_t st) {
     const int grid4 = ((a.B + 3) / 4) * a.tiles_x * a.tiles_y;
     hipLaunchKernelGGL((conv_mfma_split16_kernel<KS, COUT, 1, true, false, 1, false, true>), dim3(grid4), dim3(256), 0, st, a);
     return tsr_check_launch();
+  }
+  // The streaming form runs the `confusion` FORWARD (256 -> 64, plain epilogue: 0.96 -> 0.81 ms at B = 2048); its dgrad
+  // launches (64 -> 128 with the mask / BatchNorm-sum epilogue, 8-B epilogue accesses on bf16 tensors) measured slower
+  // streamed (0.94 vs 0.77 ms) and stay on the tiled kernel -- which also keeps the 2-image statistics-slab numbering
+  // of every 1x1 launch that writes slabs.  TSR_B16_1X1_TILED=1: the tiled kernel for the forward too (A/B).
+  static const bool tiled = getenv("TSR_B16_1X1_TILED") != nullptr;
+  if constexpr (COUT == 64) {
+    if (!tiled && a.epi_mode == 0) return launch_1x1_b16_ex<COUT>(a, st);
   }
   const int grid = ((a.B + 1) / 2) * a.tiles_x * a.tiles_y;
   hipLaunchKernelGGL((conv_mfma_split16_kernel<KS, COUT, 1, true, false, 2, false, true>), dim3(grid), dim3(256), 0, st, a);

@@ -402,35 +402,153 @@ __global__ __launch_bounds__(256, TPSF_FWD_OCC) void tpsf_fwd_mfma_kernel(const 
   }
 }
 
-// Backward of the forward model w.r.t. (alpha, beta, gamma) for one sample, given dL/dLRd (16)
-// (autograd of reference model/tPSFNet.py:78-141 as train/tPSFNet_train.py:180-190 drives it).  With H the Toeplitz
-// matrix of h(t) = (t-49)^2 g(t):
-//   hr  = a G D G                                  (forward value, needed for the plateau and d/da)
-//   dhb = -(d/dc) (G D G) = H D G + G D H          (c = Kp / b^2)
-// so the kernel runs five Toeplitz GEMMs on the matrix cores: Rg = D G, hr = G Rg, dhb = H Rg, Rh = D H,
-// dhb += G Rh (accumulator rescaled by an exact power of two between the two dhb terms, whose operand scales
-// differ), and reduces dL/dHR-weighted sums from the accumulator registers.
-// (one workgroup per CU: two accumulator sets + the depth planes need the 512-register budget; at the
-// 256-register budget of two resident workgroups hipcc spills ~340 values per lane and runs 2.5x slower)
-__global__ __launch_bounds__(256, 1) void tpsf_bwd_mfma_kernel(const float* __restrict__ depth,
-                                                               const float* __restrict__ ab,
-                                                               const float* __restrict__ dLRd,
-                                                               float* __restrict__ dab, int B) {
+// Backward of the forward model w.r.t. (alpha, beta, gamma), given dL/dLRd (B,16) -- autograd of reference
+// model/tPSFNet.py:78-141 as train/tPSFNet_train.py:180-190 drives it -- in TWO kernels (round 3; the single
+// persistent kernel of rounds 1-2 recomputed hr = a G D G, kept two accumulator sets and ~70 epilogue values live, needed
+// the 512-register budget, still spilled, and ran one wave per SIMD with every latency exposed: 1.28 ms per 8192
+// samples against 0.18 ms of MFMA time):
+//
+//  1. tpsf_bwd_pool_kernel -- everything that is a reduction over the STORED forward output HR (40 KB per sample, read
+//     once, HBM-bound): d/d(gamma) through the Gaussian pooling masks, d/d(alpha) = sum over non-plateau pixels of
+//     wgt * hr / alpha, and the per-pixel weight wgt(y,x) = dL/dHR off the plateau (0 on it: the plateau value is a
+//     detached constant, :95-97), written to a work buffer for kernel 2.
+//  2. tpsf_bwd_dhb_kernel -- d/d(beta): with H the Toeplitz matrix of h(t) = (t-49)^2 g(t),
+//         -(d/dc)(G D G) = H D G + G D H,   c = Kp / b^2,
+//     four Toeplitz GEMMs on the matrix cores (Rg = D G -> LDS, H Rg; Rh = D H -> LDS, G Rh), each product reduced against
+//     wgt straight from its accumulator (the sum is linear in dhb, so the two terms never have to be added
+//     element-wise: ONE accumulator set is live at a time), depth planes kept in registers across both row GEMMs.
+//     58 KB of LDS and < 256 VGPRs: two workgroups per CU.
+__global__ __launch_bounds__(256) void tpsf_bwd_pool_kernel(const float* __restrict__ depth, const float* __restrict__ ab,
+                                                            const float* __restrict__ HR, const float* __restrict__ dLRd,
+                                                            float* __restrict__ dab, float* __restrict__ wgt, int B) {
+  __shared__ float ea[400], ea2[400], qd[400];       // [4][100]: mask factors, (x-cx)^2 times them, sum_c dl[a][c] ea_c(x)
+  __shared__ float dl[16];
+  __shared__ float redf[8];
+  __shared__ double redd[4 * 34];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const float alpha = ab[b * 3 + 0], gamma = ab[b * 3 + 2];
+    const float cm = KM / gamma;
+    const float mn = expf(-100.0f / gamma);
+    const float k0 = 1e-4f / (1.0f - mn);
+    const float* dp = depth + (size_t)b * NPIX;
+    const float* hp = HR + (size_t)b * NPIX;
+    float mx = -INFINITY;                // pass 1: the plateau threshold (the rows are re-read from L2 in pass 2)
+#pragma unroll 8
+    for (int k = 0; k < 40; ++k) {
+      const int p = tid + 256 * k;
+      mx = fmaxf(mx, p < NPIX ? dp[p] : -INFINITY);
+    }
+    for (int i = tid; i < 400; i += 256) {
+      const int a = i / 100, x = i - a * 100;
+      const float t = (float)(x - (12 + 25 * a));
+      const float e = expf(-cm * t * t);
+      ea[i] = e;
+      ea2[i] = t * t * e;
+    }
+    if (tid < 16) dl[tid] = dLRd[b * 16 + tid];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) redf[w] = mx;
+    __syncthreads();                                                       // (1) ea, dl, max partials
+    const float thr = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3])) - 1e-3f;
+    for (int i = tid; i < 400; i += 256) {
+      const int a = i / 100, x = i - a * 100;
+      qd[i] = dl[a * 4 + 0] * ea[x] + dl[a * 4 + 1] * ea[100 + x] + dl[a * 4 + 2] * ea[200 + x] + dl[a * 4 + 3] * ea[300 + x];
+    }
+    float dlsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) dlsum += dl[t];
+    __syncthreads();                                                       // (2) qd
+    float S[4][4], Sd[4][4], s0 = 0.f, da = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { S[a][c] = 0.f; Sd[a][c] = 0.f; }
+    float* wp = wgt + (size_t)b * NPIX;
+#pragma unroll 2
+    for (int k = 0; k < 40; ++k) {
+      const int p = tid + 256 * k;
+      if (p < NPIX) {
+        const int y = p / HS, x = p - y * HS;
+        const float v = hp[p];                                   // stored HR: the plateau already holds its fill value
+        const float ey[4] = {ea[y], ea[100 + y], ea[200 + y], ea[300 + y]};
+        const float ey2[4] = {ea2[y], ea2[100 + y], ea2[200 + y], ea2[300 + y]};
+        const float ex[4] = {ea[x], ea[100 + x], ea[200 + x], ea[300 + x]};
+        const float ex2[4] = {ea2[x], ea2[100 + x], ea2[200 + x], ea2[300 + x]};
+        const float gsum = ey[0] * qd[x] + ey[1] * qd[100 + x] + ey[2] * qd[200 + x] + ey[3] * qd[300 + x];
+        const float wv = dp[p] > thr ? 0.f : k0 * (gsum - mn * dlsum);
+        wp[p] = wv;
+        s0 += v;
+        da = fmaf(wv, v, da);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const float t = v * ey[a], t2 = v * ey2[a];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            S[a][c] = fmaf(t, ex[c], S[a][c]);
+            Sd[a][c] = fmaf(t2, ex[c], fmaf(t, ex2[c], Sd[a][c]));
+          }
+        }
+      }
+    }
+    // ---- block reduction of the 34 partial sums in double (per-thread fp32 sums hold <= 40 terms)
+    double vals[34];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { vals[a * 4 + c] = (double)S[a][c]; vals[16 + a * 4 + c] = (double)Sd[a][c]; }
+    vals[32] = (double)s0;
+    vals[33] = (double)da;
+#pragma unroll
+    for (int i = 0; i < 34; ++i) {
+      double v = vals[i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) redd[w * 34 + i] = v;
+    }
+    __syncthreads();                                                       // (3) wave sums
+    if (tid < 16) {
+      const int pair = tid;
+      const double Sv = (redd[pair] + redd[34 + pair]) + (redd[68 + pair] + redd[102 + pair]);
+      const double Sdv = (redd[16 + pair] + redd[34 + 16 + pair]) + (redd[68 + 16 + pair] + redd[102 + 16 + pair]);
+      const double S0 = (redd[32] + redd[34 + 32]) + (redd[68 + 32] + redd[102 + 32]);
+      const double gm = gamma, mnd = mn;
+      const double mnp = mnd * 100.0 / (gm * gm);                 // d mn / d gamma
+      const double dS = Sdv * (double)KM / (gm * gm);             // d S_ac / d gamma
+      const double num = Sv - mnd * S0, den = 1.0 - mnd;
+      const double dLR = 1e-4 * ((dS - mnp * S0) * den + num * mnp) / (den * den);
+      double dg = (double)dl[pair] * dLR;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) dg += __shfl_xor(dg, o);
+      if (pair == 0) {
+        const double DA = (redd[33] + redd[34 + 33]) + (redd[68 + 33] + redd[102 + 33]);
+        dab[b * 3 + 0] = (float)(DA / (double)alpha);
+        dab[b * 3 + 2] = (float)dg;
+      }
+    }
+    __syncthreads();                                                       // (4) LDS free for the next sample
+  }
+}
+
+#ifndef TPSF_BWD_OCC
+#define TPSF_BWD_OCC 2
+#endif
+// (no __restrict__ on the inputs: hipcc treats loads through restrict-const pointers as invariant, hoists the 128 weight
+// loads of the two reductions and the depth rows of the second row GEMM to the top of the sample iteration -- across the
+// barriers -- and spills ~250 registers to keep them; possibly-aliasing pointers keep every load where it is written)
+__global__ __launch_bounds__(256, TPSF_BWD_OCC) void tpsf_bwd_dhb_kernel(const float* depth, const float* ab,
+                                                                         const float* wgt, float* dab, int B) {
   __shared__ __attribute__((aligned(16))) char Tg[2 * T_PLANE];
   __shared__ __attribute__((aligned(16))) char Th[2 * T_PLANE];
   __shared__ __attribute__((aligned(16))) char RT[2 * RT_PLANE + 16];
   __shared__ float g[128], hh[128];           // g[0..98], h[0..98]
-  __shared__ float ea[400], ea2[400];         // [4][100] mask factors, and (x-cx)^2 times them
-  __shared__ float Pp[4 * 4 * 100], P2p[4 * 4 * 100];   // [wave][a][x] pooling partials with ea / ea2
-  __shared__ __attribute__((aligned(16))) unsigned char pmask[128 * 16];
-  __shared__ float dl[16];
-  __shared__ float red[16];
-  __shared__ double redd[16];
+  __shared__ float red[8];
+  __shared__ double redd[4];
 
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, li = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (tid < 4) ((float*)(RT + 2 * RT_PLANE))[tid] = 0.f;
-  for (int i = tid; i < 128 * 4; i += 256) ((unsigned*)pmask)[i] = 0u;
   const int y = 32 * w + li;
   const int q8 = (li + 7) & ~7, rcopy = q8 - li;
   const int laneT = rcopy * TC_STRIDE + 2 * (T_OFF + 8 * h - q8);
@@ -449,47 +567,26 @@ __global__ __launch_bounds__(256, 1) void tpsf_bwd_mfma_kernel(const float* __re
   if ((int)blockIdx.x < B) load_depth(blockIdx.x);
 
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    const float alpha = ab[b * 3 + 0], beta = ab[b * 3 + 1], gamma = ab[b * 3 + 2];
+    const float alpha = ab[b * 3 + 0], beta = ab[b * 3 + 1];
     const float cpsf = KP / (beta * beta);
-    const float cm = KM / gamma;
-    const float mn = expf(-100.0f / gamma);
-
-    float mabs = 0.f, mx = -INFINITY;
+    float mabs = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 7; ++ks)
 #pragma unroll
       for (int q = 0; q < 2; ++q)
-        if (y < HS && 16 * ks + 8 * h + 4 * q < HS) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            mabs = fmaxf(mabs, fabsf(dA[ks][q][j]));
-            mx = fmaxf(mx, dA[ks][q][j]);
-          }
-        }
+        for (int j = 0; j < 4; ++j) mabs = fmaxf(mabs, fabsf(dA[ks][q][j]));      // (rows / columns outside are 0)
     for (int i = tid; i < PS; i += 256) {
       const float t = (float)(i - 49);
       const float gi = expf(-cpsf * t * t);
       g[i] = gi;
       hh[i] = t * t * gi;
     }
-    for (int i = tid; i < 400; i += 256) {
-      const int a = i / 100, x = i - a * 100;
-      const float t = (float)(x - (12 + 25 * a));
-      const float e = expf(-cm * t * t);
-      ea[i] = e;
-      ea2[i] = t * t * e;
-    }
-    if (tid < 16) dl[tid] = dLRd[b * 16 + tid];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      mabs = fmaxf(mabs, __shfl_xor(mabs, o));
-      mx = fmaxf(mx, __shfl_xor(mx, o));
-    }
-    if (lane == 0) { red[w] = mabs; red[4 + w] = mx; }
+    for (int o = 32; o > 0; o >>= 1) mabs = fmaxf(mabs, __shfl_xor(mabs, o));
+    if (lane == 0) red[w] = mabs;
     __syncthreads();                                                      // (1) tables, red
     mabs = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    const float dmax = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
-
     // ---- operand scales (every wave derives the same values): sums / max of the two filters bound R = D*filter
     float sumg = lane < 50 ? g[49 + lane] : 0.f, sumh = lane < 50 ? hh[49 + lane] : 0.f;
     float hmax = sumh;
@@ -507,141 +604,7 @@ __global__ __launch_bounds__(256, 1) void tpsf_bwd_mfma_kernel(const float* __re
     build_toeplitz(Tg, g, G_SCALE, tid);
     build_toeplitz(Th, hh, sH, tid);
 
-    const float thr = dmax - 1e-3f;
-    f32x16 acc[4];
-    {
-      f16x8 a_hi[7], a_lo[7];
-#pragma unroll
-      for (int ks = 0; ks < 7; ++ks) {
-        unsigned bits = 0u;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float d = dA[ks][j >> 2][j & 3];
-          bits |= (d > thr ? 1u : 0u) << j;
-          const float t = d * sD;
-          const _Float16 hi = (_Float16)t;
-          a_hi[ks][j] = hi;
-          a_lo[ks][j] = (_Float16)(t - (float)hi);
-        }
-        if (16 * ks + 8 * h < 104) pmask[y * 16 + 2 * ks + h] = (unsigned char)bits;
-      }
-      __syncthreads();                                                    // (2) table copies, plateau bits
-
-      // ---- Rg = D G -> R^T;  hr = a G Rg
-      zero_acc(acc);
-      gemm_rows_toeplitz(acc, a_hi, a_lo, Tg, laneT);
-    }
-    if (w < 3) store_rt<false>(acc, sRg / (sD * G_SCALE), RT, w, h, li);
-    else store_rt<true>(acc, sRg / (sD * G_SCALE), RT, w, h, li);
-    __syncthreads();                                                      // (3) R^T = Rg
-    zero_acc(acc);
-    gemm_toeplitz_rt(acc, Tg, RT, laneT, w, h, li);
-
-    int li_o = li, h_o = h;
-    asm volatile("" : "+v"(li_o), "+v"(h_o));
-    const int yb = 32 * w + 4 * h_o;
-    const unsigned vx3 = ((unsigned)(li_o - (HS - 96)) >> 31);
-    unsigned long long plateau = 0ull, inside = 0ull;      // inside: pixel of the 100x100 image
-    float fmax_out = 0.f;
-    {
-      const float f2 = alpha / (G_SCALE * sRg);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int yy = yb + (r & 3) + 8 * (r >> 2);
-        const unsigned vy = ((unsigned)(yy - HS) >> 31);
-        const uint4 mrow = *(const uint4*)(pmask + yy * 16);
-        const unsigned mw[4] = {mrow.x, mrow.y, mrow.z, mrow.w};
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const unsigned vi = nt < 3 ? vy : (vy & vx3);
-          const unsigned pli = (mw[nt] >> li_o) & vi;
-          const float v = acc[nt][r] * f2 * (float)vi;
-          inside |= (unsigned long long)vi << (nt * 16 + r);
-          plateau |= (unsigned long long)pli << (nt * 16 + r);
-          fmax_out = fmaxf(fmax_out, v * (float)(1u - pli));
-          acc[nt][r] = v;
-        }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    {
-      // opaque copies: hipcc otherwise keeps the 128 per-pixel conditions alive as lane masks instead of these bits
-      unsigned plo = (unsigned)plateau, phi = (unsigned)(plateau >> 32);
-      unsigned ilo = (unsigned)inside, ihi = (unsigned)(inside >> 32);
-      asm volatile("" : "+v"(plo), "+v"(phi), "+v"(ilo), "+v"(ihi));
-      plateau = ((unsigned long long)phi << 32) | plo;
-      inside = ((unsigned long long)ihi << 32) | ilo;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) fmax_out = fmaxf(fmax_out, __shfl_xor(fmax_out, o));
-    if (lane == 0) red[8 + w] = fmax_out;
-    __syncthreads();                                                      // (4) fill
-    const float fill = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
-
-    // dL/dHR = k0 (sum_ac dl_ac ea_a(row) ea_c(col) - mn sum dl) off the plateau (the plateau value is a constant)
-    const float k0 = 1e-4f / (1.0f - mn);
-    float dlsum = 0.f;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) dlsum += dl[t];
-    float s0 = 0.f, da = 0.f;
-    {
-      float pa[4][4], pa2[4][4], qd[4][4];        // qd[nt][a] = sum_c dl[a][c] ea_c(col)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int xc = 32 * nt + li_o < HS ? 32 * nt + li_o : HS - 1;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          pa[nt][a] = 0.f;
-          pa2[nt][a] = 0.f;
-          qd[nt][a] = dl[a * 4 + 0] * ea[xc] + dl[a * 4 + 1] * ea[100 + xc] + dl[a * 4 + 2] * ea[200 + xc] +
-                      dl[a * 4 + 3] * ea[300 + xc];
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int yy = yb + (r & 3) + 8 * (r >> 2);
-        const int yc = yy < HS - 1 ? yy : HS - 1;
-        const float e[4] = {ea[yc], ea[100 + yc], ea[200 + yc], ea[300 + yc]};
-        const float e2[4] = {ea2[yc], ea2[100 + yc], ea2[200 + yc], ea2[300 + yc]};
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const unsigned pm = 0u - (unsigned)((plateau >> (nt * 16 + r)) & 1ull);
-          const float hrv = acc[nt][r];                         // 0 outside the image
-          const float v = bitsel(pm, fill, hrv);
-          s0 += v;
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            pa[nt][a] = fmaf(e[a], v, pa[nt][a]);
-            pa2[nt][a] = fmaf(e2[a], v, pa2[nt][a]);
-          }
-          const float gsum = e[0] * qd[nt][0] + e[1] * qd[nt][1] + e[2] * qd[nt][2] + e[3] * qd[nt][3];
-          da = fmaf(k0 * (gsum - mn * dlsum), bitsel(pm, 0.f, hrv), da);
-        }
-        asm volatile("" ::: "memory");     // keep the row's LDS reads and arithmetic in its iteration (hipcc
-        __builtin_amdgcn_sched_barrier(0); // otherwise regroups the unrolled rows and spills hundreds of values)
-      }
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          pa[nt][a] += __shfl_xor(pa[nt][a], 32);
-          pa2[nt][a] += __shfl_xor(pa2[nt][a], 32);
-          if (h == 0 && 32 * nt + li < HS) {
-            Pp[(w * 4 + a) * 100 + 32 * nt + li] = pa[nt][a];
-            P2p[(w * 4 + a) * 100 + 32 * nt + li] = pa2[nt][a];
-          }
-        }
-    }
-
-    // ---- dhb = H Rg + G Rh
-    zero_acc(acc);
-    gemm_toeplitz_rt(acc, Th, RT, laneT, w, h, li);                       // scale sH * sRg
-    __syncthreads();                                                      // (5) every wave is done with Rg
-    {
-      // the depth rows again (L2): their fp16 planes were not kept across the first epilogue
-      load_depth(b);
-      f16x8 a_hi[7], a_lo[7];
+    auto depth_planes = [&](f16x8 (&a_hi)[7], f16x8 (&a_lo)[7]) {
 #pragma unroll
       for (int ks = 0; ks < 7; ++ks)
 #pragma unroll
@@ -651,101 +614,74 @@ __global__ __launch_bounds__(256, 1) void tpsf_bwd_mfma_kernel(const float* __re
           a_hi[ks][j] = hi;
           a_lo[ks][j] = (_Float16)(t - (float)hi);
         }
-      f32x16 accr[4];
-      zero_acc(accr);
-      gemm_rows_toeplitz(accr, a_hi, a_lo, Th, laneT);
-      if (w < 3) store_rt<false>(accr, sRh / (sD * sH), RT, w, h, li);
-      else store_rt<true>(accr, sRh / (sD * sH), RT, w, h, li);
-    }
-    __syncthreads();                                                      // (6) R^T = Rh
-    {
-      const float resc = (G_SCALE * sRh) / (sH * sRg);                    // exact power of two
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] *= resc;
-    }
-    gemm_toeplitz_rt(acc, Tg, RT, laneT, w, h, li);                       // scale 2^13 * sRh
-    if (b + (int)gridDim.x < B) load_depth(b + gridDim.x);
+    };
+    __syncthreads();                                                      // (2) table copies
 
-    float db = 0.f;
-    {
-      const float f3 = 1.0f / (G_SCALE * sRh);
-      float qd[4][4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int xc = 32 * nt + li_o < HS ? 32 * nt + li_o : HS - 1;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-          qd[nt][a] = dl[a * 4 + 0] * ea[xc] + dl[a * 4 + 1] * ea[100 + xc] + dl[a * 4 + 2] * ea[200 + xc] +
-                      dl[a * 4 + 3] * ea[300 + xc];
-      }
+    // sum over this lane's accumulator pixels of wgt * acc (wgt is 0 on the plateau; rows / columns outside the image
+    // are masked: their accumulators hold finite garbage of the padded GEMM)
+    int li_o = li, h_o = h;
+    asm volatile("" : "+v"(li_o), "+v"(h_o));
+    const float* wp = wgt + (size_t)b * NPIX;
+    auto dot_w = [&](const f32x16 (&ac)[4]) {
+      const int yb = 32 * w + 4 * h_o;
+      const int x3 = 96 + li_o < HS ? 96 + li_o : HS - 1;
+      const float ok3 = 96 + li_o < HS ? 1.f : 0.f;
+      float part = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int yy = yb + (r & 3) + 8 * (r >> 2);
-        const int yc = yy < HS - 1 ? yy : HS - 1;
-        const float e[4] = {ea[yc], ea[100 + yc], ea[200 + yc], ea[300 + yc]};
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const unsigned um = 0u - (unsigned)(((inside & ~plateau) >> (nt * 16 + r)) & 1ull);
-          const float gsum = e[0] * qd[nt][0] + e[1] * qd[nt][1] + e[2] * qd[nt][2] + e[3] * qd[nt][3];
-          db = fmaf(k0 * (gsum - mn * dlsum), bitsel(um, acc[nt][r] * f3, 0.f), db);
-        }
-        asm volatile("" ::: "memory");
+        const float* wr = wp + (yy < HS ? yy : HS - 1) * HS;
+        const float rowok = yy < HS ? 1.f : 0.f;
+        const float w0 = wr[li_o], w1 = wr[32 + li_o], w2 = wr[64 + li_o], w3 = wr[x3];
+        part = fmaf(w0 * rowok, ac[0][r], part);
+        part = fmaf(w1 * rowok, ac[1][r], part);
+        part = fmaf(w2 * rowok, ac[2][r], part);
+        part = fmaf(w3 * (rowok * ok3), ac[3][r], part);
+        // pin the partial sum here: LLVM otherwise SINKS the whole multiply-add chain of the first reduction to the end of
+        // the sample iteration (its only use), keeping 64 loaded weights (through scratch) and a second accumulator set alive
+        asm volatile("" : "+v"(part) : : "memory");
         __builtin_amdgcn_sched_barrier(0);
       }
-    }
-    double s0d = (double)s0, dad = (double)da, dbd = (double)db;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      s0d += __shfl_xor(s0d, o);
-      dad += __shfl_xor(dad, o);
-      dbd += __shfl_xor(dbd, o);
-    }
-    if (lane == 0) { redd[w] = s0d; redd[4 + w] = dad; redd[8 + w] = dbd; }
-    __syncthreads();                                                      // (7) partial sums, pooling partials
-    const double S0 = (redd[0] + redd[1]) + (redd[2] + redd[3]);
-    double dg = 0.0;
+      return part;
+    };
+
+    f32x16 acc[4];
     {
-      const int pair = tid >> 4, sub = tid & 15, a = pair >> 2, c = pair & 3;
-      float S = 0.f, Sd = 0.f;      // S_ac = sum HR m_ac ; Sd = sum HR m_ac d^2_ac
-      for (int x = sub; x < HS; x += 16) {
-        const float p = (Pp[(0 * 4 + a) * 100 + x] + Pp[(1 * 4 + a) * 100 + x]) +
-                        (Pp[(2 * 4 + a) * 100 + x] + Pp[(3 * 4 + a) * 100 + x]);
-        const float p2 = (P2p[(0 * 4 + a) * 100 + x] + P2p[(1 * 4 + a) * 100 + x]) +
-                         (P2p[(2 * 4 + a) * 100 + x] + P2p[(3 * 4 + a) * 100 + x]);
-        S = fmaf(p, ea[c * 100 + x], S);
-        Sd = fmaf(p2, ea[c * 100 + x], fmaf(p, ea2[c * 100 + x], Sd));
-      }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        S += __shfl_xor(S, o);
-        Sd += __shfl_xor(Sd, o);
-      }
-      if (sub == 0) {
-        const double gm = gamma, mnd = mn;
-        const double mnp = mnd * 100.0 / (gm * gm);                 // d mn / d gamma
-        const double dS = (double)Sd * (double)KM / (gm * gm);      // d S_ac / d gamma
-        const double num = (double)S - mnd * S0, den = 1.0 - mnd;
-        const double dLR = 1e-4 * ((dS - mnp * S0) * den + num * mnp) / (den * den);
-        dg = (double)dl[pair] * dLR;
-      }
-      // the four pairs of a wave sit in lanes 0, 16, 32, 48
-      dg += __shfl_xor(dg, 16);
-      dg += __shfl_xor(dg, 32);
-      if (lane == 0) redd[12 + w] = dg;
+      f16x8 a_hi[7], a_lo[7];
+      depth_planes(a_hi, a_lo);
+      zero_acc(acc);
+      gemm_rows_toeplitz(acc, a_hi, a_lo, Tg, laneT);                     // Rg = D G
     }
-    __syncthreads();                                                      // (8)
+    if (w < 3) store_rt<false>(acc, sRg / (sD * G_SCALE), RT, w, h, li);
+    else store_rt<true>(acc, sRg / (sD * G_SCALE), RT, w, h, li);
+    __syncthreads();                                                      // (3) R^T = Rg
+    zero_acc(acc);
+    gemm_toeplitz_rt(acc, Th, RT, laneT, w, h, li);                       // H Rg, scale sH * sRg
+    double db = (double)dot_w(acc) / ((double)sH * (double)sRg);
+    __syncthreads();                                                      // (4) every wave is done with Rg
+    {
+      load_depth(b);             // the rows again (L2): neither they nor their planes are kept across the first product
+      f16x8 a_hi[7], a_lo[7];
+      depth_planes(a_hi, a_lo);
+      zero_acc(acc);
+      gemm_rows_toeplitz(acc, a_hi, a_lo, Th, laneT);                     // Rh = D H
+    }
+    if (w < 3) store_rt<false>(acc, sRh / (sD * sH), RT, w, h, li);
+    else store_rt<true>(acc, sRh / (sD * sH), RT, w, h, li);
+    __syncthreads();                                                      // (5) R^T = Rh
+    zero_acc(acc);
+    gemm_toeplitz_rt(acc, Tg, RT, laneT, w, h, li);                       // G Rh, scale 2^13 * sRh
+    db += (double)dot_w(acc) / ((double)G_SCALE * (double)sRh);
+    if (b + (int)gridDim.x < B) load_depth(b + gridDim.x);               // planes and accumulators are dead: next rows
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) db += __shfl_xor(db, o);
+    if (lane == 0) redd[w] = db;
+    __syncthreads();                                                      // (6) partial sums; LDS free for the next sample
     if (tid == 0) {
-      const double DA = (redd[4] + redd[5]) + (redd[6] + redd[7]);
-      const double DB = (redd[8] + redd[9]) + (redd[10] + redd[11]);
-      const double DG = (redd[12] + redd[13]) + (redd[14] + redd[15]);
-      dab[b * 3 + 0] = (float)(DA / (double)alpha);
+      const double DB = (redd[0] + redd[1]) + (redd[2] + redd[3]);
       // raw = sum D e^{-c r^2}: d raw / d beta = dhb * 2 Kp / beta^3 ; HR = alpha * raw
       dab[b * 3 + 1] = (float)(DB * (double)alpha * 2.0 * (double)KP / ((double)beta * beta * beta));
-      dab[b * 3 + 2] = (float)DG;
     }
-    __syncthreads();                                                      // (9) LDS free for the next sample
   }
 }
 
@@ -758,11 +694,13 @@ extern "C" int tpsf_forward(const float* depth, const float* alpha_beta, float* 
   return tsr_check_launch();
 }
 
-extern "C" int tpsf_backward(const float* depth, const float* alpha_beta, const float* dLR_deg, float* d_alpha_beta,
-                             int B, void* stream) {
-  if (!depth || !alpha_beta || !dLR_deg || !d_alpha_beta || B <= 0) return TSR_ERR_ARG;
-  const int grid = B < 256 ? B : 256;          // one persistent workgroup per CU
-  hipLaunchKernelGGL(tpsf_bwd_mfma_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, depth, alpha_beta, dLR_deg,
-                     d_alpha_beta, B);
+extern "C" int tpsf_backward(const float* depth, const float* alpha_beta, const float* HR, const float* dLR_deg,
+                             float* d_alpha_beta, float* work, int B, void* stream) {
+  if (!depth || !alpha_beta || !HR || !dLR_deg || !d_alpha_beta || !work || B <= 0) return TSR_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(tpsf_bwd_pool_kernel, dim3(B < 2048 ? B : 2048), dim3(256), 0, st, depth, alpha_beta, HR, dLR_deg,
+                     d_alpha_beta, work, B);
+  const int grid = B < 256 * TPSF_BWD_OCC ? B : 256 * TPSF_BWD_OCC;      // persistent workgroups, TPSF_BWD_OCC per CU
+  hipLaunchKernelGGL(tpsf_bwd_dhb_kernel, dim3(grid), dim3(256), 0, st, depth, alpha_beta, work, d_alpha_beta, B);
   return tsr_check_launch();
 }

@@ -140,7 +140,8 @@ def test_tpsf_kernels_wide_dynamic_range_batch():
     psf = torch.empty(B, 1, 99, 99, device="cuda")
     dab = torch.empty(B, 3, device="cuda")
     call("tpsf_forward", ptr(d), ptr(a_), ptr(HR), ptr(LRd), ptr(psf), I(B), stream())
-    call("tpsf_backward", ptr(d), ptr(a_), ptr(dl_), ptr(dab), I(B), stream())
+    work = torch.empty(B * 10000, device="cuda")
+    call("tpsf_backward", ptr(d), ptr(a_), ptr(HR), ptr(dl_), ptr(dab), ptr(work), I(B), stream())
     n = 24                                          # fp64 restatement (oracle functions) on a subset
     ab64 = ab[:n].double().requires_grad_(True)
     HR64, LR64, psf64 = O.tpsf_forward_from_ab(ab64, depth[:n].double())

@@ -33,7 +33,8 @@ def timeit(fn):
 
 
 tf = timeit(lambda: call("tpsf_forward", ptr(depth), ptr(ab), ptr(HR), ptr(LRd), ptr(psf), I(B), stream()))
-tb = timeit(lambda: call("tpsf_backward", ptr(depth), ptr(ab), ptr(dl), ptr(dab), I(B), stream()))
+work = torch.empty(B * 10000, device="cuda")
+tb = timeit(lambda: call("tpsf_backward", ptr(depth), ptr(ab), ptr(HR), ptr(dl), ptr(dab), ptr(work), I(B), stream()))
 fb = 4 * (10000 + 10000 + 9801 + 16 + 3)
 print(f"tpsf_forward  B={B}: {tf:.3f} ms  {B / tf / 1e3:.2f} M samples/s  {B * fb / tf / 1e6:.0f} GB/s ({B * fb / tf / 8e9 * 100:.1f}% of 8 TB/s)")
 print(f"tpsf_backward B={B}: {tb:.3f} ms  {B / tb / 1e3:.2f} M samples/s  {B * 40000 / tb / 1e6:.0f} GB/s")
