@@ -673,7 +673,8 @@ int tsr_conv_k32_fuse1x1(const ConvArgs& a, int ks, hipStream_t st) {
   // The fused forms stay at 256 threads (2 workgroups per CU): with 512 threads the parked tile needs 139 KB of LDS, one
   // workgroup per CU, and the fused epilogue is no longer hidden behind a second workgroup's main loop -- same-box A/B of
   // the whole eval forward: 145.2 ms (512) vs 144.6 ms (256); TSR_CONV_K32_FUSE512=1 selects the 512-thread form.
-  static const bool f512 = getenv("TSR_CONV_K32_FUSE512") != nullptr;
+  static const char* f512e = getenv("TSR_CONV_K32_FUSE512");       // "1": both kernel sizes, "3" / "5": that size only
+  const bool f512 = f512e && (f512e[0] == '1' || f512e[0] == '0' + ks);
   if (f512 && !k32_256()) {
     const int grid = ((a.B + 3) / 4) * a.tiles_x * a.tiles_y;
     if (ks == 5) hipLaunchKernelGGL((conv_k32_kernel<5, 128, false, 2, true, false, 512>), dim3(grid), dim3(512), 0, st, a);

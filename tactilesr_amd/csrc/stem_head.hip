@@ -10,6 +10,7 @@
 //    is elided.  Reads CB16, writes the NCHW (B,1,H,W) result.  HBM-read bound.
 //  * layout converters NCHW <-> CB16 (test / probe plumbing).
 #include "tsr_common.h"
+#include <stdlib.h>
 
 // ATen upsample_bilinear2d (align_corners=False) source index.
 __device__ __forceinline__ void bilin_src(int dst, float scale, int n_in, int& i0, int& i1, float& lam) {
@@ -277,15 +278,122 @@ __global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ in,
   if (live && q == 0) out[(size_t)b * HW + p] = v;
 }
 
+// LDS-tiled form (round 3, default): the kernel above asks L1 / the texture path for every input line nine times (once
+// per tap: 72 16-B load instructions per thread) and ran at 2.1 TB/s = 0.26 of HBM although its HBM traffic is the
+// algorithmic 3.36 GB (the re-reads hit L2).  Here a workgroup owns an 8x8 pixel patch of one image, stages the 10x10
+// halo of one 16-channel block per step (1.6 global loads per thread instead of 9; double-buffered, one barrier per
+// block) and takes the nine taps from LDS: thread = (pixel, channel quad) as before, so a 16-lane group reads 256
+// contiguous bytes (4 pixels x 64 B): bank-conflict free without padding.
+template <bool IN16>
+__global__ __launch_bounds__(256) void head_lds_kernel(const float* __restrict__ in, int in_ctot, int cin,
+                                                       const float* __restrict__ w, float* __restrict__ out, int relu,
+                                                       int B, int H, int W, int tiles_x, int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) float hl[];   // [cin/16][9][16] weights, then 2 x [100 px][16] halo
+  const int tid = threadIdx.x;
+  const int nblk = cin >> 4;
+  for (int i = tid; i < nblk * 9 * 16; i += 256) {
+    const int j = i & 15, r = i >> 4;
+    const int tap = r % 9, blk = r / 9;
+    hl[i] = w[(blk * 16 + j) * 9 + tap];
+  }
+  float* halo = hl + nblk * 9 * 16;
+  const int HW = H * W, tpi = tiles_x * tiles_y;
+  int b, trem;
+  {   // XCD-aware order: the patches of one image (they share halo rows) run on one XCD / L2
+    const int nwg = gridDim.x;
+    const int qn = nwg >> 3, rn = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int logical = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+    b = logical / tpi;
+    trem = logical - b * tpi;
+  }
+  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+  const int y0 = ty * 8, x0 = tx * 8;
+  const int in_blocks = in_ctot >> 4;
+  // staging items (halo pixel, quad): this thread's two slots
+  int soff[2], sdst[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int it = tid + 256 * k;
+    soff[k] = -1;
+    sdst[k] = -1;
+    if (it < 400) {
+      const int qd = it & 3, hp = it >> 2;
+      const int hy = hp / 10, hx = hp - hy * 10;
+      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      sdst[k] = hp * 16 + qd * 4;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) soff[k] = (gy * W + gx) * 16 + qd * 4;
+    }
+  }
+  const size_t ibase = (size_t)b * in_blocks * HW * 16;
+  auto load = [&](int blk, f32x4* hv) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      hv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (soff[k] >= 0) hv[k] = tsr_ld4<IN16>(in, ibase + (size_t)blk * HW * 16 + soff[k]);
+    }
+  };
+  auto store = [&](int buf, const f32x4* hv) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (sdst[k] >= 0) *(f32x4*)(halo + buf * 1600 + sdst[k]) = hv[k];
+  };
+  const int q = tid & 3, p = tid >> 2, py = p >> 3, px = p & 7;
+  f32x4 hv[2];
+  load(0, hv);
+  store(0, hv);
+  if (nblk > 1) load(1, hv);
+  __syncthreads();
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int blk = 0; blk < nblk; ++blk) {
+    const float* hb = halo + (blk & 1) * 1600 + (py * 10 + px) * 16 + 4 * q;
+    const float* wb = hl + blk * 9 * 16 + 4 * q;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      float s = 0.f;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const f32x4 v = *(const f32x4*)(hb + (kh * 10 + kw) * 16);
+        const f32x4 wv = *(const f32x4*)(wb + (kh * 3 + kw) * 16);
+        s = fmaf(v[0], wv[0], fmaf(v[1], wv[1], fmaf(v[2], wv[2], fmaf(v[3], wv[3], s))));
+      }
+      if (kh == 0) a0 += s; else if (kh == 1) a1 += s; else a2 += s;
+    }
+    if (blk + 1 < nblk) {
+      store((blk + 1) & 1, hv);             // the other buffer: last read before the barrier that ended step blk - 1
+      if (blk + 2 < nblk) load(blk + 2, hv);
+    }
+    __syncthreads();
+  }
+  float v = (a0 + a1) + a2;
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // lane ^ 2
+  if (relu) v = tsr_relu(v);
+  const int gy = y0 + py, gx = x0 + px;
+  if (q == 0 && gy < H && gx < W) out[(size_t)b * HW + gy * W + gx] = v;
+}
+
+template <bool IN16>
+static int head_launch(const float* in, int in_ctot, int cin, const float* w_oihw, float* out_nchw, int relu, int B, int H,
+                       int W, void* stream) {
+  static const bool old = getenv("TSR_HEAD_OLD") != nullptr;       // A/B: the round-1/2 kernel (nine global reads per line)
+  if (old) {
+    dim3 grid((H * W + 63) / 64, B);
+    hipLaunchKernelGGL(head_kernel<IN16>, grid, dim3(256), (size_t)cin * 9 * 4, (hipStream_t)stream, in, in_ctot, cin,
+                       w_oihw, out_nchw, relu, B, H, W);
+    return tsr_check_launch();
+  }
+  const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
+  const size_t smem = (size_t)cin * 9 * 4 + 2 * 1600 * 4;
+  hipLaunchKernelGGL(head_lds_kernel<IN16>, dim3(B * tiles_x * tiles_y), dim3(256), smem, (hipStream_t)stream, in, in_ctot,
+                     cin, w_oihw, out_nchw, relu, B, H, W, tiles_x, tiles_y);
+  return tsr_check_launch();
+}
+
 extern "C" int tsr_head_fwd(const float* in, int in_ctot, int cin, const float* w_oihw, float* out_nchw,
                             int relu, int B, int H, int W, void* stream) {
   if (!in || !w_oihw || !out_nchw || B <= 0 || (cin & 15) || (in_ctot & 15) || cin > in_ctot || cin <= 0)
     return TSR_ERR_ARG;
-  dim3 grid((H * W + 63) / 64, B);
-  const size_t smem = (size_t)cin * 9 * 4;
-  hipLaunchKernelGGL(head_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, in, in_ctot, cin, w_oihw,
-                     out_nchw, relu, B, H, W);
-  return tsr_check_launch();
+  return head_launch<false>(in, in_ctot, cin, w_oihw, out_nchw, relu, B, H, W, stream);
 }
 
 // bf16 activation storage: `in` is bf16 CB16; the image comes out fp32 NCHW as always
@@ -293,11 +401,7 @@ extern "C" int tsr_head_fwd_b16(const void* in_bf16, int in_ctot, int cin, const
                                 int relu, int B, int H, int W, void* stream) {
   if (!in_bf16 || !w_oihw || !out_nchw || B <= 0 || (cin & 15) || (in_ctot & 15) || cin > in_ctot || cin <= 0)
     return TSR_ERR_ARG;
-  dim3 grid((H * W + 63) / 64, B);
-  const size_t smem = (size_t)cin * 9 * 4;
-  hipLaunchKernelGGL(head_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, (const float*)in_bf16, in_ctot, cin,
-                     w_oihw, out_nchw, relu, B, H, W);
-  return tsr_check_launch();
+  return head_launch<true>((const float*)in_bf16, in_ctot, cin, w_oihw, out_nchw, relu, B, H, W, stream);
 }
 
 // ---------------------------------------------------------------------------------------
