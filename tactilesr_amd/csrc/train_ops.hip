@@ -339,15 +339,14 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
   }
   __syncthreads();
   const int HW = H * W, b = blockIdx.y, nblk = cin >> 4;
-  // item = (channel block, pixel, channel quad): the four lanes of a quad cover one 64-B CB16 line, a wave 16 whole
-  // lines = 1 KB contiguous per load / store instruction (one lane per (pixel, block) with four 16-B accesses at a
-  // 64-B lane stride: 3.5 ms per step at B = 2048; this form 2.9 ms.  Staging the masked dout strip in LDS per 64-pixel
-  // workgroup instead of 18 small global loads per lane measured slower and erratic, 2.9-18 ms: its serial prologue)
+  // item = (pixel, channel quad), looping over the channel blocks: the nine masked dout neighbours of the pixel are
+  // gathered ONCE per thread and reused for every block (round 2 made the block part of the item: each of the 32 threads
+  // of a pixel repeated the 18 small loads -- 3.4 ms per step at B = 2048, 1 TB/s on a kernel that moves 3.4 GB).  The
+  // four lanes of a quad still cover one 64-B CB16 line, a wave 16 whole lines per load / store instruction.
   const int item = blockIdx.x * 256 + tid;
   float amax = 0.f;
-  if (item < HW * nblk * 4) {
-    const int qd = item & 3, pq = item >> 2;
-    const int blk = pq / HW, q = pq - blk * HW;
+  if (item < HW * 4) {
+    const int qd = item & 3, q = item >> 2;
     const int y = q / W, x = q - y * W;
     float dp[9];
 #pragma unroll
@@ -362,20 +361,25 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         }
         dp[kh * 3 + kw] = v;
       }
-    const size_t eo = (((size_t)b * (h_ctot >> 4) + blk) * HW + q) * 16 + qd * 4;
-    const size_t zo = (((size_t)b * (dz_ctot >> 4) + blk) * HW + q) * 16 + qd * 4;
-    const f32x4 hv = tsr_ld4<B16>(h0, eo);
-    f32x4 r;
+    for (int blk = 0; blk < nblk; ++blk) {
+      const size_t eo = (((size_t)b * (h_ctot >> 4) + blk) * HW + q) * 16 + qd * 4;
+      const size_t zo = (((size_t)b * (dz_ctot >> 4) + blk) * HW + q) * 16 + qd * 4;
+      const f32x4 hv = tsr_ld4<B16>(h0, eo);
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = blk * 16 + qd * 4 + j;
-      float s = 0.f;
+      for (int t = 0; t < 9; ++t) {
+        const f32x4 wv = *(const f32x4*)(wl + t * cin + blk * 16 + qd * 4);
 #pragma unroll
-      for (int t = 0; t < 9; ++t) s = fmaf(dp[t], wl[t * cin + c], s);
-      r[j] = hv[j] > 0.f ? s : 0.f;
-      amax = fmaxf(amax, fabsf(r[j]));
+        for (int j = 0; j < 4; ++j) s4[j] = fmaf(dp[t], wv[j], s4[j]);
+      }
+      f32x4 r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r[j] = hv[j] > 0.f ? s4[j] : 0.f;
+        amax = fmaxf(amax, fabsf(r[j]));
+      }
+      tsr_st4<B16>(dz, zo, r);
     }
-    tsr_st4<B16>(dz, zo, r);
   }
   if (out_amax) {
 #pragma unroll
@@ -443,7 +447,7 @@ static int head_bwd_impl(const float* dout, const float* out, const float* h0, i
       cin > dz_ctot || (h_ctot & 15) || (dz_ctot & 15))
     return TSR_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const int items = H * W * (cin >> 4) * 4;
+  const int items = H * W * 4;
   hipLaunchKernelGGL(head_bwd_kernel<B16>, dim3((items + 255) / 256, B), dim3(256), (size_t)9 * cin * 4, st, dout, out,
                      h0, h_ctot, cin, w_oihw, dz_h0, dz_ctot, B, H, W, dz_amax);
   size_t fl = (size_t)(H + 2) * (W + 2);
