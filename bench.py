@@ -106,7 +106,7 @@ def pmc_traffic(kernel_substr, mode="eval"):
     FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 FETCH x2 correction).  PMC
     counters cannot be read from inside the process, so bench.py cites the latest pass."""
     import glob
-    pat = "r[0-9][0-9]_pmc_summary.json" if mode == "eval" else f"r[0-9][0-9]_{mode}_pmc_summary.json"
+    pat = "r[0-9][0-9]_pmc_summary.json" if mode == "eval" else f"r[0-9][0-9]_{mode}_pmc_summary.json"      # eval | train | bf16 | trainbf16
     files = sorted(glob.glob(os.path.join(REPO, "profiles", pat)))
     if not files:
         return None, None
@@ -284,7 +284,7 @@ def run_infer(args, world, rank, dev):
         per_kernel = {(f"conv{k[0]}x{k[0]}_c{k[1]}" if k[0] != "pair" else "conv3x3_5x5_pair_c128"):
                       round(sum(a.elapsed_time(b) for a, b in v) / args.steps, 3)
                       for k, v in sorted(prof.items(), key=lambda kv: str(kv[0]))}
-        traffic, traffic_src = pmc_traffic(kname) if B == 4096 else (None, None)
+        traffic, traffic_src = pmc_traffic(kname, "bf16" if args.impl == "bf16" else "eval") if B == 4096 and not args.seqs else (None, None)
         dtype = {"fp16x3": "f32 as 2 power-of-two-scaled fp16 planes x 3 MFMA products, fp32 accumulate (fp32-grade)",
                  "bf16x6": "f32 as 3 bf16 planes x 6 MFMA products, fp32 accumulate (fp32-equivalent)",
                  "f32": "f32", "bf16x3": "bf16x3 (reduced: ~16 significand bits)",
@@ -393,7 +393,7 @@ def run_train(args, world, rank, dev):
         wname = ("wgrad_mfma_f32_kernel<5" if impl == "f32" else
                  "wgrad_k32_kernel<5, 1, 128, 128" if impl == "fp16x3" and not os.environ.get("TSR_WGRAD_M32") else
                  "wgrad_tr16_kernel<5, 1, 128, 128")
-        traffic, traffic_src = pmc_traffic(wname, "train") if B == 2048 and not args.seqs else (None, None)
+        traffic, traffic_src = pmc_traffic(wname, "trainbf16" if impl == "bf16" else "train") if B == 2048 and not args.seqs else (None, None)
         res = {
             "metric": "SR train samples/sec (4x4->%dx%d)" % (side, side), "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),

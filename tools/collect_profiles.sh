@@ -14,9 +14,10 @@ run() {  # name, rocprof args..., -- bench args
   echo "== $name"
   rocprofv3 "$@" > $OUT/$name.log 2>&1
 }
-EVAL="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+EVAL="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-legs"
 TRAIN="python3 bench.py --mode train --steps 3 --warmup 1 --no-cpu-baseline"
-BF16="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --impl bf16"
+BF16="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-legs --impl bf16"
+TRAINBF16="python3 bench.py --mode train --impl bf16 --steps 3 --warmup 1 --no-cpu-baseline"
 TPSF="python3 bench.py --mode tpsf --steps 5 --warmup 1 --no-cpu-baseline"
 run eval_stats   --kernel-trace --stats --output-format csv -d $OUT/eval_stats  -- $EVAL
 run eval_fetch   --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/eval_fetch -- $EVAL
@@ -29,6 +30,11 @@ run train_write  --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/tra
 run train_sq     --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/train_sq -- $TRAIN
 run train_clk    --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/train_clk -- $TRAIN
 run bf16_stats   --kernel-trace --stats --output-format csv -d $OUT/bf16_stats  -- $BF16
+run bf16_fetch   --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/bf16_fetch -- $BF16
+run bf16_write   --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/bf16_write -- $BF16
+run trainbf16_stats --kernel-trace --stats --output-format csv -d $OUT/trainbf16_stats -- $TRAINBF16
+run trainbf16_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/trainbf16_fetch -- $TRAINBF16
+run trainbf16_write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/trainbf16_write -- $TRAINBF16
 run tpsf_stats   --kernel-trace --stats --output-format csv -d $OUT/tpsf_stats  -- $TPSF
 run tpsf_fetch   --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/tpsf_fetch -- $TPSF
 run tpsf_write   --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/tpsf_write -- $TPSF

@@ -61,7 +61,7 @@ def per_launch(v):
     return sum(big) / len(big), len(big)
 
 
-for mode in ("eval", "train", "tpsf"):
+for mode in ("eval", "train", "tpsf", "bf16", "trainbf16"):
     out = {}
     for k, d in collect([f"{mode}_fetch", f"{mode}_write"]).items():
         e = {}
