@@ -378,7 +378,7 @@ def run_train(args, world, rank, dev):
         value = B * world * args.steps / dt
         impl = os.environ.get("TSR_TRAIN_IMPL", "fp16x3")
         nprod, peak = {"bf16x6": (6, PEAK_BF16_MFMA), "fp16x3": (3, PEAK_BF16_MFMA),
-                       "bf16": (1, PEAK_BF16_MFMA)}.get(impl, (1, PEAK_F32_MFMA))
+                       "bf16": (1, PEAK_BF16_MFMA), "bf16op": (1, PEAK_BF16_MFMA)}.get(impl, (1, PEAK_F32_MFMA))
         # fwd + dgrad + wgrad, minus the dgrad of the T+1 stem convs (3->64, 3x3) whose input needs no gradient
         train_flop = 3 * fwd_flop - (model.seqsCnt + 1) * 2 * side * side * 27 * 64
         # dominant kernel of the step: the 5x5 128->128 weight-gradient launches (6 per step)
@@ -390,6 +390,10 @@ def run_train(args, world, rank, dev):
         for k, v in prof.items():
             fam.setdefault(k[0], 0.0)
             fam[k[0]] += sum(a.elapsed_time(b) for a, b in v) / args.steps
+        # the 5x5 128->128 convolution launches of the step (forward + dgrad: the same kernel, 12 launches)
+        cv = prof.get(("fwd", 5, 128, 128), []) + prof.get(("dgrad", 5, 128, 128), [])
+        cv_ms = sum(a.elapsed_time(b) for a, b in cv) / max(1, len(cv))
+        cv_alg = wg_flop / (cv_ms * 1e-3) if cv else None
         wname = ("wgrad_mfma_f32_kernel<5" if impl == "f32" else
                  "wgrad_k32_kernel<5, 1, 128, 128" if impl == "fp16x3" and not os.environ.get("TSR_WGRAD_M32") else
                  "wgrad_tr16_kernel<5, 1, 128, 128")
@@ -400,12 +404,15 @@ def run_train(args, world, rank, dev):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16x6": "f32 as 3 bf16 planes x 6 MFMA products, fp32 accumulate (fp32-equivalent)",
                       "fp16x3": "f32 as 2 scaled fp16 planes x 3 MFMA products, fp32 accumulate (fp32-grade)",
-                      "bf16": "bf16 conv operands, fp32 accumulate / params / activations (reduced precision)"}.get(impl, "f32"),
+                      "bf16": "bf16 activation / gradient STORAGE + bf16 MFMA operands, fp32 accumulate / master weights / BN "
+                              "statistics / weight gradients / Adam (reduced precision: checked against the bf16-emulating oracle)",
+                      "bf16op": "bf16 MFMA operands on fp32 tensors (A/B only)"}.get(impl, "f32"),
             "data": "synthetic",
             "config": {"workload": ("tactileSRSeqs (T=8, 100x100) " if args.seqs else "TactileSR ") +
-                       "train step (train_cal_loss + backward + Adam L2), fp32 params/activations, batch/GPU=%d "
-                       "(BASELINE configs[%s" % (B, "4] shape)" if args.seqs else
-                                                   ("3] per-GPU batch)" if B == 8192 else "3] is 8192/GPU: pass --batch 8192)")),
+                       "train step (train_cal_loss + backward + Adam L2), fp32 params, %s activations, batch/GPU=%d "
+                       "(BASELINE configs[%s" % ("bf16" if impl == "bf16" else "fp32", B, "4] shape)" if args.seqs else
+                                                   (("2] / [3] per-GPU batch)" if impl == "bf16" else "3] per-GPU batch)") if B == 8192
+                                                    else "3] is 8192/GPU: pass --batch 8192)")),
                        "batch_per_gpu": B, "parallelism": f"dp{world}",
                        "grad_allreduce_MB": round(sum(p.numel() for p in model.parameters()) * 4 / 1e6, 2),
                        "grad_buckets": len(eng.arena.buckets) if eng.arena is not None else None,
@@ -419,7 +426,11 @@ def run_train(args, world, rank, dev):
                          "mfma_pipe_util": round(wg_alg * nprod / peak, 4) if wg_alg else None,
                          "avg_launch_ms": round(wg_ms, 3), "launches_timed": len(wg),
                          "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": B * (2 * 128 * side * side * 4) + 128 * 128 * 25 * 4},
+                         "algorithmic_bytes_per_launch": B * (2 * 128 * side * side * (2 if impl == "bf16" else 4)) + 128 * 128 * 25 * 4},
+            "roofline_conv": {"bound": "mfma", "kernel": "5x5 128->128 convolution launches of the step (forward + dgrad, 12 per step)",
+                              "achieved": round(cv_alg / 1e12, 2) if cv_alg else None, "peak": peak / 1e12, "unit": "TFLOP/s",
+                              "frac": round(cv_alg / peak, 4) if cv_alg else None, "avg_launch_ms": round(cv_ms, 3),
+                              "launches_timed": len(cv), "mfma_products_per_mac": nprod},
             "whole_step": {"algorithmic_tflops": round(value / world * train_flop / 1e12, 2),
                            "frac_of_peak": round(value / world * train_flop / peak, 4),
                            "mfma_pipe_util": round(value / world * train_flop * nprod / peak, 4),
