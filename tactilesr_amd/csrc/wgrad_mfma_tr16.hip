@@ -695,6 +695,13 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
   };
 
   auto split_store = [&](f32x4 v, char* dst, int plane_stride, float mult) {
+#ifdef TSR_ABL_WG_NOCVT      // timing ablation (wrong results): the staging path as a pure copy of pre-split data, no VALU.
+    // Measured (round 3, B = 2048): 5x5 128->128 6.27 -> 5.66 ms, 3x3 128->128 2.62 -> 2.35, 5x5 64->64 2.28 -> 2.04: the
+    // ceiling of an operand format pre-split by the producers is -10 % of wgrad (~3 % of the train step).
+    *(float2*)(dst) = make_float2(v[0], v[1]);
+    *(float2*)(dst + plane_stride) = make_float2(v[2], v[3]);
+    (void)mult;
+#else
 #pragma unroll
     for (int c = 0; c < 4; ++c) v[c] *= mult;
 #pragma unroll
@@ -707,6 +714,7 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
       }
       *(PV4*)(dst + p * plane_stride) = qv;
     }
+#endif
   };
 
   auto store_item = [&](int buf) {
