@@ -206,7 +206,37 @@ def run_legs(args, dev):
     leg("tpsf_b8192", run_tpsf, mode="tpsf", steps=20, warmup=3)
     leg("seqs_eval_b512", run_infer, seqs=True, steps=3, warmup=1)
     leg("seqs_train_b256", run_train, mode="train", seqs=True, steps=3, warmup=1)
+    try:
+        legs["eval_b8_latency"] = small_batch_latency(dev)
+    except Exception as e:
+        legs["eval_b8_latency"] = {"error": f"{type(e).__name__}: {e}"}
     return legs
+
+
+def small_batch_latency(dev, B=8, n=100):
+    """Latency of ONE eval forward at the reference's eval batch (test_batch_size = 8, config/default.py:53;
+    train/tactileSR_train.py:66-101), host call to device completion, plain launches vs HIP-graph replay
+    (tactilesr_amd.model.graph.GraphedForward).  Answers whether the host's launch path bounds small batches."""
+    import tactilesr_amd
+    from tactilesr_amd.model.graph import GraphedForward
+    torch.manual_seed(42)
+    m = tactilesr_amd.TactileSR().to(dev).eval()
+    x = (torch.rand(B, 3, 4, 4, generator=torch.Generator().manual_seed(42)) * 8).to(dev)
+    gf = GraphedForward(m, x)
+
+    def lat(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    plain, replay = lat(lambda: m(x)), lat(lambda: gf(x))
+    return {"metric": "eval forward latency at the reference's eval batch", "batch": B, "unit": "ms per forward (back to back)",
+            "plain_launches_ms": round(plain, 4), "hip_graph_replay_ms": round(replay, 4),
+            "samples_per_s_plain": round(B / plain * 1e3, 1), "forwards_timed": n}
 
 
 def run_infer(args, world, rank, dev):

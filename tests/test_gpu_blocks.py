@@ -178,3 +178,40 @@ def test_device_resident_loader_on_cuda_drives_the_trainer_step():
     mse, ssim, psnr = TR.eval_func(m, DeviceSRLoader(LR, HR, batch_size=8, device="cuda"), conf)
     assert mse > 0 and -1 <= ssim <= 1 and psnr == psnr
     assert ld.epoch == 2
+
+
+def test_graphed_eval_forward_small_batch_replay():
+    """HIP-graph replay of the eval forward at the reference's eval batch (8; config/default.py:53): bit-identical to the
+    plain forward on fresh inputs, follows a parameter update (re-captures), refuses train mode / other shapes; prints the
+    host-side latency of both forms."""
+    import time
+    import tactilesr_amd
+    from tactilesr_amd.model.graph import GraphedForward
+    torch.manual_seed(42)
+    m = tactilesr_amd.TactileSR().cuda().eval()
+    g = torch.Generator().manual_seed(1)
+    xs = [(torch.rand(8, 3, 4, 4, generator=g) * 8).cuda() for _ in range(3)]
+    gf = GraphedForward(m, xs[0])
+    for x in xs:
+        assert torch.equal(gf(x).clone(), m(x))
+    with torch.no_grad():
+        m.output_layer[2].weight.mul_(2.0)
+    y = gf(xs[1]).clone()
+    assert gf.captures == 2 and torch.equal(y, m(xs[1]))
+
+    def lat(fn, n=50):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    t_plain, t_graph = lat(lambda: m(xs[0])), lat(lambda: gf(xs[0]))
+    print(f"[graph replay] B=8 eval forward: plain {t_plain:.3f} ms, HIP-graph replay {t_graph:.3f} ms")
+    assert t_graph < t_plain * 1.1
+    with pytest.raises(Exception, match="input shape"):
+        gf(torch.zeros(4, 3, 4, 4, device="cuda"))
+    m.train()
+    with pytest.raises(Exception, match="train mode"):
+        gf(xs[0])
