@@ -306,6 +306,50 @@ def _train_step_vs_oracle(T, cfg, B, seed, tol=2e-5, loss_tol=1e-5):
     return m
 
 
+def test_train_step_distinct_frames_wide_amplitude_vs_oracle(T):
+    """The train step on 160 DISTINCT frames whose taxel amplitudes span 2^8 (frame k: rand * 8 * 2^-(k mod 9)) -- the
+    large-batch train tests tile 32 frames, and every operand scale of the fp16x3 path (activations, dz, gradients) is a
+    tensor-wide max|.|, so quiet frames share their scales with frames 256x louder in forward AND backward.  Loss and
+    running statistics at 1e-5, the ReLU pattern equal to fp64's up to rounding-zero flips, every parameter gradient at
+    2e-5 (max-norm) against the fp64 oracle gradient on the device's pattern; and the OUTPUT per frame relative to the
+    frame's own maximum, quiet classes at 1e-5 (train-mode BatchNorm couples the frames through the batch statistics,
+    so a quiet frame's activations are not small -- the check is on what the tensor-wide scale does to them)."""
+    cfg = dict(patternFeatureExtraLayerCnt=2)
+    sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), 4711)
+    g = torch.Generator().manual_seed(4712)
+    B = 160
+    cls = torch.arange(B) % 9
+    LR = torch.rand(B, 3, 4, 4, generator=g) * 8 * (2.0 ** -cls.float()).view(-1, 1, 1, 1)
+    HR = torch.rand(B, 1, 40, 40, generator=g) * 25
+    l64, _, ns64, pre64 = GC.oracle_grads(sd, LR, HR, record=True)
+    m = T.TactileSR(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    eng = _debug_engine(m)
+    out = m(LR.cuda())
+    loss = F.mse_loss(out, HR.cuda())
+    assert abs(loss.item() - l64) < 1e-5 * abs(l64)
+    with torch.no_grad():
+        ref = O.tactilesr_forward({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, LR.double(),
+                                  training=True)
+    per = (out.detach().cpu().double() - ref).abs().amax(dim=(1, 2, 3)) / ref.abs().amax(dim=(1, 2, 3)).clamp_min(1e-30)
+    live = ref.abs().amax(dim=(1, 2, 3)) > 1e-3 * float(ref.abs().max())
+    quiet = live & (cls >= 5)
+    print(f"[train wide amplitude] per-frame output error: quiet classes {float(per[quiet].max()):.2e}, all live frames "
+          f"{float(per[live].max()):.2e}")
+    assert int(quiet.sum()) >= 60 and float(per[quiet].max()) < 1e-5
+    loss.backward()
+    new_sd = m.state_dict()
+    for k, v in ns64.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert relerr(new_sd[k], v) < 1e-5, k
+    masks = {k: v.cpu() for k, v in eng.activation_masks(eng.last_ctx).items()}
+    flips = GC.check_pattern(masks, pre64)
+    _, g64m, _, _ = GC.oracle_grads(sd, LR, HR, masks=masks)
+    worst = GC.check_grads({k: p.grad for k, p in m.named_parameters()}, g64m, tol=2e-5)
+    print(f"[train wide amplitude] {flips} ReLU flips; worst on-pattern grad error {worst[0]:.2e} ({worst[1]})")
+
+
 @pytest.mark.parametrize("B", [1, 2])
 def test_train_step_seqs_T8_sf25_vs_oracle(T, B):
     """BASELINE configs[4] shape as a TRAIN step: TactileSR(scale_factor=25, seqsCnt=8), 4x4x24 -> 100x100, default
