@@ -215,7 +215,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
   const char* wsrc = (const char*)a.wp;
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 0x7fffffff, 0x00020000);
 
-  auto load_halo = [&](int c, f32x4* hv) {
+  auto load_halo = [&](int c, f32x4* hv) __attribute__((always_inline)) {
     // (an odd block count is padded to even: the phantom block re-reads the last real one against zero weights)
     const float* inc = in_base + (size_t)(c < nreal ? c : nreal - 1) * HW * 16;
     // branch-free: out-of-image items read a valid dummy address (offset 0) and are zeroed by their scale in store_halo
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
 #pragma unroll
     for (int k = 0; k < NIT; ++k) hv[k] = *(const f32x4*)(inc + (unsigned)(st_src[k] < 0 ? 0 : st_src[k]));
   };
-  auto store_halo = [&](const f32x4* hv, int c, int hb = 0) {
+  auto store_halo = [&](const f32x4* hv, int c, int hb = 0) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       if (st_dst[k] >= 0) {
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
 
   int s = 0;
   int slot = 0;                            // s % 3, kept incrementally
-  auto block = [&](int c, auto oddc) {
+  auto block = [&](int c, auto oddc) __attribute__((always_inline)) {
     constexpr int ODD = decltype(oddc)::value;
     constexpr int NST = HS + ODD;
 #pragma unroll

@@ -524,16 +524,16 @@ __global__ void pack_conv_weight_bf16s_kernel(const float* __restrict__ w, typen
 // pairs; TSR_CONV_M32=1 keeps the 32x32x16 kernel of this file (A/B measurements).  Pack and launch ask the same question.
 int tsr_conv_k32(const ConvArgs& a, int cout, int ks, bool ext, hipStream_t st);      // conv_mfma_k32.hip
 int tsr_conv_k32_fuse1x1(const ConvArgs& a, int ks, hipStream_t st);
-// C_out = 64: the 3x3 convs run the K = 32 kernel too since round 3 (4 images x all 64 channels per workgroup, double-
-// buffered halo: eval 1.62 -> 1.46 ms per launch at B = 4096, train dgrad 1.02 -> 0.98 ms at B = 2048; TSR_CONV_K32_NO64=1
-// keeps them on the 32x32x16 kernel).  The 5x5 C_out = 64 convs stay on the 32x32x16 kernel: the training instantiation of
-// their K = 32 form keeps an array in scratch (1.64 -> 4.78 ms); TSR_CONV_K32_ALL=1 routes them there as well (A/B).
+// C_out = 64 convs run the K = 32 kernel too since round 3 (4 images x all 64 channels per workgroup): 3x3 eval 1.62 ->
+// 1.46 ms per launch at B = 4096, train (B = 2048) 3x3 dgrad 1.02 -> 0.96 ms, 5x5 forward 1.61 -> 1.45, 5x5 dgrad
+// 1.74 -> 1.63.  In round 2 the training instantiation of the 5x5 form ran 3x slower: one of the kernel's lambdas was
+// not inlined there, so its by-reference captures (the argument block, the staging index arrays) lived in scratch;
+// the lambdas are always_inline now.  TSR_CONV_K32_NO64=1 keeps C_out = 64 on the 32x32x16 kernel (A/B).
 static bool use_k32(int ks, int kdim, int cout) {
   static const bool off = getenv("TSR_CONV_M32") != nullptr;
-  static const bool all = getenv("TSR_CONV_K32_ALL") != nullptr;
   static const bool no64 = getenv("TSR_CONV_K32_NO64") != nullptr;
   (void)kdim;          // an odd channel-block count is padded with a zero-weight block (pack) / a re-read block (kernel)
-  return !off && ks > 1 && (cout == 128 || all || (cout == 64 && ks == 3 && !no64));
+  return !off && ks > 1 && (cout == 128 || (cout == 64 && !no64));
 }
 // images per workgroup (= statistics-slab entries per workgroup) of the fp16x3 kernel that runs (cout, ks)
 int tsr_conv_k32_images(int cout);            // conv_mfma_k32.hip
