@@ -286,10 +286,20 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
     char* wb_ = wbuf + (slot) * WSLAB_B;                                                 \
     _Pragma("unroll") for (int v = 0; v < WV; ++v) ((f32x4*)wb_)[tid + v * NTHR] = wreg[v]; \
   }
+#if defined(TSR_ABL_K32_NOW2)      // slabs 0..2 only (real data in LDS, no stream)
+#define DMA_W(sidx, slot) { if ((sidx) < 3) DMA_BYTES((size_t)(sidx) * WSLAB_B, slot, WV) }
+#elif defined(TSR_ABL_K32_NOW3)    // the stream re-reads slabs 0..2 (L1 / L2 hot)
+#define DMA_W(sidx, slot) DMA_BYTES((size_t)((sidx) % 3) * WSLAB_B, slot, WV)
+#else
 #define DMA_W(sidx, slot) DMA_BYTES((size_t)(sidx) * WSLAB_B, slot, WV)
+#endif
   // wait for the slab only: the n_ YOUNGEST vector-memory operations (the next block's halo loads, issued after the
   // slab request of the same step) may stay in flight -- vmcnt counts in issue order
+#ifdef TSR_ABL_K32_NOWAIT          // timing only: the slab is not awaited (racy)
+#define DMA_WAIT_N(n_) {}
+#else
 #define DMA_WAIT_N(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14))
+#endif
 #define DMA_WAIT() DMA_WAIT_N(0)
   // pair form: the slabs of the outer-ring steps hold the 5x5 conv's 64 channels only (half size); the stream is walked
   // with a running offset.  pq_ = index of the step within its block pair (0..24), compile time.

@@ -39,7 +39,7 @@ def test_tpsf_forward_backward_vs_reference_golden(golden):
         ref = torch.from_numpy(g[f"grad/{k}"])
         err = relerr(p.grad, ref)
         print(f"[tpsf grad] {k}: {err:.2e}")
-        assert err < 1e-4, (k, err)
+        assert err < 2e-5, (k, err)
 
 
 def test_tpsf_large_batch_properties():
@@ -150,7 +150,7 @@ def test_tpsf_kernels_wide_dynamic_range_batch():
         assert relerr(HR[i], HR64[i]) < 1e-5, i
         assert relerr(psf[i], psf64[i]) < 1e-5, i
     assert relerr(LRd[:n], LR64.reshape(n, 16)) < 1e-5
-    assert relerr(dab[:n], ab64.grad) < 2e-5
+    assert relerr(dab[:n], ab64.grad) < 1e-5
     assert torch.isfinite(HR).all() and torch.isfinite(dab).all()
 
 
@@ -187,7 +187,7 @@ def test_tpsf_B8192_forward_backward_tiling_invariance():
     gl = torch.autograd.grad(lo, list(leaves.values()))
     assert abs(loss.item() - lo.item()) < 1e-5 * lo.item()
     for (k, p), ref in zip(net.named_parameters(), gl):
-        assert relerr(p.grad, ref) < 1e-4, k
+        assert relerr(p.grad, ref) < 2e-5, k
 
 
 def test_seqs_dataset_generator_matches_the_batch1_loop(tmp_path):

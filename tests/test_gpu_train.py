@@ -74,8 +74,8 @@ def test_conv2d_wgrad(T, ks, cin, cout, B, H, W, affine, impl):
     outb = torch.empty(cout, device="cuda")
     call("tsr_reduce_splits", ptr(slab), ptr(out), L(n), I(ns), Fl(1.0), stream())
     call("tsr_reduce_splits", ptr(bslab), ptr(outb), L(cout), I(ns), Fl(1.0), stream())
-    assert relerr(out, gw) < 2e-5
-    assert relerr(outb, gb) < 2e-5
+    assert relerr(out, gw) < 1e-5
+    assert relerr(outb, gb) < 1e-5
 
 
 @pytest.mark.parametrize("ks,cin,cout,B,H,W,NP", [(3, 64, 64, 3, 40, 40, 64), (5, 128, 128, 2, 16, 24, 64),
@@ -126,9 +126,9 @@ def test_conv2d_dgrad_with_mask_and_bn_sums(T, ks, cin, cout, B, H, W, NP):
         assert am.item() == T.from_cb16(gbuf, B, cin, H, W)[:, o:o + NP].abs().max().item()
         dgam.append(out[0].clone())
         dbet.append(out[1].clone())
-    assert relerr(T.from_cb16(gbuf, B, cin, H, W), gz) < 2e-5
-    assert relerr(torch.cat(dgam), ggm) < 2e-5
-    assert relerr(torch.cat(dbet), gbt) < 2e-5
+    assert relerr(T.from_cb16(gbuf, B, cin, H, W), gz) < 1e-5
+    assert relerr(torch.cat(dgam), ggm) < 1e-5
+    assert relerr(torch.cat(dbet), gbt) < 1e-5
 
 
 def _subs(t, k=512):
@@ -153,7 +153,7 @@ def test_train_forward_backward_vs_reference_golden(T, golden, impl, monkeypatch
     assert abs(loss.item() - g["losses"][0]) <= 1e-5 * abs(g["losses"][0])
     loss.backward()
     named = dict(m.named_parameters())
-    # Gradients, hard bar: max-norm 2e-5 on EVERY parameter against the fp64 oracle gradient evaluated on the ReLU
+    # Gradients, hard bar: max-norm 1e-5 on EVERY parameter against the fp64 oracle gradient evaluated on the ReLU
     # pattern the device took; the pattern itself must equal the fp64 pattern except at pre-activations that are
     # zero to rounding (tests/_gradcheck.py explains why the two halves are separated).
     masks = {k: v.cpu() for k, v in m._train_engine.activation_masks(m._train_engine.last_ctx).items()}
@@ -162,7 +162,7 @@ def test_train_forward_backward_vs_reference_golden(T, golden, impl, monkeypatch
     assert abs(l64 - float(g["loss64"])) <= 1e-9 * abs(l64)          # the oracle's fp64 run IS the reference's
     flips = GC.check_pattern(masks, pre64)
     _, g64m, _, _ = GC.oracle_grads(sd, LRc, HRc, masks=masks)
-    worst = GC.check_grads({k: p.grad for k, p in named.items()}, g64m, tol=2e-5)
+    worst = GC.check_grads({k: p.grad for k, p in named.items()}, g64m, tol=1e-5)
     print(f"[grad {impl}] {flips} ReLU flips vs fp64; worst on-pattern max-norm error {worst[0]:.2e} ({worst[1]})")
     # Gradients, bridge to the reference's own numbers: the fixture holds the reference's fp32 and fp64 gradients
     # (each on its own ReLU pattern).  The HIP gradient must sit as close to the reference's fp64 run as the
@@ -180,7 +180,7 @@ def test_train_forward_backward_vs_reference_golden(T, golden, impl, monkeypatch
         n64 = max(np.linalg.norm(ref64), 1e-30)
         l2_hip, l2_ref = float(np.linalg.norm(got - ref64) / n64), float(np.linalg.norm(ref32 - ref64) / n64)
         print(f"[grad] {k}: hip-vs-f64 {e_hip:.2e} (L2 {l2_hip:.2e})  ref32-vs-f64 {e_ref:.2e} (L2 {l2_ref:.2e})")
-        assert e_hip <= max(2e-5, 4 * e_ref) and l2_hip <= max(2e-5, 4 * l2_ref), (k, e_hip, e_ref, l2_hip, l2_ref)
+        assert e_hip <= max(1e-5, 4 * e_ref) and l2_hip <= max(1e-5, 4 * l2_ref), (k, e_hip, e_ref, l2_hip, l2_ref)
     new_sd = m.state_dict()
     for s in [str(s) for s in g["stat_keys"]]:
         assert relerr(new_sd[s + ".running_mean"], torch.from_numpy(g[f"stat/{s}.running_mean"])) < 1e-5, s
@@ -272,14 +272,14 @@ def test_eval_func_after_training_uses_updated_running_stats(T):
 @pytest.mark.parametrize("Tn,nm,B,sf", [(2, 1, 3, 10), (2, 1, 4, 10), (1, 2, 3, 10), (1, 1, 2, 25), (2, 1, 1, 25)])
 def test_train_multiframe_and_odd_batch_vs_oracle(T, Tn, nm, B, sf):
     """seqsCnt=2 (two stems -> channel-stacked fuse conv) and odd batches (image-pair tail): loss, running stats
-    and EVERY parameter gradient against the CPU oracle in fp64, max-norm 2e-5 on the device's own ReLU pattern
+    and EVERY parameter gradient against the CPU oracle in fp64, max-norm 1e-5 on the device's own ReLU pattern
     (tests/_gradcheck.py); the pattern may differ from fp64's only at pre-activations that are zero to rounding.
     sf=25 is the tactileSRSeqs output size: 100x100 = 12.5 patches of 8 (ragged tiles in every train-mode epilogue,
     dgrad and wgrad)."""
     _train_step_vs_oracle(T, dict(seqsCnt=Tn, patternFeatureExtraLayerCnt=nm, scale_factor=sf), B, 977)
 
 
-def _train_step_vs_oracle(T, cfg, B, seed, tol=2e-5, loss_tol=1e-5):
+def _train_step_vs_oracle(T, cfg, B, seed, tol=1e-5, loss_tol=1e-5):
     sf, Tn = cfg.get("scale_factor", 10), cfg.get("seqsCnt", 1)
     sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), seed)
     g = torch.Generator().manual_seed(seed + 1)
@@ -311,7 +311,7 @@ def test_train_step_distinct_frames_wide_amplitude_vs_oracle(T):
     large-batch train tests tile 32 frames, and every operand scale of the fp16x3 path (activations, dz, gradients) is a
     tensor-wide max|.|, so quiet frames share their scales with frames 256x louder in forward AND backward.  Loss and
     running statistics at 1e-5, the ReLU pattern equal to fp64's up to rounding-zero flips, every parameter gradient at
-    2e-5 (max-norm) against the fp64 oracle gradient on the device's pattern; and the OUTPUT per frame relative to the
+    1e-5 (max-norm) against the fp64 oracle gradient on the device's pattern; and the OUTPUT per frame relative to the
     frame's own maximum, quiet classes at 1e-5 (train-mode BatchNorm couples the frames through the batch statistics,
     so a quiet frame's activations are not small -- the check is on what the tensor-wide scale does to them)."""
     cfg = dict(patternFeatureExtraLayerCnt=2)
@@ -346,7 +346,7 @@ def test_train_step_distinct_frames_wide_amplitude_vs_oracle(T):
     masks = {k: v.cpu() for k, v in eng.activation_masks(eng.last_ctx).items()}
     flips = GC.check_pattern(masks, pre64)
     _, g64m, _, _ = GC.oracle_grads(sd, LR, HR, masks=masks)
-    worst = GC.check_grads({k: p.grad for k, p in m.named_parameters()}, g64m, tol=2e-5)
+    worst = GC.check_grads({k: p.grad for k, p in m.named_parameters()}, g64m, tol=1e-5)
     print(f"[train wide amplitude] {flips} ReLU flips; worst on-pattern grad error {worst[0]:.2e} ({worst[1]})")
 
 
@@ -354,8 +354,9 @@ def test_train_step_distinct_frames_wide_amplitude_vs_oracle(T):
 def test_train_step_seqs_T8_sf25_vs_oracle(T, B):
     """BASELINE configs[4] shape as a TRAIN step: TactileSR(scale_factor=25, seqsCnt=8), 4x4x24 -> 100x100, default
     fp16x3 arithmetic against the fp64 oracle (2 MSRBs keep the CPU side in seconds; every kernel shape of the full
-    net is exercised: 8 stems, the 512->64 fuse conv, ragged 12.5-patch tiles)."""
-    _train_step_vs_oracle(T, dict(seqsCnt=8, scale_factor=25, patternFeatureExtraLayerCnt=2), B, 1977)
+    net is exercised: 8 stems, the 512->64 fuse conv, ragged 12.5-patch tiles).  Gradient bar 2e-5 (the sf = 10 tests hold
+    1e-5): 10^4 output pixels funnel into 16 LR taxels per stem weight; measured 1.07e-5 on ONE stem weight tensor."""
+    _train_step_vs_oracle(T, dict(seqsCnt=8, scale_factor=25, patternFeatureExtraLayerCnt=2), B, 1977, tol=2e-5)
 
 
 def test_train_step_seqs_T8_sf25_bf16_reduced_precision(T, monkeypatch):
@@ -383,7 +384,7 @@ def test_train_step_seqs_T8_sf25_bf16_reduced_precision(T, monkeypatch):
         assert cos > 0.95, (k, cos)      # measured worst 0.978 (a stem weight: 8 plain-bf16 stems feed a 512-ch fuse conv)
 
 
-def _tiled_train_step(T, reps, cfg, seed):
+def _tiled_train_step(T, reps, cfg, seed, tol=1e-5):
     """Size-independent property at a large batch (B = 32 base frames tiled `reps` times): batch statistics, the MSE
     loss and hence every gradient of a tiled batch equal those of the 32 base frames, which the CPU oracle can run.
     The activation pattern of the first 32 frames must equal fp64's up to rounding-zero flips, all replicas must
@@ -411,7 +412,7 @@ def _tiled_train_step(T, reps, cfg, seed):
     eng.last_ctx = None
     flips = GC.check_pattern(masks, pre64)
     _, g64m, _, _ = GC.oracle_grads(sd, LRb, HRb, masks=masks)
-    worst = GC.check_grads({k: p.grad for k, p in m.named_parameters()}, g64m, tol=2e-5)
+    worst = GC.check_grads({k: p.grad for k, p in m.named_parameters()}, g64m, tol=tol)
     print(f"[tiled x{reps}] {flips} ReLU flips; worst on-pattern grad error {worst[0]:.2e} ({worst[1]})")
     return m
 
@@ -422,9 +423,11 @@ def test_large_batch_train_step_tiling_invariance(T):
 
 def test_train_step_B8192_tiling_invariance(T):
     """BASELINE configs[2]/[3] per-GPU batch: one full TactileSR (6 MSRB) train step at B = 8192 (168 GB of saved
-    activations in HBM) = 32 frames x 256."""
+    activations in HBM) = 32 frames x 256.  Gradient bar 2e-5 here (every other whole-step test: 1e-5): a weight-gradient
+    entry is an fp32 sum of 8192 x 1600 products; measured 1.2e-5 of the tensor max on four conv_5_2 weights (the
+    same step at 32 x 5 frames holds 1e-5)."""
     torch.cuda.empty_cache()
-    m = _tiled_train_step(T, 256, dict(), 42)
+    m = _tiled_train_step(T, 256, dict(), 42, tol=2e-5)
     del m
     torch.cuda.empty_cache()
 
@@ -591,7 +594,7 @@ def test_multi_step_loss_trajectory_tracks_the_oracle(T):
     rel = [abs(a - b) / abs(a) for a, b in zip(ref, got)]
     print("[trajectory]", ["%.1e" % r for r in rel])
     assert ref[-1] < 0.8 * ref[0]                     # the curve is alive
-    assert max(rel[:3]) < 2e-5 and max(rel) < 1e-3, rel
+    assert max(rel[:3]) < 1e-5 and max(rel) < 1e-3, rel
 
 
 def test_seqs_transplant_forward_backward_frozen_blocks(T):
@@ -631,7 +634,7 @@ def test_seqs_transplant_forward_backward_frozen_blocks(T):
     masks = {k: v.cpu() for k, v in eng.activation_masks(eng.last_ctx).items()}
     GC.check_pattern(masks, pre64)
     _, g64m, _, _ = GC.oracle_grads(sd, LR, HR, masks=masks)
-    GC.check_grads({k: p.grad for k, p in m.named_parameters()}, g64m, tol=2e-5)
+    GC.check_grads({k: p.grad for k, p in m.named_parameters()}, g64m, tol=1e-5)
     before = {k: v.detach().clone() for k, v in m.state_dict().items()}
     opt.step()
     after = m.state_dict()
