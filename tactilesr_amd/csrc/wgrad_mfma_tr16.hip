@@ -23,6 +23,7 @@
 // free for every tap.  Staging writes are 8 B per lane, 512 contiguous bytes per wave: conflict free.
 #include "tsr_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __bf16 tb16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 tb16x4 __attribute__((ext_vector_type(4)));
@@ -550,9 +551,14 @@ struct WgradKGeom {
   static constexpr int DZ_BLKB = tr16_pad_px(4 * PITCH) * 32, A_BLKB = tr16_pad_px(AROWS * PITCH) * 32;
   static constexpr int DZ_PLANEB = (CO / 16) * DZ_BLKB, A_PLANEB = (CI / 16) * A_BLKB;
   static constexpr int BUFB = 2 * (DZ_PLANEB + A_PLANEB);
-  static constexpr int N_DZ = DZ_PX * (CO / 16) * 4, N_A = A_PX * (CI / 16) * 4;
-  static constexpr int NIT_DZ = (N_DZ + NT - 1) / NT, NIT_A = (N_A + NT - 1) / NT;
-  static constexpr int LDSB = (2 * BUFB > 32 * CO * 4 ? 2 * BUFB : 32 * CO * 4) + CI * 8;
+  // staging map: thread = (channel quad q, pixel-in-group pl, 16-channel block, pixel group); a thread keeps ONE channel
+  // quad of ONE block for the whole kernel (its BN scale / shift live in 8 registers, its bias partial sums in 4) and
+  // walks groups of 4 consecutive pixels: 16 lanes = 4 pixels x 64 B in memory, 128 contiguous bytes per plane in LDS
+  static constexpr int NPG_DZ = NT / 16 / (CO / 16), NPG_A = NT / 16 / (CI / 16);     // pixel groups per pass
+  static constexpr int NIT_DZ = (DZ_PX / 4 + NPG_DZ - 1) / NPG_DZ, NIT_A = (A_PX / 4 + NPG_A - 1) / NPG_A;
+  static constexpr int BRED_SLOTS = 4 * NPG_DZ;
+  static constexpr int LDSB = 2 * BUFB > BRED_SLOTS * CO * 4 ? 2 * BUFB : BRED_SLOTS * CO * 4;
+  static_assert(NT % 16 == 0 && (NT / 16) % (CO / 16) == 0 && (NT / 16) % (CI / 16) == 0 && A_PX % 4 == 0, "staging map");
 };
 
 template <int KS, int KHW, int CO, int CI, int WM>
@@ -624,11 +630,7 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
 #pragma unroll
       for (int k = 0; k < G::NTAP; ++k) acc[m][n][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float bsum[G::NIT_DZ][4];
-#pragma unroll
-  for (int j = 0; j < G::NIT_DZ; ++j)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bsum[j][q] = 0.f;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
   const int tpi = g.tiles_x * g.tiles_y;
   const int total_items = g.B * tpi;
@@ -637,34 +639,34 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
   const int it1 = it0 + per < total_items ? it0 + per : total_items;
   int nb = it0 / tpi, nty = (it0 - nb * tpi) / g.tiles_x, ntx = it0 - nb * tpi - nty * g.tiles_x;
 
-  // staging slots (see wgrad_tr16_kernel): branch-free loads, scalar item base + 32-bit per-thread offsets
-  int offd[G::NIT_DZ], safed[G::NIT_DZ], offa[G::NIT_A], safea[G::NIT_A], rcd[G::NIT_DZ], rca[G::NIT_A], ldsd[G::NIT_DZ], ldsa[G::NIT_A];
+  // staging slots: branch-free loads, scalar item base + 32-bit per-thread offsets (out-of-image slots read the thread's
+  // own (block, quad) at the item's first pixel and are zeroed when stored)
+  const int sq = tid & 3, spl = (tid >> 2) & 3;
+  const int blkd = (tid >> 4) % (CO / 16), pgd = (tid >> 4) / (CO / 16);
+  const int blka = (tid >> 4) % (CI / 16), pga = (tid >> 4) / (CI / 16);
+  const int safed = blkd * HW * 16 + sq * 4, safea = blka * HW * 16 + sq * 4;
+  int offd[G::NIT_DZ], offa[G::NIT_A], rcd[G::NIT_DZ], rca[G::NIT_A], ldsd[G::NIT_DZ], ldsa[G::NIT_A];
 #pragma unroll
   for (int j = 0; j < G::NIT_DZ; ++j) {
-    const int i = (tid + j * NT) % G::N_DZ;
-    const int q = i & 3, px = (i >> 2) & 31, blk = i >> 7;
-    safed[j] = blk * HW * 16 + q * 4;
-    offd[j] = safed[j] + ((px >> 3) * g.W + (px & 7)) * 16;
+    const int px = 4 * (pgd + j * G::NPG_DZ) + spl;          // may run past the tile in the last pass: never stored
+    offd[j] = safed + ((px >> 3) * g.W + (px & 7)) * 16;
     rcd[j] = ((px >> 3) << 8) | (px & 7);
-    ldsd[j] = blk * G::DZ_BLKB + ((px >> 3) * G::PITCH + (px & 7)) * 32 + q * 8;
+    ldsd[j] = blkd * G::DZ_BLKB + ((px >> 3) * G::PITCH + (px & 7)) * 32 + sq * 8;
   }
 #pragma unroll
   for (int j = 0; j < G::NIT_A; ++j) {
-    const int i = (tid + j * NT) % G::N_A;
-    const int q = i & 3, pi = i >> 2;
-    const int px = pi % G::A_PX, blk = pi / G::A_PX;
+    const int px = 4 * (pga + j * G::NPG_A) + spl;
     const int r = px / G::ACOLS, cx = px - r * G::ACOLS;
-    safea[j] = blk * HW * 16 + q * 4;
-    offa[j] = safea[j] + ((r + kh0 - P) * g.W + cx - P) * 16;
+    offa[j] = safea + ((r + kh0 - P) * g.W + cx - P) * 16;
     rca[j] = (r << 8) | cx;
-    ldsa[j] = blk * G::A_BLKB + (r * G::PITCH + cx) * 32 + q * 8;
+    ldsa[j] = blka * G::A_BLKB + (r * G::PITCH + cx) * 32 + sq * 8;
   }
-  float* tsc = (float*)(lds + 2 * G::BUFB);
+  // the producer's BN scale / shift of this thread's channel quad, pre-multiplied by the staging scale
+  // (2 relu(t) = t + |t| is positively homogeneous)
+  f32x4 tsc = {0.f, 0.f, 0.f, 0.f}, tsh = {0.f, 0.f, 0.f, 0.f};
   if (g.a_scale) {
-    for (int c = threadIdx.x; c < CI; c += NT) {
-      tsc[c] = g.a_scale[cib * CI + c];
-      tsc[CI + c] = g.a_shift[cib * CI + c];
-    }
+    tsc = *(const f32x4*)(g.a_scale + cib * CI + blka * 16 + sq * 4) * s_ah;
+    tsh = *(const f32x4*)(g.a_shift + cib * CI + blka * 16 + sq * 4) * s_ah;
   }
 
   f32x4 hd[G::NIT_DZ], ha[G::NIT_A];
@@ -681,15 +683,15 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
     okd = oka = 0;
 #pragma unroll
     for (int j = 0; j < G::NIT_DZ; ++j) {
-      const bool ok = (y0 + (rcd[j] >> 8) < g.H) & (x0 + (rcd[j] & 255) < g.W);
-      hd[j] = *(const f32x4*)(dzb + (ok ? offd[j] : safed[j]));
+      const bool ok = (y0 + (rcd[j] >> 8) < g.H) & (x0 + (rcd[j] & 255) < g.W) & ((rcd[j] >> 8) < 4);
+      hd[j] = *(const f32x4*)(dzb + (ok ? offd[j] : safed));
       okd |= (unsigned)ok << j;
     }
 #pragma unroll
     for (int j = 0; j < G::NIT_A; ++j) {
       const int gy = y0 + (rca[j] >> 8) + kh0 - P, gx = x0 + (rca[j] & 255) - P;
-      const bool ok = (gy >= 0) & (gy < g.H) & (gx >= 0) & (gx < g.W);
-      ha[j] = *(const f32x4*)(ab + (ok ? offa[j] : safea[j]));
+      const bool ok = (gy >= 0) & (gy < g.H) & (gx >= 0) & (gx < g.W) & ((rca[j] >> 8) < G::AROWS);
+      ha[j] = *(const f32x4*)(ab + (ok ? offa[j] : safea));
       oka |= (unsigned)ok << j;
     }
   };
@@ -698,8 +700,11 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
 #ifdef TSR_ABL_WG_NOCVT      // timing ablation (wrong results): the staging path as a pure copy of pre-split data, no VALU.
     // Measured (round 3, B = 2048): 5x5 128->128 6.27 -> 5.66 ms, 3x3 128->128 2.62 -> 2.35, 5x5 64->64 2.28 -> 2.04: the
     // ceiling of an operand format pre-split by the producers is -10 % of wgrad (~3 % of the train step).
-    *(float2*)(dst) = make_float2(v[0], v[1]);
-    *(float2*)(dst + plane_stride) = make_float2(v[2], v[3]);
+    // (the bits are masked into small finite fp16 values: NaN / Inf operands would change the chip's power and clock)
+    uint2 w0 = {__float_as_uint(v[0]) & 0x33ff33ffu, __float_as_uint(v[1]) & 0x33ff33ffu};
+    uint2 w1 = {__float_as_uint(v[2]) & 0x33ff33ffu, __float_as_uint(v[3]) & 0x33ff33ffu};
+    *(uint2*)(dst) = w0;
+    *(uint2*)(dst + plane_stride) = w1;
     (void)mult;
 #else
 #pragma unroll
@@ -712,7 +717,11 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
         qv[c] = (PT)v[c];
         v[c] -= (float)qv[c];
       }
+#ifdef TSR_ABL_WG_NODSW      // timing ablation: conversions kept, LDS writes dropped
+      asm volatile("" :: "v"(qv));
+#else
       *(PV4*)(dst + p * plane_stride) = qv;
+#endif
     }
 #endif
   };
@@ -722,28 +731,29 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
     char* at = dzt + 2 * G::DZ_PLANEB;
 #pragma unroll
     for (int j = 0; j < G::NIT_DZ; ++j) {
-      if ((j + 1) * NT <= G::N_DZ || tid + j * NT < G::N_DZ) {
+      if (4 * (j + 1) * G::NPG_DZ <= G::DZ_PX || 4 * (pgd + j * G::NPG_DZ) < G::DZ_PX) {
         const f32x4 v = hd[j];
         const bool ok = (okd >> j) & 1;
         if (do_bias) {
           const float keep = ok ? 1.f : 0.f;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) bsum[j][c] = fmaf(v[c], keep, bsum[j][c]);
+          for (int c = 0; c < 4; ++c) bsum[c] = fmaf(v[c], keep, bsum[c]);
         }
         split_store(v, dzt + ldsd[j], G::DZ_PLANEB, ok ? s_d : 0.f);
       }
     }
 #pragma unroll
     for (int j = 0; j < G::NIT_A; ++j) {
-      if ((j + 1) * NT <= G::N_A || tid + j * NT < G::N_A) {
+      if (4 * (j + 1) * G::NPG_A <= G::A_PX || 4 * (pga + j * G::NPG_A) < G::A_PX) {
         f32x4 v = ha[j];
+        const bool ok = (oka >> j) & 1;
         if (g.a_scale) {
-          const int cq = ((ldsa[j] / G::A_BLKB) * 16) + ((ldsa[j] >> 1) & 12);
-          const f32x4 sc = *(const f32x4*)(tsc + cq), sh = *(const f32x4*)(tsc + CI + cq);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = tsr_relu_x2(fmaf(v[c], sc[c], sh[c]));      // 2 relu(.): s_ah = s_a / 2
+          for (int c = 0; c < 4; ++c) v[c] = tsr_relu_x2(fmaf(v[c], tsc[c], tsh[c]));      // 2 relu(.) s_ah
+          split_store(v, at + ldsa[j], G::A_PLANEB, ok ? 1.f : 0.f);
+        } else {
+          split_store(v, at + ldsa[j], G::A_PLANEB, ok ? s_ah : 0.f);
         }
-        split_store(v, at + ldsa[j], G::A_PLANEB, ((oka >> j) & 1) ? s_ah : 0.f);
       }
     }
   };
@@ -754,7 +764,8 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
   const int a_lane = (wm * MT) * G::DZ_BLKB + (gq * G::PITCH + tq) * 32 + tp * 8;
   const int b_lane = (wn * 2) * G::A_BLKB + (gq * G::PITCH + tq) * 32 + tp * 8;
 
-  auto mma_item = [&](int buf, auto&& between_sweeps) {
+  auto mma_item = [&](int buf, auto late_c, auto&& between_sweeps) __attribute__((always_inline)) {
+    constexpr int stage_after = decltype(late_c)::value;      // the staging block follows this sweep
     const char* dzt = lds + buf * G::BUFB;
     const char* at = dzt + 2 * G::DZ_PLANEB;
     auto load_b = [&](PV8* bf, int plane, int tap) {
@@ -782,7 +793,7 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
 #pragma unroll
     for (int sw = 0; sw < 3; ++sw) {
       // (prefetching sweep 2's first tap under sweep 1's last one spills at 128 x 128 x 5 taps: 3.28 -> 4.11 ms)
-      if (sw != 2) load_a(af, SA[sw]);                 // sweeps 1 and 2 share dz plane 0
+      if (sw != 2 || stage_after == 1) load_a(af, SA[sw]);      // sweeps 1 and 2 share dz plane 0 (re-read after a staging block)
       load_b(bf[0], SB[sw], 0);
 #pragma unroll
       for (int tap = 0; tap < G::NTAP; ++tap) {
@@ -795,15 +806,25 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
             acc[m][n][tap] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf[cb][n], acc[m][n][tap], 0, 0, 0);
         if (tap + 1 < G::NTAP) {
           constexpr int NMF = MT * 2, PER = NMF / 4 > 0 ? NMF / 4 : 1;
+#if defined(TSR_WG_SPREAD_READS)      // the former schedule: one read after every PER MFMAs (5x5 128x128 7.15 vs 7.05 ms)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
           }
+#else
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // the next tap's reads first: a whole tap of cover
+          __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+          (void)PER;
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (sw == 0) {       // the staging block: no fragment is live across it
+      // the staging block: no fragment is live across it.  8-wave tiles: waves w and w + 4 share a SIMD and, synchronised
+      // by the per-item barrier, would run their conversion blocks (VALU) at the same time and their sweeps (MFMA) at the
+      // same time -- the two pipes would take turns idling.  The upper four waves therefore stage one sweep LATER: while
+      // one wave of a SIMD converts, the other one multiplies.
+      if (sw == stage_after) {
         between_sweeps();
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -816,15 +837,51 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
     store_item(0);
   }
   __syncthreads();
-  int cur = 0;
-  for (int item = it0; item < it1; ++item) {
-    const bool more = item + 1 < it1;
-    if (more) load_item();
-    mma_item(cur, [&]() {
-      if (more) store_item(cur ^ 1);
-    });
-    __syncthreads();
-    cur ^= 1;
+  auto sweep_items = [&](auto late_c) __attribute__((always_inline)) {
+    int cur = 0;
+    for (int item = it0; item < it1; ++item) {
+      const bool more = item + 1 < it1;
+#if defined(TSR_ABL_WG_NOSTAGE)          // timing ablations (wrong results): no staging at all / no global loads / no barrier
+      mma_item(cur, late_c, [&]() {});
+      __syncthreads();
+#elif defined(TSR_ABL_WG_NOLOAD)      // no global loads; the stale registers are made opaque so that the conversions stay in the loop
+#pragma unroll
+      for (int j = 0; j < G::NIT_DZ; ++j) asm volatile("" : "+v"(hd[j]));
+#pragma unroll
+      for (int j = 0; j < G::NIT_A; ++j) asm volatile("" : "+v"(ha[j]));
+      mma_item(cur, late_c, [&]() {
+        if (more) store_item(cur ^ 1);
+      });
+      __syncthreads();
+#elif defined(TSR_ABL_WG_NOBAR)
+      if (more) load_item();
+      mma_item(cur, late_c, [&]() {
+        if (more) store_item(cur ^ 1);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+#else
+      if (more) load_item();
+      mma_item(cur, late_c, [&]() {
+        if (more) store_item(cur ^ 1);
+      });
+      __syncthreads();
+#endif
+      cur ^= 1;
+    }
+  };
+  // Two copies of the item loop (each with its own register allocation), chosen per wave: see the staging block above.
+#ifndef TSR_WG_STAGE_EARLY
+#define TSR_WG_STAGE_EARLY 0
+#endif
+#ifndef TSR_WG_STAGE_LATE
+#define TSR_WG_STAGE_LATE TSR_WG_STAGE_EARLY
+#endif
+  if constexpr (TSR_WG_STAGE_EARLY != TSR_WG_STAGE_LATE) {
+    const bool late_wave = G::NWAVE == 8 && __builtin_amdgcn_readfirstlane(wave) >= 4;
+    if (late_wave) sweep_items(std::integral_constant<int, TSR_WG_STAGE_LATE>());
+    else sweep_items(std::integral_constant<int, TSR_WG_STAGE_EARLY>());
+  } else {
+    sweep_items(std::integral_constant<int, TSR_WG_STAGE_EARLY>());
   }
 
   {   // this split's partial dW: slab[sp][co][ci][kh][kw]
@@ -850,22 +907,15 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
   }
 
   if (do_bias) {
-    float* bred = (float*)lds;                 // [32 px][CO]
+    float* bred = (float*)lds;                 // [pixel slot = 4 pgd + spl][CO]
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < G::NIT_DZ; ++j) {
-      const int i = tid + j * NT;
-      if ((j + 1) * NT <= G::N_DZ || i < G::N_DZ) {
-        const int q = i & 3, px = (i >> 2) & 31, blk = i >> 7;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) bred[px * CO + blk * 16 + q * 4 + c] = bsum[j][c];
-      }
-    }
+    for (int c = 0; c < 4; ++c) bred[(pgd * 4 + spl) * CO + blkd * 16 + sq * 4 + c] = bsum[c];
     __syncthreads();
     for (int c = threadIdx.x; c < CO; c += NT) {
       float s = 0.f;
 #pragma unroll
-      for (int px = 0; px < 32; ++px) s += bred[px * CO + c];
+      for (int px = 0; px < G::BRED_SLOTS; ++px) s += bred[px * CO + c];
       g.bslab[(size_t)sp * g.cout + cob * CO + c] = s;
     }
   }
