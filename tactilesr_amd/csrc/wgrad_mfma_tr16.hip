@@ -459,7 +459,11 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
   if (it0 < it1 && stager) {
     load_item();
     store_item(0);
+#ifdef TSR_WG_LOAD_AT_ITEM_START
     if (SPEC && it0 + 1 < it1) load_item();          // specialised stagers run one item ahead with the loads in flight
+#else
+    if (it0 + 1 < it1) load_item();                  // item + 1 in flight from here on (both forms)
+#endif
   }
   __syncthreads();
   int cur = 0;
@@ -467,8 +471,8 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
     zero_acc();
     for (int item = it0; item < it1; ++item) {
       const bool more = item + 1 < it1;
-#ifndef TSR_ABL_WG_NOLOAD
-      if (more) load_item();               // global loads fly under K step 0 (issuing them a whole item ahead: no gain)
+#if !defined(TSR_ABL_WG_NOLOAD) && defined(TSR_WG_LOAD_AT_ITEM_START)
+      if (more) load_item();               // (former order: item + 1 requested at the start of item)
 #endif
 #ifndef TSR_ABL_WG_NOMMA
       mma_item(cur, [&]() {
@@ -477,6 +481,9 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
         if (more) store_item(cur ^ 1);     // the other buffer: its last readers passed the previous barrier
 #else
         asm volatile("" :: "v"(hd[0][0]), "v"(ha[0][0]), "v"(ha[G::NIT_A - 1][3]), "v"(hd[G::NIT_DZ - 1][3]));
+#endif
+#if !defined(TSR_ABL_WG_NOLOAD) && !defined(TSR_WG_LOAD_AT_ITEM_START)
+        if (item + 2 < it1) load_item();   // the staging registers are free again: item + 2 flies for a whole item
 #endif
 #ifndef TSR_ABL_WG_NOMMA
       });
@@ -835,6 +842,9 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
   if (it0 < it1) {
     load_item();
     store_item(0);
+#ifndef TSR_WG_LOAD_AT_ITEM_START
+    if (it0 + 1 < it1) load_item();
+#endif
   }
   __syncthreads();
   auto sweep_items = [&](auto late_c) __attribute__((always_inline)) {
@@ -859,10 +869,18 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
         if (more) store_item(cur ^ 1);
       });
       __builtin_amdgcn_sched_barrier(0);
-#else
+#elif defined(TSR_WG_LOAD_AT_ITEM_START)
       if (more) load_item();
       mma_item(cur, late_c, [&]() {
         if (more) store_item(cur ^ 1);
+      });
+      __syncthreads();
+#else
+      // item + 1 is in the staging registers (requested a whole item ago); as soon as they have been converted into the
+      // other LDS buffer they are reloaded with item + 2
+      mma_item(cur, late_c, [&]() {
+        if (more) store_item(cur ^ 1);
+        if (item + 2 < it1) load_item();
       });
       __syncthreads();
 #endif
