@@ -87,9 +87,13 @@ struct WgradTGeom {
   static constexpr int DZ_BLKB = tr16_pad_px(DZ_PX) * 32, A_BLKB = tr16_pad_px(A_PX) * 32;
   static constexpr int DZ_PLANEB = (CO / 16) * DZ_BLKB, A_PLANEB = (CI / 16) * A_BLKB;
   static constexpr int BUFB = NS * (DZ_PLANEB + A_PLANEB);
-  static constexpr int N_DZ = DZ_PX * (CO / 16) * 4, N_A = A_PX * (CI / 16) * 4;     // float4 staging items
-  static constexpr int NIT_DZ = (N_DZ + NT - 1) / NT, NIT_A = (N_A + NT - 1) / NT;
-  static constexpr int LDSB = (2 * BUFB > 32 * CO * 4 ? 2 * BUFB : 32 * CO * 4) + CI * 8;   // + (scale, shift) table
+  // staging map: thread = (channel quad, pixel-in-group, 16-channel block, pixel group) -- one channel quad of one block
+  // per thread for the whole kernel (BN scale / shift in 8 registers, 4 bias partials), groups of 4 consecutive pixels
+  static constexpr int NPG_DZ = NT / 16 / (CO / 16), NPG_A = NT / 16 / (CI / 16);     // pixel groups per pass
+  static constexpr int NIT_DZ = (DZ_PX / 4 + NPG_DZ - 1) / NPG_DZ, NIT_A = (A_PX / 4 + NPG_A - 1) / NPG_A;
+  static constexpr int BRED_SLOTS = 4 * NPG_DZ;
+  static constexpr int LDSB = 2 * BUFB > BRED_SLOTS * CO * 4 ? 2 * BUFB : BRED_SLOTS * CO * 4;
+  static_assert(NT % 16 == 0 && (NT / 16) % (CO / 16) == 0 && (NT / 16) % (CI / 16) == 0 && A_PX % 4 == 0, "staging map");
 };
 
 // SPEC: role-specialised workgroup of 2 x NWAVE waves -- waves [0, NWAVE) only run the MFMA loop (one per SIMD for the
@@ -186,11 +190,7 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
   };
 
   // ---- staging roles: item i -> (quad = i & 3, pixel, block); consecutive threads walk a CB16 line, then the row
-  float bsum[G::NIT_DZ][4];
-#pragma unroll
-  for (int j = 0; j < G::NIT_DZ; ++j)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) bsum[j][q] = 0.f;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
   // work items of this split: a contiguous range of (image, patch row, patch column), walked with counters (no
   // division in the loop; the launcher guarantees B * patches < 2^31)
@@ -206,34 +206,33 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
   // VGPR offset -- and its (row, column) for the bounds tests.  Loads are BRANCH-FREE: an out-of-image slot reads its
   // block's corner pixel instead (always valid) and is zeroed by a select when it is stored (a conditional load makes
   // hipcc branch around every load and drain vmcnt per slot).
-  int offd[G::NIT_DZ], safed[G::NIT_DZ], offa[G::NIT_A], safea[G::NIT_A], rcd[G::NIT_DZ], rca[G::NIT_A], ldsd[G::NIT_DZ], ldsa[G::NIT_A];
+  const int sq = tid & 3, spl = (tid >> 2) & 3;
+  const int blkd = (tid >> 4) % (CO / 16), pgd = (tid >> 4) / (CO / 16);
+  const int blka = (tid >> 4) % (CI / 16), pga = (tid >> 4) / (CI / 16);
+  const int safed = blkd * HW * 16 + sq * 4, safea = blka * HW * 16 + sq * 4;
+  int offd[G::NIT_DZ], offa[G::NIT_A], rcd[G::NIT_DZ], rca[G::NIT_A], ldsd[G::NIT_DZ], ldsa[G::NIT_A];
 #pragma unroll
   for (int j = 0; j < G::NIT_DZ; ++j) {
-    const int i = (tid + j * NT) % G::N_DZ;          // (tail threads of a partial pass mirror an early item; masked)
-    const int q = i & 3, px = (i >> 2) & 31, blk = i >> 7;
-    safed[j] = blk * HW * 16 + q * 4;
-    offd[j] = safed[j] + ((px >> 3) * g.W + (px & 7)) * 16;
+    const int px = 4 * (pgd + j * G::NPG_DZ) + spl;          // may run past the tile in the last pass: never stored
+    offd[j] = safed + ((px >> 3) * g.W + (px & 7)) * 16;
     rcd[j] = ((px >> 3) << 8) | (px & 7);
-    ldsd[j] = blk * G::DZ_BLKB + px * 32 + q * 8;
+    ldsd[j] = blkd * G::DZ_BLKB + px * 32 + sq * 8;
   }
 #pragma unroll
   for (int j = 0; j < G::NIT_A; ++j) {
-    const int i = (tid + j * NT) % G::N_A;
-    const int q = i & 3, pi = i >> 2;
-    const int px = pi % G::A_PX, blk = pi / G::A_PX;
+    const int px = 4 * (pga + j * G::NPG_A) + spl;
     const int r = px / G::ACOLS, cx = px - r * G::ACOLS;
-    safea[j] = blk * HW * 16 + q * 4;
-    offa[j] = safea[j] + ((r + kh0 - P) * g.W + cx - P) * 16;
+    offa[j] = safea + ((r + kh0 - P) * g.W + cx - P) * 16;
     rca[j] = (r << 8) | cx;
-    ldsa[j] = blk * G::A_BLKB + px * 32 + q * 8;
+    ldsa[j] = blka * G::A_BLKB + px * 32 + sq * 8;
   }
-  // the fused input transform's per-channel (scale, shift) of this workgroup's CI channels, kept in LDS
-  float* tsc = (float*)(lds + 2 * G::BUFB);
+  // the fused input transform's (scale, shift) of this thread's channel quad; the fp16 / bf16 split forms carry the
+  // staging scale in it (2 relu(t) = t + |t| is positively homogeneous), the bf16-tensor form keeps relu(bn(z)) itself
+  f32x4 tsc = {0.f, 0.f, 0.f, 0.f}, tsh = {0.f, 0.f, 0.f, 0.f};
   if (g.a_scale) {
-    for (int c = threadIdx.x; c < CI; c += NTT) {
-      tsc[c] = g.a_scale[cib * CI + c];
-      tsc[CI + c] = g.a_shift[cib * CI + c];
-    }
+    const float pre = IO16 ? 1.f : s_ah;
+    tsc = *(const f32x4*)(g.a_scale + cib * CI + blka * 16 + sq * 4) * pre;
+    tsh = *(const f32x4*)(g.a_shift + cib * CI + blka * 16 + sq * 4) * pre;
   }
 
   f32x4 hd[G::NIT_DZ], ha[G::NIT_A];
@@ -254,24 +253,24 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
     okd = oka = 0;
 #pragma unroll
     for (int j = 0; j < G::NIT_DZ; ++j) {
-      const bool ok = (y0 + (rcd[j] >> 8) < g.H) & (x0 + (rcd[j] & 255) < g.W);
+      const bool ok = (y0 + (rcd[j] >> 8) < g.H) & (x0 + (rcd[j] & 255) < g.W) & ((rcd[j] >> 8) < 4);
       if constexpr (IO16) {      // 4 bf16 = 8 B, carried in the low half of the slot
-        const float2 t = *(const float2*)(dzb16 + (ok ? offd[j] : safed[j]));
+        const float2 t = *(const float2*)(dzb16 + (ok ? offd[j] : safed));
         hd[j][0] = t.x; hd[j][1] = t.y;
       } else {
-        hd[j] = *(const f32x4*)(dzb + (ok ? offd[j] : safed[j]));
+        hd[j] = *(const f32x4*)(dzb + (ok ? offd[j] : safed));
       }
       okd |= (unsigned)ok << j;
     }
 #pragma unroll
     for (int j = 0; j < G::NIT_A; ++j) {
       const int gy = y0 + (rca[j] >> 8) + kh0 - P, gx = x0 + (rca[j] & 255) - P;
-      const bool ok = (gy >= 0) & (gy < g.H) & (gx >= 0) & (gx < g.W);
+      const bool ok = (gy >= 0) & (gy < g.H) & (gx >= 0) & (gx < g.W) & ((rca[j] >> 8) < G::AROWS);
       if constexpr (IO16) {
-        const float2 t = *(const float2*)(ab16 + (ok ? offa[j] : safea[j]));
+        const float2 t = *(const float2*)(ab16 + (ok ? offa[j] : safea));
         ha[j][0] = t.x; ha[j][1] = t.y;
       } else {
-        ha[j] = *(const f32x4*)(ab + (ok ? offa[j] : safea[j]));
+        ha[j] = *(const f32x4*)(ab + (ok ? offa[j] : safea));
       }
       oka |= (unsigned)ok << j;
     }
@@ -300,60 +299,59 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
       typedef __bf16 io_bf16x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
       for (int j = 0; j < G::NIT_DZ; ++j) {
-        if ((j + 1) * NT <= G::N_DZ || tid + j * NT < G::N_DZ) {
+        if (4 * (j + 1) * G::NPG_DZ <= G::DZ_PX || 4 * (pgd + j * G::NPG_DZ) < G::DZ_PX) {
           const bool ok = (okd >> j) & 1;
           const float2 raw = ok ? make_float2(hd[j][0], hd[j][1]) : make_float2(0.f, 0.f);
           if (do_bias) {
             const io_bf16x4 q = __builtin_bit_cast(io_bf16x4, raw);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) bsum[j][c] += (float)q[c];
+            for (int c = 0; c < 4; ++c) bsum[c] += (float)q[c];
           }
           *(float2*)(dzt + ldsd[j]) = raw;
         }
       }
 #pragma unroll
       for (int j = 0; j < G::NIT_A; ++j) {
-        if ((j + 1) * NT <= G::N_A || tid + j * NT < G::N_A) {
+        if (4 * (j + 1) * G::NPG_A <= G::A_PX || 4 * (pga + j * G::NPG_A) < G::A_PX) {
           const bool ok = (oka >> j) & 1;
-          float2 raw = ok ? make_float2(ha[j][0], ha[j][1]) : make_float2(0.f, 0.f);
-          if (g.a_scale && ok) {      // relu(bn(z)) of the stored bf16 pre-activation, fp32 arithmetic, back to bf16
+          float2 raw = make_float2(ha[j][0], ha[j][1]);
+          if (g.a_scale) {      // relu(bn(z)) of the stored bf16 pre-activation, fp32 arithmetic, back to bf16 (branch-free)
             const io_bf16x4 zq = __builtin_bit_cast(io_bf16x4, raw);
-            const int cq = ((ldsa[j] / G::A_BLKB) * 16) + ((ldsa[j] >> 1) & 12);
-            const f32x4 sc = *(const f32x4*)(tsc + cq), sh = *(const f32x4*)(tsc + CI + cq);
             io_bf16x4 aq;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) aq[c] = (__bf16)tsr_relu(fmaf((float)zq[c], sc[c], sh[c]));
+            for (int c = 0; c < 4; ++c) aq[c] = (__bf16)tsr_relu(fmaf((float)zq[c], tsc[c], tsh[c]));
             raw = __builtin_bit_cast(float2, aq);
           }
-          *(float2*)(at + ldsa[j]) = raw;
+          *(float2*)(at + ldsa[j]) = ok ? raw : make_float2(0.f, 0.f);
         }
       }
       return;
     }
 #pragma unroll
     for (int j = 0; j < G::NIT_DZ; ++j) {
-      if ((j + 1) * NT <= G::N_DZ || tid + j * NT < G::N_DZ) {
+      if (4 * (j + 1) * G::NPG_DZ <= G::DZ_PX || 4 * (pgd + j * G::NPG_DZ) < G::DZ_PX) {
         const f32x4 v = hd[j];
         const bool ok = (okd >> j) & 1;
         if (do_bias) {
           const float keep = ok ? 1.f : 0.f;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) bsum[j][c] = fmaf(v[c], keep, bsum[j][c]);
+          for (int c = 0; c < 4; ++c) bsum[c] = fmaf(v[c], keep, bsum[c]);
         }
         split_store(v, dzt + ldsd[j], G::DZ_PLANEB, ok ? s_d : 0.f);
       }
     }
 #pragma unroll
     for (int j = 0; j < G::NIT_A; ++j) {
-      if ((j + 1) * NT <= G::N_A || tid + j * NT < G::N_A) {
+      if (4 * (j + 1) * G::NPG_A <= G::A_PX || 4 * (pga + j * G::NPG_A) < G::A_PX) {
         f32x4 v = ha[j];
+        const bool ok = (oka >> j) & 1;
         if (g.a_scale) {      // producer's train-mode BN + ReLU, fused into the load (in-image pixels only)
-          const int cq = ((ldsa[j] / G::A_BLKB) * 16) + ((ldsa[j] >> 1) & 12);
-          const f32x4 sc = *(const f32x4*)(tsc + cq), sh = *(const f32x4*)(tsc + CI + cq);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = tsr_relu_x2(fmaf(v[c], sc[c], sh[c]));      // 2 relu(.): s_ah = s_a / 2
+          for (int c = 0; c < 4; ++c) v[c] = tsr_relu_x2(fmaf(v[c], tsc[c], tsh[c]));      // 2 relu(.) s_ah
+          split_store(v, at + ldsa[j], G::A_PLANEB, ok ? 1.f : 0.f);
+        } else {
+          split_store(v, at + ldsa[j], G::A_PLANEB, ok ? s_ah : 0.f);
         }
-        split_store(v, at + ldsa[j], G::A_PLANEB, ((oka >> j) & 1) ? s_ah : 0.f);
       }
     }
   };
@@ -435,7 +433,7 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
     }
   };
 
-  __syncthreads();                         // tsc published (and the scale-bound scratch is free)
+  __syncthreads();                         // (the scale-bound scratch is free)
   // ---- this split's partial dW: slab[sp][co][ci][kh][kw]
   auto write_slab = [&]() {
     constexpr int T = KS * KS;
@@ -512,21 +510,16 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
   }
 
   if (do_bias) {       // thread slot j holds the sums of 4 channels of (pixel, block): reduce the 32 pixels
-    float* bred = (float*)lds;                 // [32 px][CO]
+    float* bred = (float*)lds;                 // [pixel slot = 4 pgd + spl][CO]
+    if (stager) {
 #pragma unroll
-    for (int j = 0; j < G::NIT_DZ; ++j) {
-      const int i = tid + j * NT;
-      if (stager && ((j + 1) * NT <= G::N_DZ || i < G::N_DZ)) {
-        const int q = i & 3, px = (i >> 2) & 31, blk = i >> 7;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) bred[px * CO + blk * 16 + q * 4 + c] = bsum[j][c];
-      }
+      for (int c = 0; c < 4; ++c) bred[(pgd * 4 + spl) * CO + blkd * 16 + sq * 4 + c] = bsum[c];
     }
     __syncthreads();
     for (int c = threadIdx.x; c < CO; c += NTT) {
       float s = 0.f;
 #pragma unroll
-      for (int px = 0; px < 32; ++px) s += bred[px * CO + c];
+      for (int px = 0; px < G::BRED_SLOTS; ++px) s += bred[px * CO + c];
       g.bslab[(size_t)sp * g.cout + cob * CO + c] = s;
     }
   }
