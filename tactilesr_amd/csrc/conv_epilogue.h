@@ -177,6 +177,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
       const f32x4 bb4 = a.bn_a ? *(const f32x4*)(a.bn_b + nq) : zero4;
       f32x4 s1 = zero4, s2 = zero4;
       const int gx = x0 + j + 4 * h;
+      // the stored activation and the partial gradient of the eight tile rows are requested together, branch-free (a slot
+      // outside the image reads the image's first pixel and is dropped): the loads used to sit inside the bounds branch,
+      // each waited for on its own
+      f32x4 mvv[8], rvv[8];
+      bool okk[8];
+      unsigned pov[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int gy = y0 + t;                   // t = 4 mb + g
+        okk[t] = img_ok && gy < a.H && gx < a.W;
+        pov[t] = okk[t] ? (unsigned)(gy * a.W + gx) * 16u : 0u;
+        mvv[t] = tsr_ld4<IO16>(a.mask, midx4 + pov[t]);
+        rvv[t] = a.res ? tsr_ld4<IO16>(a.res, ridx4 + pov[t]) : zero4;
+      }
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -184,24 +198,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
           float t0 = acc[mb][nb][4 * g + 0], t1 = acc[mb][nb][4 * g + 1], t2 = acc[mb][nb][4 * g + 2],
                 t3 = acc[mb][nb][4 * g + 3];
           quad_transpose(t0, t1, t2, t3, j);
-          const int gy = y0 + 4 * mb + g;
-          if (img_ok && gy < a.H && gx < a.W) {
-            const size_t po = (size_t)(gy * a.W + gx) * 16;
-            f32x4 v = {t0, t1, t2, t3};
-            const f32x4 mv = tsr_ld4<IO16>(a.mask, midx4 + po);
-            f32x4 rv = zero4;
-            if (a.res) rv = tsr_ld4<IO16>(a.res, ridx4 + po);
+          const int t = 4 * mb + g;
+          f32x4 v = {t0, t1, t2, t3};
+          const f32x4 mv = okk[t] ? mvv[t] : zero4, rv = rvv[t];      // (a dropped slot must not feed NaN into the sums)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              float x = (v[c] * accmul) * sc4[c] + rv[c];
-              if (!(fmaf(mv[c], msc4[c], msh4[c]) > 0.f)) x = 0.f;
-              v[c] = x;
-              amax = fmaxf(amax, fabsf(x));
-              s1[c] += x;
-              s2[c] = fmaf(x, fmaf(mv[c], ba4[c], bb4[c]), s2[c]);
-            }
-            tsr_st4<IO16>(a.out, oidx4 + po, v);
+          for (int c = 0; c < 4; ++c) {
+            float x = (v[c] * accmul) * sc4[c] + rv[c];
+            if (!(fmaf(mv[c], msc4[c], msh4[c]) > 0.f)) x = 0.f;
+            if (!okk[t]) x = 0.f;
+            v[c] = x;
+            amax = fmaxf(amax, fabsf(x));
+            s1[c] += x;
+            s2[c] = fmaf(x, fmaf(mv[c], ba4[c], bb4[c]), s2[c]);
           }
+          if (okk[t]) tsr_st4<IO16>(a.out, oidx4 + pov[t], v);
         }
       if (a.bn_a) {
 #pragma unroll

@@ -153,28 +153,37 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[
       const f32x4 ba4 = a.bn_a ? *(const f32x4*)(a.bn_a + nq) : zero4;
       const f32x4 bb4 = a.bn_a ? *(const f32x4*)(a.bn_b + nq) : zero4;
       f32x4 s1 = zero4, s2 = zero4;
+      // the stored activation and the partial gradient of the four tiles are requested together, branch-free (a slot
+      // outside the image reads the image's first pixel and is dropped): one memory latency per channel block instead of
+      // one per tile -- the loads used to sit inside the bounds branch, each waited for on its own
+      f32x4 mvv[4], rvv[4];
+      bool okk[4];
+      unsigned pov[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int gy = y0 + 2 * mt + dyl;
+        okk[mt] = img_ok && gy < a.H && gx < a.W;
+        pov[mt] = okk[mt] ? (unsigned)(gy * a.W + gx) * 16u : 0u;
+        mvv[mt] = *(const f32x4*)(mb4 + pov[mt]);
+        rvv[mt] = rb4 ? *(const f32x4*)(rb4 + pov[mt]) : zero4;
+      }
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         float t0 = acc[mt][nt][0], t1 = acc[mt][nt][1], t2 = acc[mt][nt][2], t3 = acc[mt][nt][3];
         quad_transpose(t0, t1, t2, t3, j);
-        const int gy = y0 + 2 * mt + dyl;
-        if (img_ok && gy < a.H && gx < a.W) {
-          const size_t po = (size_t)(gy * a.W + gx) * 16;
-          f32x4 v = {t0, t1, t2, t3};
-          const f32x4 mv = *(const f32x4*)(mb4 + po);
-          f32x4 rv = zero4;
-          if (rb4) rv = *(const f32x4*)(rb4 + po);
+        f32x4 v = {t0, t1, t2, t3};
+        const f32x4 mv = okk[mt] ? mvv[mt] : zero4, rv = rvv[mt];      // (a dropped slot must not feed NaN into the sums)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            float x = (v[c] * accmul) * sc4[c] + rv[c];
-            if (!(fmaf(mv[c], msc4[c], msh4[c]) > 0.f)) x = 0.f;
-            v[c] = x;
-            amax = fmaxf(amax, fabsf(x));
-            s1[c] += x;
-            s2[c] = fmaf(x, fmaf(mv[c], ba4[c], bb4[c]), s2[c]);
-          }
-          *(f32x4*)(ob4 + po) = v;
+        for (int c = 0; c < 4; ++c) {
+          float x = (v[c] * accmul) * sc4[c] + rv[c];
+          if (!(fmaf(mv[c], msc4[c], msh4[c]) > 0.f)) x = 0.f;
+          if (!okk[mt]) x = 0.f;
+          v[c] = x;
+          amax = fmaxf(amax, fabsf(x));
+          s1[c] += x;
+          s2[c] = fmaf(x, fmaf(mv[c], ba4[c], bb4[c]), s2[c]);
         }
+        if (okk[mt]) *(f32x4*)(ob4 + pov[mt]) = v;
       }
       if (a.bn_a) {
         // the 16 lanes (4 of the quad x 4 pixel groups) that hold the same 4 channels
