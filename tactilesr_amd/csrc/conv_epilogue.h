@@ -62,6 +62,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
         rb4 = a.res;
       }
       const int gx = x0 + j + 4 * h;
+      // residual rows of this channel block: requested together, branch-free (dropped slots read the image's first pixel)
+      f32x4 rvv[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int gy = y0 + t;
+        const unsigned pr = (img_ok && gy < a.H && gx < a.W) ? (unsigned)(gy * a.W + gx) * 16u : 0u;
+        rvv[t] = rb4 ? tsr_ld4<IO16>(a.res, ridx4 + pr) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
@@ -76,7 +84,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = (v[c] * accmul) * sc4[c] + sh4[c];
             if (rb4) {
-              f32x4 rv = tsr_ld4<IO16>(a.res, ridx4 + po);
+              f32x4 rv = rvv[4 * mb + g];
               if (EXT && a.res_scale) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) rv[c] = tsr_relu(fmaf(rv[c], rsc4[c], rsh4[c]));

@@ -47,6 +47,23 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[
       if (a.scale) sc4 = *(const f32x4*)(a.scale + nq);
       if (a.shift) sh4 = *(const f32x4*)(a.shift + nq);
       if (EXT && a.res_scale) { rsc4 = *(const f32x4*)(a.res_scale + nq); rsh4 = *(const f32x4*)(a.res_shift + nq); }
+      // residual tile of this channel block: requested together, branch-free (dropped slots read the image's first pixel)
+      f32x4 rvv[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int gy = y0 + 2 * mt + dyl;
+        const unsigned pr = (img_ok && gy < a.H && gx < a.W) ? (unsigned)(gy * a.W + gx) * 16u : 0u;
+        rvv[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (rb4) {
+          if (IO16) {
+            const ep_bf16x4 r16 = *(const ep_bf16x4*)((const __bf16*)a.res + ridx4 + pr);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) rvv[mt][c] = (float)r16[c];
+          } else {
+            rvv[mt] = *(const f32x4*)(rb4 + pr);
+          }
+        }
+      }
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         float t0 = acc[mt][nt][0], t1 = acc[mt][nt][1], t2 = acc[mt][nt][2], t3 = acc[mt][nt][3];
@@ -58,14 +75,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] = (v[c] * accmul) * sc4[c] + sh4[c];
           if (rb4) {
-            f32x4 rv;
-            if (IO16) {
-              const ep_bf16x4 r16 = *(const ep_bf16x4*)((const __bf16*)a.res + ridx4 + po);
-#pragma unroll
-              for (int c = 0; c < 4; ++c) rv[c] = (float)r16[c];
-            } else {
-              rv = *(const f32x4*)(rb4 + po);
-            }
+            f32x4 rv = rvv[mt];
             if (EXT && a.res_scale) {
 #pragma unroll
               for (int c = 0; c < 4; ++c) rv[c] = tsr_relu(fmaf(rv[c], rsc4[c], rsh4[c]));

@@ -198,6 +198,30 @@ __device__ __forceinline__ void conv_fuse1x1_b16_epilogue(const ConvArgs& a, f32
       for (int r = 0; r < 16; ++r) acc2[mb][n2][r] = 0.f;
   const char* ea = ew + (li >> 3) * E::ROWB + (li & 7) * E::PIXB + h * 16;
   const __bf16* wb = (const __bf16*)a.w2 + ((size_t)h * 64 + li) * 8;          // [chunk][2][64][8]
+  // the residual tile of the output stage, requested up front and branch-free (inside the output stage's bounds branch
+  // each of the 16 loads was waited for on its own)
+  const int out_blocks = a.out_ctot >> 4, res_blocks = a.res_ctot >> 4;
+  const int bsafe = img_ok ? b : 0;
+  const int gx = x0 + j + 4 * h;
+  bool okk[8];
+  unsigned pov[8];
+  fz_bf16x4 rvv[2][8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int gy = y0 + t;                     // t = 4 mb + g
+    okk[t] = img_ok && gy < a.H && gx < a.W;
+    pov[t] = okk[t] ? (unsigned)(gy * a.W + gx) * 16u : 0u;
+  }
+#pragma unroll
+  for (int n2 = 0; n2 < 2; ++n2) {
+    const int rq = a.res_coff + n2 * 32 + 4 * k4;
+    const __bf16* rb4 = a.res ? (const __bf16*)a.res + (((size_t)bsafe * res_blocks + (rq >> 4)) * HW) * 16 + (rq & 15) : nullptr;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (rb4) rvv[n2][t] = *(const fz_bf16x4*)(rb4 + pov[t]);
+      else rvv[n2][t] = (fz_bf16x4){(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    }
+  }
 #pragma unroll
   for (int hb = 0; hb < 2; ++hb) {
     if (hb) __syncthreads();          // every wave is done reading the first 64 channels
@@ -246,9 +270,6 @@ __device__ __forceinline__ void conv_fuse1x1_b16_epilogue(const ConvArgs& a, f32
     }
   }
   // + bias + residual (bf16), ReLU, bf16 store
-  const int out_blocks = a.out_ctot >> 4, res_blocks = a.res_ctot >> 4;
-  const int bsafe = img_ok ? b : 0;
-  const int gx = x0 + j + 4 * h;
 #pragma unroll
   for (int n2 = 0; n2 < 2; ++n2) {
     const int nq2 = n2 * 32 + 4 * k4;
@@ -256,11 +277,6 @@ __device__ __forceinline__ void conv_fuse1x1_b16_epilogue(const ConvArgs& a, f32
     f32x4 sh4 = {0.f, 0.f, 0.f, 0.f};
     if (a.shift2) sh4 = *(const f32x4*)(a.shift2 + nq2);
     __bf16* ob4 = (__bf16*)a.out + (((size_t)bsafe * out_blocks + (oq >> 4)) * HW) * 16 + (oq & 15);
-    const __bf16* rb4 = nullptr;
-    if (a.res) {
-      const int rq = a.res_coff + nq2;
-      rb4 = (const __bf16*)a.res + (((size_t)bsafe * res_blocks + (rq >> 4)) * HW) * 16 + (rq & 15);
-    }
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -268,19 +284,16 @@ __device__ __forceinline__ void conv_fuse1x1_b16_epilogue(const ConvArgs& a, f32
         float t0 = acc2[mb][n2][4 * g + 0], t1 = acc2[mb][n2][4 * g + 1], t2 = acc2[mb][n2][4 * g + 2],
               t3 = acc2[mb][n2][4 * g + 3];
         quad_transpose(t0, t1, t2, t3, j);
-        const int gy = y0 + 4 * mb + g;
-        if (img_ok && gy < a.H && gx < a.W) {
-          const size_t po = (size_t)(gy * a.W + gx) * 16;
+        const int t = 4 * mb + g;
+        if (okk[t]) {
           f32x4 v = {t0 + sh4[0], t1 + sh4[1], t2 + sh4[2], t3 + sh4[3]};
-          if (rb4) {
-            const fz_bf16x4 rv = *(const fz_bf16x4*)(rb4 + po);
+          const fz_bf16x4 rv = rvv[n2][t];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] += (float)rv[c];
-          }
+          for (int c = 0; c < 4; ++c) v[c] += (float)rv[c];
           fz_bf16x4 o;
 #pragma unroll
           for (int c = 0; c < 4; ++c) o[c] = (__bf16)(a.relu2 ? tsr_relu(v[c]) : v[c]);
-          *(fz_bf16x4*)(ob4 + po) = o;
+          *(fz_bf16x4*)(ob4 + pov[t]) = o;
         }
       }
   }

@@ -41,6 +41,28 @@ __device__ __forceinline__ void conv_fuse1x1_epilogue16(const ConvArgs& a, f32x4
 #pragma unroll
       for (int n2 = 0; n2 < 2; ++n2)
         fb[kk][p][n2] = *(const fq_f16x8*)(wb + (size_t)((2 * kk) * 2 + p) * (2 * 64 * 8) + n2 * 16 * 8);
+  // the residual tile of step 4 (x, or the other conv's partial sum): requested here as well, branch-free (a slot outside
+  // the image reads the image's first pixel and is dropped) -- inside step 4's bounds branch every one of the eight loads
+  // was waited for on its own at the very end of the workgroup
+  const int out_blocks = a.out_ctot >> 4, res_blocks = a.res_ctot >> 4;
+  const int bsafe = img_ok ? b : 0;
+  const int gx = x0 + dxl + j;
+  bool okk[4];
+  unsigned pov[4];
+  f32x4 rvv[2][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int gy = y0 + 2 * mt + dyl;
+    okk[mt] = img_ok && gy < a.H && gx < a.W;
+    pov[mt] = okk[mt] ? (unsigned)(gy * a.W + gx) * 16u : 0u;
+  }
+#pragma unroll
+  for (int n2 = 0; n2 < 2; ++n2) {
+    const int rq = a.res_coff + wn * 32 + n2 * 16 + 4 * k4;
+    const float* rb4 = a.res ? a.res + (((size_t)bsafe * res_blocks + (rq >> 4)) * HW) * 16 + (rq & 15) : nullptr;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) rvv[n2][mt] = rb4 ? *(const f32x4*)(rb4 + pov[mt]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   // ---- 1. BatchNorm fold + ReLU in place (lane = channel), zero outside the image, tile maximum
   float amax = 0.f;
 #pragma unroll
@@ -132,10 +154,7 @@ __device__ __forceinline__ void conv_fuse1x1_epilogue16(const ConvArgs& a, f32x4
   }
   // ---- 4. + bias + residual, ReLU, max|out|, 16-B stores
   const float mul2 = a.w2_inv_scale / s_e;
-  const int out_blocks = a.out_ctot >> 4, res_blocks = a.res_ctot >> 4;
-  const int bsafe = img_ok ? b : 0;
   float omax = 0.f;
-  const int gx = x0 + dxl + j;
 #pragma unroll
   for (int n2 = 0; n2 < 2; ++n2) {
     const int nq2 = wn * 32 + n2 * 16 + 4 * k4;
@@ -143,32 +162,20 @@ __device__ __forceinline__ void conv_fuse1x1_epilogue16(const ConvArgs& a, f32x4
     f32x4 sh4 = {0.f, 0.f, 0.f, 0.f};
     if (a.shift2) sh4 = *(const f32x4*)(a.shift2 + nq2);
     float* ob4 = a.out + (((size_t)bsafe * out_blocks + (oq >> 4)) * HW) * 16 + (oq & 15);
-    const float* rb4 = nullptr;
-    if (a.res) {
-      const int rq = a.res_coff + nq2;
-      rb4 = a.res + (((size_t)bsafe * res_blocks + (rq >> 4)) * HW) * 16 + (rq & 15);
-    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       float t0 = acc2[mt][n2][0], t1 = acc2[mt][n2][1], t2 = acc2[mt][n2][2], t3 = acc2[mt][n2][3];
       quad_transpose(t0, t1, t2, t3, j);
-      const int gy = y0 + 2 * mt + dyl;
-      if (img_ok && gy < a.H && gx < a.W) {
-        const size_t po = (size_t)(gy * a.W + gx) * 16;
+      if (okk[mt]) {
         f32x4 v = {t0, t1, t2, t3};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = v[c] * mul2 + sh4[c];
-        if (rb4) {
-          const f32x4 rv = *(const f32x4*)(rb4 + po);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] += rv[c];
-        }
+        const f32x4 rv = rvv[n2][mt];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+          v[c] = v[c] * mul2 + sh4[c] + rv[c];
           if (a.relu2) v[c] = tsr_relu(v[c]);
           omax = fmaxf(omax, fabsf(v[c]));
         }
-        *(f32x4*)(ob4 + po) = v;
+        *(f32x4*)(ob4 + pov[mt]) = v;
       }
     }
   }
