@@ -113,49 +113,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
   const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
   const int m = lane & 15, g = lane >> 4, khalf = g & 1, tsel = g >> 1;
 
-  // power-of-two operand scales (see conv_mfma_split16.hip)
-  float sx = 1.f, accmul = 1.f;
-  {
-    float mx = a.in_amax ? *a.in_amax : 0.f;
-    if (EXT && a.in_scale) {
-      __shared__ float bnd[2 * NW];
-      float ms = 0.f, mt = 0.f;
-      for (int c = threadIdx.x; c < a.cin; c += NTHR) {
-        ms = fmaxf(ms, fabsf(a.in_scale[c]));
-        mt = fmaxf(mt, fabsf(a.in_shift[c]));
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        ms = fmaxf(ms, __shfl_xor(ms, o));
-        mt = fmaxf(mt, __shfl_xor(mt, o));
-      }
-      if (lane == 0) { bnd[wave * 2] = ms; bnd[wave * 2 + 1] = mt; }
-      __syncthreads();
-      ms = 0.f; mt = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) { ms = fmaxf(ms, bnd[2 * w]); mt = fmaxf(mt, bnd[2 * w + 1]); }
-      mx = mx * ms + mt;
-    }
-    if (mx > 0.f) {
-      int e = (int)((__float_as_uint(mx) >> 23) & 0xFF) - 127;
-      int be = 13 - e + 127;
-      be = be < 1 ? 1 : (be > 254 ? 254 : be);
-      sx = __uint_as_float((unsigned)be << 23);
-    }
-    float w_inv = a.w_inv_scale;
-    if (a.w_amax) {
-      const float wmx = *a.w_amax;
-      w_inv = 1.f;
-      if (wmx > 0.f && wmx < 3.0e38f) {
-        int be = 127 - (13 - ((int)((__float_as_uint(wmx) >> 23) & 0xFF) - 127));
-        be = be < 1 ? 1 : (be > 254 ? 254 : be);
-        w_inv = __uint_as_float((unsigned)be << 23);
-      }
-    }
-    accmul = w_inv / sx;
-  }
-  const float sxh = (EXT && a.in_scale) ? 0.5f * sx : sx;     // staging scale (virtual inputs arrive as 2 relu(.))
-
+  float sx = 1.f, accmul = 1.f, sxh = 1.f;      // power-of-two operand scales: set in the prologue (operand_scales)
   int bid;
   {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
@@ -361,17 +319,64 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
   }
 
   // ---- prologue: halo(0), W(0), W(1) in LDS; W(2) in flight
+  // power-of-two operand scales (see conv_mfma_split16.hip).  Called AFTER the first slab's global loads have been
+  // issued: its own dependent loads (amax scalars, the BN vectors' bound) and barrier run under their latency -- with one
+  // 512-thread workgroup per CU nothing else hides a serial prologue.
+  auto operand_scales = [&]() __attribute__((always_inline)) {
+    float mx = a.in_amax ? *a.in_amax : 0.f;
+    if (EXT && a.in_scale) {
+      __shared__ float bnd[2 * NW];
+      float ms = 0.f, mt = 0.f;
+      for (int c = threadIdx.x; c < a.cin; c += NTHR) {
+        ms = fmaxf(ms, fabsf(a.in_scale[c]));
+        mt = fmaxf(mt, fabsf(a.in_shift[c]));
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        ms = fmaxf(ms, __shfl_xor(ms, o));
+        mt = fmaxf(mt, __shfl_xor(mt, o));
+      }
+      if (lane == 0) { bnd[wave * 2] = ms; bnd[wave * 2 + 1] = mt; }
+      __syncthreads();
+      ms = 0.f; mt = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { ms = fmaxf(ms, bnd[2 * w]); mt = fmaxf(mt, bnd[2 * w + 1]); }
+      mx = mx * ms + mt;
+    }
+    if (mx > 0.f) {
+      int e = (int)((__float_as_uint(mx) >> 23) & 0xFF) - 127;
+      int be = 13 - e + 127;
+      be = be < 1 ? 1 : (be > 254 ? 254 : be);
+      sx = __uint_as_float((unsigned)be << 23);
+    }
+    float w_inv = a.w_inv_scale;
+    if (a.w_amax) {
+      const float wmx = *a.w_amax;
+      w_inv = 1.f;
+      if (wmx > 0.f && wmx < 3.0e38f) {
+        int be = 127 - (13 - ((int)((__float_as_uint(wmx) >> 23) & 0xFF) - 127));
+        be = be < 1 ? 1 : (be > 254 ? 254 : be);
+        w_inv = __uint_as_float((unsigned)be << 23);
+      }
+    }
+    accmul = w_inv / sx;
+    sxh = (EXT && a.in_scale) ? 0.5f * sx : sx;     // staging scale (virtual inputs arrive as 2 relu(.))
+  };
+
   f32x4 hv[NIT], wreg[WDMA ? 1 : WV];
   size_t woff = 0;                        // pair form: byte offset of the next slab to request
   load_halo(0, hv);
   if constexpr (PAIR) {                   // S >= 25; steps 0, 1 are outer-ring steps
     DMA_WP(0, 0);
     DMA_WP(1, 1);
+    operand_scales();
   } else if constexpr (WDMA) {
     DMA_W(0, 0);
     if (S > 1) DMA_W(1, 1);
+    operand_scales();
   } else {
     LOAD_W(0);
+    operand_scales();
     STORE_W(0);
     if (S > 1) { LOAD_W(1); STORE_W(1); }
   }
