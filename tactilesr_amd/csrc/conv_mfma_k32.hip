@@ -173,9 +173,17 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
   const char* wsrc = (const char*)a.wp;
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 0x7fffffff, 0x00020000);
 
+  // BN scale / shift of this thread's channel quad of the block in flight (every staging item of a thread carries the
+  // same quad): requested WITH the slab, not at the block boundary where the conversion would wait for them
+  f32x4 hsc = {1.f, 1.f, 1.f, 1.f}, hsh = {0.f, 0.f, 0.f, 0.f};
   auto load_halo = [&](int c, f32x4* hv) __attribute__((always_inline)) {
     // (an odd block count is padded to even: the phantom block re-reads the last real one against zero weights)
     const float* inc = in_base + (size_t)(c < nreal ? c : nreal - 1) * HW * 16;
+    if (EXT && a.in_scale) {
+      const int cq = (c < nreal ? c : nreal - 1) * 16 + (tid & 3) * 4;
+      hsc = *(const f32x4*)(a.in_scale + cq);
+      hsh = *(const f32x4*)(a.in_shift + cq);
+    }
     // branch-free: out-of-image items read a valid dummy address (offset 0) and are zeroed by their scale in store_halo
     // (hipcc otherwise wraps every load in its own exec-masked branch with a wait in front)
 #pragma unroll
@@ -187,11 +195,8 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
       if (st_dst[k] >= 0) {
         f32x4 v = hv[k];
         if (EXT && a.in_scale) {   // producer's train-mode BN+ReLU, fused into the load
-          const int cq = (c < nreal ? c : nreal - 1) * 16 + ((tid + k * NTHR) & 3) * 4;
-          const f32x4 sc = *(const f32x4*)(a.in_scale + cq);
-          const f32x4 sh = *(const f32x4*)(a.in_shift + cq);
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) v[jj] = tsr_relu_x2(fmaf(v[jj], sc[jj], sh[jj]));     // 2 relu(bn(z)); sxh = sx / 2
+          for (int jj = 0; jj < 4; ++jj) v[jj] = tsr_relu_x2(fmaf(v[jj], hsc[jj], hsh[jj]));     // 2 relu(bn(z)); sxh = sx / 2
         }
         // zero padding outside the image: a SELECT, not a multiply by 0 -- the dummy element that was loaded for a padded
         // slot may be NaN / Inf (another image's pixel) and must not leak into this image's border

@@ -236,7 +236,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
   const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   // ---- helpers (all loops fully unrolled: fragment registers are plain SSA values)
+  // BN scale / shift of this thread's channel quad of the block in flight (every staging item of a thread carries the
+  // same quad): requested WITH the slab, not at the block boundary where the conversion would wait for them
+  f32x4 hsc = {1.f, 1.f, 1.f, 1.f}, hsh = {0.f, 0.f, 0.f, 0.f};
   auto load_halo = [&](int c, f32x4* hv) {
+    if (EXT && a.in_scale) {
+      hsc = *(const f32x4*)(a.in_scale + c * 16 + (tid & 3) * 4);
+      hsh = *(const f32x4*)(a.in_shift + c * 16 + (tid & 3) * 4);
+    }
     if (IO16) {     // 4 bf16 = 8 B per item, carried in the low half of the f32x4 slot
       const __bf16* inc = in_base16 + (size_t)c * HW * 16;
 #pragma unroll
@@ -268,12 +275,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
             // producer's train-mode BN + ReLU on the stored bf16 pre-activation, fp32 arithmetic, rounded to the bf16
             // MFMA operand (training with bf16 activation storage)
             const bf16x4 zq = __builtin_bit_cast(bf16x4, make_float2(hv[k][0], hv[k][1]));
-            const int cq = c * 16 + ((tid + k * 256) & 3) * 4;
-            const f32x4 sc = *(const f32x4*)(a.in_scale + cq);
-            const f32x4 sh = *(const f32x4*)(a.in_shift + cq);
             bf16x4 aq;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) aq[j] = (__bf16)tsr_relu(fmaf((float)zq[j], sc[j], sh[j]));
+            for (int j = 0; j < 4; ++j) aq[j] = (__bf16)tsr_relu(fmaf((float)zq[j], hsc[j], hsh[j]));
             *(bf16x4*)(halo + hb * HALO_B + st_dst[k]) = aq;
           } else {
             *(float2*)(halo + hb * HALO_B + st_dst[k]) = make_float2(hv[k][0], hv[k][1]);
@@ -286,11 +290,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
       if (st_dst[k] >= 0) {
         f32x4 v = hv[k];
         if (EXT && a.in_scale && st_src[k] >= 0) {   // producer's train-mode BN+ReLU, fused into the load
-          const int cq = c * 16 + ((tid + k * 256) & 3) * 4;
-          const f32x4 sc = *(const f32x4*)(a.in_scale + cq);
-          const f32x4 sh = *(const f32x4*)(a.in_shift + cq);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = tsr_relu(fmaf(v[j], sc[j], sh[j]));
+          for (int j = 0; j < 4; ++j) v[j] = tsr_relu(fmaf(v[j], hsc[j], hsh[j]));
         }
         if (F16) {
 #pragma unroll
