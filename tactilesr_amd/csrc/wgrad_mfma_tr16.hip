@@ -820,10 +820,10 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      // the staging block: no fragment is live across it.  8-wave tiles: waves w and w + 4 share a SIMD and, synchronised
-      // by the per-item barrier, would run their conversion blocks (VALU) at the same time and their sweeps (MFMA) at the
-      // same time -- the two pipes would take turns idling.  The upper four waves therefore stage one sweep LATER: while
-      // one wave of a SIMD converts, the other one multiplies.
+      // the staging block: no fragment is live across it.  (Measured and dropped: staging the upper four waves of an
+      // 8-wave tile one sweep later, so that the two waves of a SIMD convert and multiply at different times -- as a
+      // wave-uniform run-time branch, without spills: 5x5 128x128 6.69 -> 6.87 ms, 3x3 128x64 2.40 -> 2.55.  The
+      // position itself (after sweep 0 / 1 / 2 for all waves) is neutral or worse as well: TSR_WG_STAGE_EARLY.)
       if (sw == stage_after) {
         between_sweeps();
         __builtin_amdgcn_sched_barrier(0);
