@@ -28,6 +28,25 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[
   const int bsafe = img_ok ? b : 0;
   typedef __bf16 ep_bf16x4 __attribute__((ext_vector_type(4)));
   const int gx = x0 + dxl + j;                            // pixel column after the transpose
+  // Per-channel vectors of ALL channel blocks, requested before the first store: behind a store to a.out the compiler may
+  // not hoist them (the pointers could alias), and every block would start with an exposed L2 round trip.
+  const f32x4 one4v = {1.f, 1.f, 1.f, 1.f}, zero4v = {0.f, 0.f, 0.f, 0.f};
+  f32x4 pv0[NT], pv1[NT], pv2[NT], pv3[NT], pv4[NT];
+  const bool m2 = EXT && a.epi_mode == 2, m0 = !EXT || a.epi_mode == 0;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int nq = wn * (COUT / WN) + nt * 16 + 4 * k4;
+    pv0[nt] = one4v; pv1[nt] = zero4v; pv2[nt] = one4v; pv3[nt] = zero4v; pv4[nt] = zero4v;
+    if (m0) {             // scale, shift, residual scale, residual shift
+      if (a.scale) pv0[nt] = *(const f32x4*)(a.scale + nq);
+      if (a.shift) pv1[nt] = *(const f32x4*)(a.shift + nq);
+      if (EXT && a.res_scale) { pv2[nt] = *(const f32x4*)(a.res_scale + nq); pv3[nt] = *(const f32x4*)(a.res_shift + nq); }
+    } else if (m2) {      // scale, mask scale, mask shift, bn_a, bn_b
+      if (a.scale) pv0[nt] = *(const f32x4*)(a.scale + nq);
+      if (a.mask_scale) { pv2[nt] = *(const f32x4*)(a.mask_scale + nq); pv1[nt] = *(const f32x4*)(a.mask_shift + nq); }
+      if (a.bn_a) { pv3[nt] = *(const f32x4*)(a.bn_a + nq); pv4[nt] = *(const f32x4*)(a.bn_b + nq); }
+    }
+  }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = wn * (COUT / WN) + nt * 16 + cl;        // channel before the transpose
@@ -43,10 +62,7 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[
       rb4 = a.res + ridx4;
     }
     if (!EXT || a.epi_mode == 0) {
-      f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f}, rsc4 = sc4, rsh4 = sh4;
-      if (a.scale) sc4 = *(const f32x4*)(a.scale + nq);
-      if (a.shift) sh4 = *(const f32x4*)(a.shift + nq);
-      if (EXT && a.res_scale) { rsc4 = *(const f32x4*)(a.res_scale + nq); rsh4 = *(const f32x4*)(a.res_shift + nq); }
+      const f32x4 sc4 = pv0[nt], sh4 = pv1[nt], rsc4 = pv2[nt], rsh4 = pv3[nt];
       // residual tile of this channel block: requested together, branch-free (dropped slots read the image's first pixel)
       f32x4 rvv[4];
 #pragma unroll
@@ -156,12 +172,8 @@ __device__ __forceinline__ void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[
       // ReLU backward by the stored activation (+ optional BN-backward partial sums), transposed layout
       const int mq = a.mask_coff + nq;
       const float* mb4 = a.mask + (((size_t)bsafe * mask_blocks + (mq >> 4)) * HW) * 16 + (mq & 15);
-      f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
-      const f32x4 sc4 = a.scale ? *(const f32x4*)(a.scale + nq) : one4;
-      const f32x4 msc4 = a.mask_scale ? *(const f32x4*)(a.mask_scale + nq) : one4;
-      const f32x4 msh4 = a.mask_scale ? *(const f32x4*)(a.mask_shift + nq) : zero4;
-      const f32x4 ba4 = a.bn_a ? *(const f32x4*)(a.bn_a + nq) : zero4;
-      const f32x4 bb4 = a.bn_a ? *(const f32x4*)(a.bn_b + nq) : zero4;
+      const f32x4 zero4 = zero4v;
+      const f32x4 sc4 = pv0[nt], msc4 = pv2[nt], msh4 = pv1[nt], ba4 = pv3[nt], bb4 = pv4[nt];
       f32x4 s1 = zero4, s2 = zero4;
       // the stored activation and the partial gradient of the four tiles are requested together, branch-free (a slot
       // outside the image reads the image's first pixel and is dropped): one memory latency per channel block instead of

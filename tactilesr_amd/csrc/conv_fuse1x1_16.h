@@ -63,12 +63,23 @@ __device__ __forceinline__ void conv_fuse1x1_epilogue16(const ConvArgs& a, f32x4
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) rvv[n2][mt] = rb4 ? *(const f32x4*)(rb4 + pov[mt]) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  // (the BN fold's and the output stage's per-channel values as well: one round trip for everything the epilogue reads)
+  float bsc[4], bsh[4];
+  f32x4 osh[2];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int n = wn * 64 + nt * 16 + cl;
+    bsc[nt] = a.scale ? a.scale[n] : 1.f;
+    bsh[nt] = a.shift ? a.shift[n] : 0.f;
+  }
+#pragma unroll
+  for (int n2 = 0; n2 < 2; ++n2)
+    osh[n2] = a.shift2 ? *(const f32x4*)(a.shift2 + wn * 32 + n2 * 16 + 4 * k4) : (f32x4){0.f, 0.f, 0.f, 0.f};
   // ---- 1. BatchNorm fold + ReLU in place (lane = channel), zero outside the image, tile maximum
   float amax = 0.f;
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
-    const int n = wn * 64 + nt * 16 + cl;
-    const float sc = (a.scale ? a.scale[n] : 1.f) * accmul, sh = a.shift ? a.shift[n] : 0.f;
+    const float sc = bsc[nt] * accmul, sh = bsh[nt];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -159,8 +170,7 @@ __device__ __forceinline__ void conv_fuse1x1_epilogue16(const ConvArgs& a, f32x4
   for (int n2 = 0; n2 < 2; ++n2) {
     const int nq2 = wn * 32 + n2 * 16 + 4 * k4;
     const int oq = a.out_coff + nq2;
-    f32x4 sh4 = {0.f, 0.f, 0.f, 0.f};
-    if (a.shift2) sh4 = *(const f32x4*)(a.shift2 + nq2);
+    const f32x4 sh4 = osh[n2];
     float* ob4 = a.out + (((size_t)bsafe * out_blocks + (oq >> 4)) * HW) * 16 + (oq & 15);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
