@@ -152,30 +152,44 @@ extern "C" int tsr_bn_bwd_finalize(const float* slab, int entries, int C, double
 }
 
 // g[:, gcoff:gcoff+C] = c1*g + c2*z[:, zcoff:zcoff+C] + c3   (BN backward, elementwise, CB16, in place)
+// One workgroup per (image, 16-channel block): its HW x 16 values are contiguous; a thread keeps one channel quad (c1..c3 in
+// 12 registers, no index arithmetic per element) and has UNR independent 16-B load pairs in flight.
 template <bool B16>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ g, int g_ctot, int g_coff,
                                                            const float* __restrict__ z, int z_ctot, int z_coff,
                                                            const float* __restrict__ c1, const float* __restrict__ c2,
-                                                           const float* __restrict__ c3, int C, int HW, size_t total4,
+                                                           const float* __restrict__ c3, int C, int HW,
                                                            float* __restrict__ out_amax) {
+  constexpr int UNR = 5;
+  const int nblk = C >> 4;
+  const int b = blockIdx.x / nblk, blk = blockIdx.x - b * nblk;
+  const int c = blk * 16 + (threadIdx.x & 3) * 4;
+  const size_t gbase = (((size_t)b * (g_ctot >> 4) + ((g_coff >> 4) + blk)) * HW) * 16;
+  const size_t zbase = (((size_t)b * (z_ctot >> 4) + ((z_coff >> 4) + blk)) * HW) * 16;
+  const f32x4 k1 = *(const f32x4*)(c1 + c), k2 = *(const f32x4*)(c2 + c), k3 = *(const f32x4*)(c3 + c);
+  const int n4 = HW * 4;
   float amax = 0.f;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-    const int q = i & 3;
-    size_t r = i >> 2;
-    const int pix = r % HW; r /= HW;
-    const int blk = r % (C >> 4);
-    const int b = r / (C >> 4);
-    const int c = blk * 16 + q * 4;
-    const size_t gi = (((size_t)b * (g_ctot >> 4) + ((g_coff + c) >> 4)) * HW + pix) * 16 + q * 4;
-    const f32x4 zv = tsr_ld4<B16>(z, (((size_t)b * (z_ctot >> 4) + ((z_coff + c) >> 4)) * HW + pix) * 16 + q * 4);
-    const f32x4 k1 = *(const f32x4*)(c1 + c), k2 = *(const f32x4*)(c2 + c), k3 = *(const f32x4*)(c3 + c);
-    f32x4 gv = tsr_ld4<B16>(g, gi);
+  for (int i0 = threadIdx.x; i0 < n4; i0 += 256 * UNR) {
+    f32x4 gv[UNR], zv[UNR];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      gv[j] = fmaf(k1[j], gv[j], fmaf(k2[j], zv[j], k3[j]));
-      amax = fmaxf(amax, fabsf(gv[j]));
+    for (int u = 0; u < UNR; ++u) {
+      const int i = i0 + u * 256;
+      const size_t o = (size_t)(i < n4 ? i : i0) * 4;       // (tail: re-read the first item, not stored)
+      gv[u] = tsr_ld4<B16>(g, gbase + o);
+      zv[u] = tsr_ld4<B16>(z, zbase + o);
     }
-    tsr_st4<B16>(g, gi, gv);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int i = i0 + u * 256;
+      if (i < n4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          gv[u][j] = fmaf(k1[j], gv[u][j], fmaf(k2[j], zv[u][j], k3[j]));
+          amax = fmaxf(amax, fabsf(gv[u][j]));
+        }
+        tsr_st4<B16>(g, gbase + (size_t)i * 4, gv[u]);
+      }
+    }
   }
   if (out_amax) {
 #pragma unroll
@@ -190,10 +204,9 @@ extern "C" int tsr_bn_bwd_apply(float* g, int g_ctot, int g_coff, const float* z
   if (!g || !z || !c1 || !c2 || !c3 || (C & 15) || (g_ctot & 15) || (g_coff & 15) || (z_ctot & 15) || (z_coff & 15) ||
       g_coff + C > g_ctot || z_coff + C > z_ctot)
     return TSR_ERR_ARG;
-  const size_t total4 = (size_t)B * C * HW / 4;
-  const size_t grid = (total4 + 255) / 256;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid > 16384 ? 16384 : (int)grid), dim3(256), 0, (hipStream_t)stream,
-                     g, g_ctot, g_coff, z, z_ctot, z_coff, c1, c2, c3, C, HW, total4, out_amax);
+  if (B <= 0 || HW <= 0 || (long long)B * (C >> 4) > 0x7fffffffLL) return TSR_ERR_ARG;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(B * (C >> 4)), dim3(256), 0, (hipStream_t)stream,
+                     g, g_ctot, g_coff, z, z_ctot, z_coff, c1, c2, c3, C, HW, out_amax);
   return tsr_check_launch();
 }
 
@@ -204,10 +217,9 @@ extern "C" int tsr_bn_bwd_apply_b16(void* g, int g_ctot, int g_coff, const void*
   if (!g || !z || !c1 || !c2 || !c3 || (C & 15) || (g_ctot & 15) || (g_coff & 15) || (z_ctot & 15) || (z_coff & 15) ||
       g_coff + C > g_ctot || z_coff + C > z_ctot)
     return TSR_ERR_ARG;
-  const size_t total4 = (size_t)B * C * HW / 4;
-  const size_t grid = (total4 + 255) / 256;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid > 16384 ? 16384 : (int)grid), dim3(256), 0, (hipStream_t)stream,
-                     (float*)g, g_ctot, g_coff, (const float*)z, z_ctot, z_coff, c1, c2, c3, C, HW, total4, (float*)nullptr);
+  if (B <= 0 || HW <= 0 || (long long)B * (C >> 4) > 0x7fffffffLL) return TSR_ERR_ARG;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(B * (C >> 4)), dim3(256), 0, (hipStream_t)stream,
+                     (float*)g, g_ctot, g_coff, (const float*)z, z_ctot, z_coff, c1, c2, c3, C, HW, (float*)nullptr);
   return tsr_check_launch();
 }
 
