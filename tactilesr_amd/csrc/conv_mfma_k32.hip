@@ -200,7 +200,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
         }
         // zero padding outside the image: a SELECT, not a multiply by 0 -- the dummy element that was loaded for a padded
         // slot may be NaN / Inf (another image's pixel) and must not leak into this image's border
-        const bool inside = st_src[k] >= 0;
+        const bool inside = st_src[k] >= 0 && c < nreal;      // (the phantom block of an odd block count is staged as zeros)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) v[jj] = inside ? v[jj] * sxh : 0.f;
 #pragma unroll

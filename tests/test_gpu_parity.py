@@ -461,6 +461,44 @@ def test_conv2d_fwd_fp16_split(T, ks, cin, cout, B, H, W, outlier):
     assert abs(float(amax_out) - float(got.abs().max())) == 0.0
 
 
+@pytest.mark.parametrize("ks,cin,cout", [(5, 64, 128), (3, 64, 64), (5, 48, 128), (3, 16, 64)])
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_conv2d_fp16_split_non_finite_input_stays_in_its_receptive_field(T, ks, cin, cout, bad):
+    """torch's conv propagates a NaN / Inf input element to exactly the outputs whose window covers it.  The split-operand
+    kernels read dummy elements for padding and (odd block counts) a phantom channel block against zero weights: neither
+    may carry the bad value anywhere else -- every other output must be BIT-identical to the clean run (the operand scale
+    comes from the producer's amax scalar, which skips non-finite values: here the clean tensor's)."""
+    import math
+    from tactilesr_amd._lib import call, ptr, stream, load, c_int as I, c_float as Fl
+    B, H, W, P = 3, 16, 24, ks // 2
+    g = torch.Generator().manual_seed(ks + cin + cout)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = (torch.randn(cout, cin, ks, ks, generator=g) * 0.05).cuda().contiguous()
+    wscale = 2.0 ** (13 - math.floor(math.log2(float(w.abs().max()))))
+    wp = torch.empty(load().tsr_conv_weight_bf16s_elems(cout, cin, ks, 2), dtype=torch.float16, device="cuda")
+    call("tsr_pack_conv_weight_f16s", ptr(w), ptr(wp), I(cout), I(cin), I(ks), Fl(wscale), stream())
+    amax_in = x.abs().max().reshape(1).cuda()
+
+    def run(xx):
+        out = torch.empty(B * cout * H * W, device="cuda")
+        call("tsr_conv2d_fwd_f16s", ptr(T.to_cb16(xx.cuda())), I(cin), I(0), I(cin), ptr(wp), I(cout), I(ks), Fl(1.0 / wscale),
+             ptr(amax_in), ptr(None), ptr(None), ptr(None), ptr(None), I(0), I(0), ptr(out), I(cout), I(0), I(0), I(B), I(H),
+             I(W), stream())
+        return T.from_cb16(out, B, cout, H, W).cpu()
+
+    clean = run(x)
+    # pixel (0, 0) of image 1 is also the dummy element its padding slots read; (7, 9) sits inside a tile
+    for (b, c, y, xx_) in [(1, 0, 0, 0), (2, cin - 1, 7, 9)]:
+        xb = x.clone()
+        xb[b, c, y, xx_] = bad
+        got = run(xb)
+        win = torch.zeros(B, 1, H, W, dtype=torch.bool)
+        win[b, 0, max(0, y - P):y + P + 1, max(0, xx_ - P):xx_ + P + 1] = True
+        win = win.expand(B, cout, H, W)
+        assert not torch.isfinite(got[win]).any(), "every output whose window covers the bad element is non-finite"
+        assert torch.equal(got[~win], clean[~win]), "no other output changes"
+
+
 def test_stem_publishes_amax(T):
     from tactilesr_amd._lib import call, ptr, stream, c_int as I
     g = torch.Generator().manual_seed(3)
