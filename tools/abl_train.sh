@@ -1,6 +1,8 @@
 #!/bin/bash
-# Same-box A/B of library variants on the train step: ABL_LIST="cur wg_s1 ..." tools/abl_train.sh [bench args]
-P='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"], {k: v for k, v in d["whole_step"]["ms_per_launch"].items() if k.startswith("wgrad")})'
+# Same-box A/B of library variants (tools/build_variant.py NAME -D...) on the train step:
+#   ABL_LIST="cur NAME cur NAME" tools/abl_train.sh [extra bench args, e.g. --impl bf16]
+# prints ms/step, the loss (a variant that changes results shows here) and the per-launch times by layer shape.
+P='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"], "loss", d.get("loss"), d["whole_step"]["ms_per_launch"])'
 for v in ${ABL_LIST:-cur}; do
   echo "== $v"
   if [ $v = cur ]; then python bench.py --mode train --batch 2048 --no-legs --no-cpu-baseline --steps 3 --warmup 1 "$@" | python -c "$P";
