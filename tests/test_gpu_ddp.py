@@ -125,3 +125,29 @@ def test_bench_train_two_ranks_fresh_subprocess_gloo():
     assert len(enq) == ddp["buckets"] >= 2 and [e["bucket"] for e in enq] == list(range(len(enq)))
     assert all(e["device_ms"] is not None and e["device_ms"] >= 0 for e in enq)
     assert enq[0]["device_ms"] < enq[-1]["device_ms"]               # buckets leave as backward produces them
+
+
+def test_bench_infer_two_ranks_fresh_subprocess_gloo():
+    """The DEFAULT bench mode (eval forward: the line the driver's N = 1, 2, 4, 8 scaling run reads) with two ranks, started
+    as a fresh process like the train test above: replicas sharded by sample, no data-path collective -- only the
+    barrier and the MAX-over-ranks of the timed region.  Checks n_gpus == 2, weak scaling, a positive whole-job rate,
+    a per-GPU step time, the roofline block, and that no CPU baseline / legs ran at N > 1."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TSR_BENCH_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--batch", "64", "--steps", "3",
+                        "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["warmup"] == 1
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["higher_is_better"] is True
+    assert abs(d["value"] - 2 * 64 / (d["ms_per_step"] * 1e-3)) <= 1e-2 * d["value"]       # whole-job rate = all ranks' samples / time
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    assert "legs" not in d and "cpu_baseline" not in d
