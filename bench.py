@@ -165,6 +165,9 @@ def main():
             and args.batch == 4096:
         res["legs"] = run_legs(args, dev)
     if rank == 0:
+        from tactilesr_amd import _lib
+        res["library"] = {"abi": _lib.ABI_VERSION, "variant_build_flags": _lib.build_flags(),        # 0 = the shipped build
+                          "path": os.path.relpath(_lib.LIB_PATH, REPO)}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
@@ -182,7 +185,6 @@ def run_legs(args, dev):
         a.seqs, a.impl, a.impl_given, a.batch = False, "fp16x3", False, 4096
         for k, v in over.items():
             setattr(a, k, v)
-        saved = os.environ.get("TSR_TRAIN_IMPL")
         t0 = time.perf_counter()
         try:
             r = fn(a, 1, 0, dev)
@@ -191,10 +193,6 @@ def run_legs(args, dev):
         except Exception as e:        # a leg must never take the headline down with it
             legs[name] = {"error": f"{type(e).__name__}: {e}"}
         finally:
-            if saved is None:
-                os.environ.pop("TSR_TRAIN_IMPL", None)
-            else:
-                os.environ["TSR_TRAIN_IMPL"] = saved
             gc.collect()
             torch.cuda.empty_cache()
 
@@ -306,7 +304,7 @@ def run_infer(args, world, rank, dev):
         peak = PEAK_F32_MFMA if args.impl == "f32" else PEAK_BF16_MFMA
         alg = B * c5_flop / (c5_ms * 1e-3) if ev else None       # algorithmic FLOP/s of the launch
         executed = alg * nprod if ev else None                               # MFMA FLOP/s actually executed
-        k32 = args.impl == "fp16x3" and not os.environ.get("TSR_CONV_M32")      # conv_mfma_k32.hip (16x16x32 MFMA)
+        k32 = args.impl == "fp16x3"                                             # conv_mfma_k32.hip (16x16x32 MFMA)
         kname = ("conv_mfma_f32_kernel<5, 128" if args.impl == "f32" else
                  ("conv_k32_kernel<5, 128, false, 2, %s" % ("true, false, 256" if fused else "false, false, 512")) if k32 else
                  "conv_mfma_split16_kernel<5, 128, %d, false, %s" % ({"fp16x3": 2, "bf16x6": 3, "bf16x3": 2, "bf16": 1}[args.impl],
@@ -367,9 +365,9 @@ def run_train(args, world, rank, dev):
     if world > 1:
         import torch.distributed as dist
     torch.manual_seed(42)
-    os.environ["TSR_TRAIN_IMPL"] = args.impl if args.impl_given else os.environ.get("TSR_TRAIN_IMPL", "fp16x3")
     model, cin_lr, side, cfg_over, fwd_flop = make_model(args)
     model = model.to(dev).train()
+    model.train_impl = args.impl if args.impl_given else "fp16x3"       # explicit: no environment variable selects arithmetic
     opt = optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-2)
     sync = ddp.GradSync(model, broadcast_buffers=args.broadcast_buffers) if world > 1 else None
     if sync:
@@ -406,7 +404,7 @@ def run_train(args, world, rank, dev):
         losses_all = [float(x) for x in lt]
     if rank == 0:
         value = B * world * args.steps / dt
-        impl = os.environ.get("TSR_TRAIN_IMPL", "fp16x3")
+        impl = eng.impl
         nprod, peak = {"bf16x6": (6, PEAK_BF16_MFMA), "fp16x3": (3, PEAK_BF16_MFMA),
                        "bf16": (1, PEAK_BF16_MFMA), "bf16op": (1, PEAK_BF16_MFMA)}.get(impl, (1, PEAK_F32_MFMA))
         # fwd + dgrad + wgrad, minus the dgrad of the T+1 stem convs (3->64, 3x3) whose input needs no gradient
@@ -425,7 +423,7 @@ def run_train(args, world, rank, dev):
         cv_ms = sum(a.elapsed_time(b) for a, b in cv) / max(1, len(cv))
         cv_alg = wg_flop / (cv_ms * 1e-3) if cv else None
         wname = ("wgrad_mfma_f32_kernel<5" if impl == "f32" else
-                 "wgrad_k32_kernel<5, 1, 128, 128" if impl == "fp16x3" and not os.environ.get("TSR_WGRAD_M32") else
+                 "wgrad_k32_kernel<5, 1, 128, 128" if impl == "fp16x3" else
                  "wgrad_tr16_kernel<5, 1, 128, 128")
         traffic, traffic_src = pmc_traffic(wname, "trainbf16" if impl == "bf16" else "train") if B == 2048 and not args.seqs else (None, None)
         res = {

@@ -32,6 +32,10 @@ extern "C" {
 /* Library / ABI version (bumped on any signature change). */
 int tsr_abi_version(void);
 
+/* 0 for the shipped library; non-zero for an experimental variant built by tools/build_variant.py (extra -D flags).  The
+ * Python binding refuses a non-zero library unless TSR_ALLOW_VARIANT=1 is set, and bench.py reports the value. */
+int tsr_build_flags(void);
+
 /* Re-order an nn.Conv2d weight (OIHW fp32; Cout in {64,128}, Cin % 16 == 0, k in {1,3,5})
  * into the [Cin/16][k*k][4][Cout][4] stream order tsr_conv2d_fwd consumes.
  * w_packed holds Cout*Cin*k*k floats. */

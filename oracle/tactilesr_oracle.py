@@ -348,6 +348,35 @@ def tactilesr_forward(p: Params, x: torch.Tensor, scale_factor=10, axisCnt=3,
 
 
 # --------------------------------------------------------------------------
+# TactileSRCNN (model/tactileSR_model.py:101-153): imported by both trainers, instantiated by none
+# --------------------------------------------------------------------------
+def tactilesrcnn_state_shapes() -> "Dict[str, Tuple[int, ...]]":
+    """Key -> shape in the reference class's ``state_dict()`` order (registration order msrb_layer, input_zyx,
+    upSample (no state), output; model/tactileSR_model.py:105-129)."""
+    d = {k.replace("patternFeatureExtra_layer", "msrb_layer"): v
+         for k, v in tactilesr_state_shapes(patternFeatureExtraLayerCnt=6, forceFeatureExtraLayerCnt=0).items()
+         if k.startswith("patternFeatureExtra_layer")}
+    for i, cin in ((0, 3), (3, 64), (6, 64)):
+        d[f"input_zyx.{i}.weight"] = (64, cin, 3, 3)
+        for s, shp in (("weight", (64,)), ("bias", (64,)), ("running_mean", (64,)), ("running_var", (64,)),
+                       ("num_batches_tracked", ())):
+            d[f"input_zyx.{i + 1}.{s}"] = shp
+    d["output.0.weight"] = (1, 64, 3, 3)
+    return d
+
+
+def tactilesrcnn_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
+    """TactileSRCNN.forward in eval mode, model/tactileSR_model.py:146-151: bilinear x10 -> three conv3x3+BN+ReLU ->
+    six MSRBs -> conv 64->1 + ReLU."""
+    h = bilinear_resize(x, (x.shape[2] * 10, x.shape[3] * 10))
+    for i in (0, 3, 6):
+        h = _conv_bn_relu(p, f"input_zyx.{i}", f"input_zyx.{i + 1}", h, 1, False, None)
+    for i in range(_count(p, "msrb_layer")):
+        h = msrb_forward(p, f"msrb_layer.{i}", h)
+    return F.relu(F.conv2d(h, p["output.0.weight"], padding=1))
+
+
+# --------------------------------------------------------------------------
 # trainer step semantics (train/tactileSR_train.py:41-51 ; cpu/trainer.py:346-362)
 # --------------------------------------------------------------------------
 def prepare_target(HR_raw: torch.Tensor, HR_scale_num=10.0, scale_factor=10) -> torch.Tensor:

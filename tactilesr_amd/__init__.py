@@ -5,7 +5,7 @@ HIP kernel in ``lib/libtactilesr_hip.so`` reached through the C ABI of
 ``include/tactilesr_hip.h``.  No CPU fallback exists in this package.
 """
 from . import _lib  # noqa: F401
-from .model.tactileSR_model import TactileSR, MSRB, ResBlock  # noqa: F401
+from .model.tactileSR_model import TactileSR, TactileSRCNN, MSRB, ResBlock  # noqa: F401
 from .model.tPSFNet import tPSFNet  # noqa: F401
 
-__all__ = ["TactileSR", "MSRB", "ResBlock", "tPSFNet"]
+__all__ = ["TactileSR", "TactileSRCNN", "MSRB", "ResBlock", "tPSFNet"]

@@ -13,13 +13,14 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TSR_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libtactilesr_hip.so")   # override: kernel A/B experiments
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _P, _I, _F, _L = c_void_p, c_int, c_float, c_longlong
 
 # name -> argtypes; must list every symbol include/tactilesr_hip.h declares
 SIGNATURES = {
     "tsr_abi_version": [],
+    "tsr_build_flags": [],
     "tsr_pack_conv_weight": [_P, _P, _I, _I, _I, _P],
     "tsr_conv2d_fwd": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "tsr_conv_weight_bf16s_elems": [_I, _I, _I, _I],
@@ -112,8 +113,22 @@ def load() -> ctypes.CDLL:
     v = lib.tsr_abi_version()
     if v != ABI_VERSION:
         raise TactileSRHipError(f"libtactilesr_hip.so ABI {v} != expected {ABI_VERSION}: rebuild")
+    flags = lib.tsr_build_flags()
+    if flags != 0:
+        # an experimental variant (tools/build_variant.py): never loaded by accident, never silent
+        if os.environ.get("TSR_ALLOW_VARIANT") != "1":
+            raise TactileSRHipError(f"{LIB_PATH} is an experimental variant build (tsr_build_flags() = {flags}); set "
+                                    "TSR_ALLOW_VARIANT=1 to load it for a kernel A/B measurement")
+        import warnings
+        warnings.warn(f"tactilesr_amd: loaded an experimental variant library ({LIB_PATH}, build flags {flags}); "
+                      "its results are NOT parity-checked")
     _lib = lib
     return lib
+
+
+def build_flags() -> int:
+    """0 = the shipped library, non-zero = an experimental variant (see tsr_build_flags in include/tactilesr_hip.h)."""
+    return int(load().tsr_build_flags())
 
 
 def ptr(t) -> c_void_p:

@@ -18,7 +18,6 @@
 // fp32-faithful (1e-5 relative parity with the reference's CPU path).
 #include "tsr_common.h"
 #include "tactilesr_hip.h"
-#include <stdlib.h>
 
 #include "conv_args.h"
 #include "conv_epilogue.h"
@@ -203,20 +202,12 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
   }
 }
 
-static int g_prefetch = -1;   // TSR_CONV_PREFETCH=0/1 (tuning knob; default per instantiation below)
-
 template <int KS, int COUT, bool EXT>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
   const int groups = (a.B + 1) / 2;
   const int grid = groups * a.tiles_x * a.tiles_y;
-  if (g_prefetch < 0) {
-    const char* e = getenv("TSR_CONV_PREFETCH");
-    g_prefetch = e ? atoi(e) : 0;
-  }
-  if (g_prefetch)
-    hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, COUT, EXT, true>), dim3(grid), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, COUT, EXT, false>), dim3(grid), dim3(256), 0, st, a);
+  // (the PF = true form -- halo prefetch into registers -- measured no faster in round 1 and is not instantiated)
+  hipLaunchKernelGGL((conv_mfma_f32_kernel<KS, COUT, EXT, false>), dim3(grid), dim3(256), 0, st, a);
   return tsr_check_launch();
 }
 

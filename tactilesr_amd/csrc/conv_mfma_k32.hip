@@ -30,7 +30,6 @@
 #include "conv_epilogue16.h"
 #include "conv_fuse1x1_16.h"
 #include "tactilesr_hip.h"
-#include <stdlib.h>
 #include <type_traits>
 
 typedef _Float16 kf16x8 __attribute__((ext_vector_type(8)));
@@ -90,11 +89,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
   static_assert(NTHR == 256 || (NTHR == 512 && WN == 2), "512 threads: 4 images x 2 C_out halves");
   typedef K32Geom<KS, COUT, WN, DBH, NTHR> G;
   constexpr int NW = NTHR / 64;
-#ifdef TSR_EXP_K32_EXTDMA                 // experiment: LDS-DMA in the training instantiations too
-  constexpr bool WDMA = true;
-#else
   constexpr bool WDMA = !EXT;             // weight slabs by LDS-DMA (inference) or through registers (training)
-#endif
   constexpr int IMG = G::IMG, P = KS / 2, HH = G::HH, T = G::T, HS = G::HS, NT = COUT / (16 * WN);
   constexpr int PIXB = G::PIXB, ROWB = G::ROWB, IMGB = G::IMGB, HALO_B = G::HALO_B;
   constexpr int SROWB = G::SROWB, SIMGB = G::SIMGB, SIDE_B = G::SIDE_B;
@@ -223,10 +218,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
   // access through FLAT and then degrades every counted lgkmcnt wait of the step to lgkmcnt(0) -- a full LDS drain in the
   // middle of every step (whole eval forward 133.3 -> 131.9 ms with the MUBUF form).  Against register staging
   // (4 global loads + 4 ds_write_b128 per thread and step, 16 VGPRs): 5x5 128->128 11.57 -> 10.75 ms, eval forward
-  // 141.4 -> 137.0 ms.  (TSR_ABL_K32_* : timing ablations, wrong results -- tools/build_variant.py)
-#if defined(TSR_ABL_K32_NOW)
-#define DMA_BYTES(goff_, slot_, nv_) {}
-#else
+  // 141.4 -> 137.0 ms.
 #define DMA_BYTES(goff_, slot_, nv_)                                                     \
   {                                                                                      \
     const int vo_ = (int)(goff_) + tid * 16;                                             \
@@ -235,7 +227,6 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(dst_ + v * NTHR * 16), 16, \
                                                vo_ + v * NTHR * 16, 0, 0, 0);             \
   }
-#endif
   // Training launches (EXT) keep REGISTER staging -- slab s+3 loaded into VGPRs at the end of step s, written to LDS at
   // the end of step s+1 -- and 512-thread workgroups: same-box A/B of the train step 277.2 ms against 281.7 (LDS-DMA, 256
   // threads) / 285 (LDS-DMA, 512 threads); the inference launches gain 4 % from LDS-DMA at 256 threads (138.5 -> 132.8 ms).
@@ -249,20 +240,10 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
     char* wb_ = wbuf + (slot) * WSLAB_B;                                                 \
     _Pragma("unroll") for (int v = 0; v < WV; ++v) ((f32x4*)wb_)[tid + v * NTHR] = wreg[v]; \
   }
-#if defined(TSR_ABL_K32_NOW2)      // slabs 0..2 only (real data in LDS, no stream)
-#define DMA_W(sidx, slot) { if ((sidx) < 3) DMA_BYTES((size_t)(sidx) * WSLAB_B, slot, WV) }
-#elif defined(TSR_ABL_K32_NOW3)    // the stream re-reads slabs 0..2 (L1 / L2 hot)
-#define DMA_W(sidx, slot) DMA_BYTES((size_t)((sidx) % 3) * WSLAB_B, slot, WV)
-#else
 #define DMA_W(sidx, slot) DMA_BYTES((size_t)(sidx) * WSLAB_B, slot, WV)
-#endif
   // wait for the slab only: the n_ YOUNGEST vector-memory operations (the next block's halo loads, issued after the
   // slab request of the same step) may stay in flight -- vmcnt counts in issue order
-#ifdef TSR_ABL_K32_NOWAIT          // timing only: the slab is not awaited (racy)
-#define DMA_WAIT_N(n_) {}
-#else
 #define DMA_WAIT_N(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14))
-#endif
 #define DMA_WAIT() DMA_WAIT_N(0)
   // pair form: the slabs of the outer-ring steps hold the 5x5 conv's 64 channels only (half size); the stream is walked
   // with a running offset.  pq_ = index of the step within its block pair (0..24), compile time.
@@ -272,11 +253,7 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
     if (PAIR_HALF(pq_)) { DMA_BYTES(woff, slot, WV / 2); woff += WSLAB_B / 2; }          \
     else { DMA_BYTES(woff, slot, WV); woff += WSLAB_B; }                                 \
   }
-#ifdef TSR_ABL_K32_NOBAR
-#define STEP_BARRIER() __builtin_amdgcn_sched_barrier(0)
-#else
 #define STEP_BARRIER() __syncthreads()
-#endif
   // fragments of pair step st_ (taps 2 st_, 2 st_ + 1 of the resident block), plane p_
 #define LOAD_A(dst, p_, st_, hb_)                                                        \
   {                                                                                      \
@@ -293,15 +270,11 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
   {                                                                                      \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) dst[mt] = *(const kf16x8*)(lds + lcd + mt * 2 * ROWB + (p_) * 32); \
   }
-#ifdef TSR_ABL_K32_NOBRD
-#define LOAD_B(dst, p_, slot_) { if (a.B < 0) { const char* wb_ = wbuf + laneB; _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) dst[nt] = *(const kf16x8*)(wb_ + nt * 256); } }
-#else
 #define LOAD_B(dst, p_, slot_)                                                           \
   {                                                                                      \
     const char* wb_ = wbuf + (slot_) * WSLAB_B + laneB + (p_) * (2 * COUT * 16);         \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) dst[nt] = *(const kf16x8*)(wb_ + nt * 256); \
   }
-#endif
   // pair form, outer-ring steps: only n-tiles 2, 3 (the 5x5 conv's channels of this wave)
 #define LOAD_B_HI(dst, p_, slot_)                                                        \
   {                                                                                      \
@@ -535,27 +508,22 @@ __global__ __launch_bounds__(NTHR, NTHR == 512 ? 1 : 2) void conv_k32_kernel(con
 }
 
 // ---- launchers (called from conv_mfma_split16.hip's dispatchers; argument checks were done there) -------------------
-// C_out = 128: 512-thread workgroups (4 images); TSR_CONV_K32_256=1 keeps the 256-thread form (2 images) -- NB the
-// statistics-slab numbering of the train epilogues follows the image count (tsr_conv2d_slab_entries_ex asks k32_images)
-static bool k32_256() {
-  static const bool on = getenv("TSR_CONV_K32_256") != nullptr;
-  return on;
-}
-int tsr_conv_k32_images(int cout) { return cout == 128 && k32_256() ? 2 : 4; }
+// Images per workgroup of the plain / training launches (= statistics-slab entries per workgroup: the slab numbering of
+// the train epilogues follows it, tsr_conv2d_slab_entries_ex asks here): 4 for both widths -- C_out = 128 training
+// launches are 512-thread workgroups (4 images x 2 C_out halves), C_out = 64 ones 256 threads (4 images x 64 channels).
+int tsr_conv_k32_images(int cout) { (void)cout; return 4; }
 
 template <int KS, int COUT, bool EXT>
 static int launch_k32(const ConvArgs& a, hipStream_t st) {
   // (C_out = 64 as 2 images x 2 halves of 32 channels, 3 workgroups per CU, measured no better than the 4-image form:
   // 5x5 3.41 vs 3.39 ms, 3x3 1.60 vs 1.68 ms at B = 4096; the 32x32x16 kernel does 3.23 / 1.61 ms)
   constexpr int WN = COUT / 64;
-  if constexpr (COUT == 128 && EXT) {      // training: 512 threads + register staging; inference: 256 threads + LDS-DMA
-    if (!k32_256()) {
-      const int grid = ((a.B + 3) / 4) * a.tiles_x * a.tiles_y;
-      hipLaunchKernelGGL((conv_k32_kernel<KS, COUT, EXT, WN, false, KS == 3, 512>), dim3(grid), dim3(512), 0, st, a);
-      return tsr_check_launch();
-    }
+  if constexpr (COUT == 128 && EXT) {      // training: 512 threads (a weight slab serves 256 pixels) + register staging
+    const int grid = ((a.B + 3) / 4) * a.tiles_x * a.tiles_y;
+    hipLaunchKernelGGL((conv_k32_kernel<KS, COUT, EXT, WN, false, KS == 3, 512>), dim3(grid), dim3(512), 0, st, a);
+    return tsr_check_launch();
   }
-  constexpr int IMG = 4 / WN;
+  constexpr int IMG = 4 / WN;              // inference: 256 threads + LDS-DMA weight ring
   const int grid = ((a.B + IMG - 1) / IMG) * a.tiles_x * a.tiles_y;
   hipLaunchKernelGGL((conv_k32_kernel<KS, COUT, EXT, WN, false, KS == 3>), dim3(grid), dim3(256), 0, st, a);
   return tsr_check_launch();
@@ -676,13 +644,6 @@ extern "C" int tsr_conv2d_fwd_f16s_pair(const float* in, int in_ctot, int in_cof
   a.B = B; a.H = H; a.W = W;
   a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8;
   a.in_amax = in_amax; a.w_inv_scale = w_inv_scale; a.out_amax = out_amax;
-  static const bool p512 = getenv("TSR_CONV_PAIR512") != nullptr;
-  if (p512) {
-    const int grid4 = ((B + 3) / 4) * a.tiles_x * a.tiles_y;
-    hipLaunchKernelGGL((conv_k32_kernel<5, 128, false, 2, false, false, 512, true>), dim3(grid4), dim3(512), 0,
-                       (hipStream_t)stream, a);
-    return tsr_check_launch();
-  }
   const int grid = ((B + 1) / 2) * a.tiles_x * a.tiles_y;
   hipLaunchKernelGGL((conv_k32_kernel<5, 128, false, 2, false, false, 256, true>), dim3(grid), dim3(256), 0,
                      (hipStream_t)stream, a);
@@ -692,15 +653,7 @@ extern "C" int tsr_conv2d_fwd_f16s_pair(const float* in, int in_ctot, int in_cof
 int tsr_conv_k32_fuse1x1(const ConvArgs& a, int ks, hipStream_t st) {
   // The fused forms stay at 256 threads (2 workgroups per CU): with 512 threads the parked tile needs 139 KB of LDS, one
   // workgroup per CU, and the fused epilogue is no longer hidden behind a second workgroup's main loop -- same-box A/B of
-  // the whole eval forward: 145.2 ms (512) vs 144.6 ms (256); TSR_CONV_K32_FUSE512=1 selects the 512-thread form.
-  static const char* f512e = getenv("TSR_CONV_K32_FUSE512");       // "1": both kernel sizes, "3" / "5": that size only
-  const bool f512 = f512e && (f512e[0] == '1' || f512e[0] == '0' + ks);
-  if (f512 && !k32_256()) {
-    const int grid = ((a.B + 3) / 4) * a.tiles_x * a.tiles_y;
-    if (ks == 5) hipLaunchKernelGGL((conv_k32_kernel<5, 128, false, 2, true, false, 512>), dim3(grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((conv_k32_kernel<3, 128, false, 2, true, true, 512>), dim3(grid), dim3(512), 0, st, a);
-    return tsr_check_launch();
-  }
+  // the whole eval forward: 145.2 ms (512) vs 144.6 ms (256).
   const int grid = ((a.B + 1) / 2) * a.tiles_x * a.tiles_y;
   if (ks == 5) hipLaunchKernelGGL((conv_k32_kernel<5, 128, false, 2, true>), dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv_k32_kernel<3, 128, false, 2, true, true>), dim3(grid), dim3(256), 0, st, a);

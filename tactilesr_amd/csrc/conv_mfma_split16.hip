@@ -25,7 +25,6 @@
 #include "conv_epilogue.h"
 #include "conv_fuse1x1.h"
 #include "tactilesr_hip.h"
-#include <stdlib.h>
 #include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -39,31 +38,13 @@ template <bool F16> struct Plane;
 template <> struct Plane<false> {
   typedef __bf16 T; typedef bf16x8 V8; typedef bf16x4 V4;
   static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
-#ifdef TSR_EXP_MFMA16   // timing experiment only (wrong results): the same FLOPs as two 16x16x32 instructions
-    f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0);
-    c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
-    c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
-    return c;
-#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-#endif
   }
 };
 template <> struct Plane<true> {
   typedef _Float16 T; typedef f16x8 V8; typedef f16x4 V4;
   static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
-#ifdef TSR_EXP_MFMA16   // timing experiment only (wrong results): the same FLOPs as two 16x16x32 instructions
-    f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
-    c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
-    c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
-    return c;
-#else
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-#endif
   }
 };
 
@@ -352,13 +333,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
   }
 
   // ---- prologue: halo(0), W(0), W(1) in LDS; W(2) in flight
-#ifdef TSR_EXP_B16_EXT_NODMA
-  constexpr bool WDMA = !EXT;
-#else
   // (LDS-DMA in the fp32-storage training instantiations: neutral here, -5 ms/step in the K = 32 kernel; the one-plane
   // bf16-storage training form moves 3x the weight bytes per MFMA and gains from it like its inference form does)
   constexpr bool WDMA = !EXT || IO16;
-#endif
   f32x4 hv[NIT], wreg[WDMA ? 1 : WV];
   load_halo(0, hv);
   if constexpr (WDMA) {
@@ -417,11 +394,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
           if (PF && (t + 1 < T || DBH)) {
             // interleave the next tap's fragment reads with this tap's MFMAs (hipcc otherwise sinks all ds_reads
             // below the MFMA block, exposing their latency in front of the barrier's lgkmcnt(0) every step)
-            #ifdef TSR_EXP_MFMA16
-            constexpr int MFX = 2;
-#else
             constexpr int MFX = 1;
-#endif
             constexpr int NRD = NS * (2 + NB), NMF = NPROD * 2 * NB, PER = (NMF / NRD > 0 ? NMF / NRD : 1) * MFX;
 #pragma unroll
             for (int i = 0; i < NRD; ++i) {
@@ -521,20 +494,18 @@ __global__ void pack_conv_weight_bf16s_kernel(const float* __restrict__ w, typen
   }
 }
 
-// fp16x3 3x3 / 5x5 convolutions run on conv_mfma_k32.hip (16x16x32 MFMA, tap pairs) when the channel blocks come in
-// pairs; TSR_CONV_M32=1 keeps the 32x32x16 kernel of this file (A/B measurements).  Pack and launch ask the same question.
+// fp16x3 3x3 / 5x5 convolutions run on conv_mfma_k32.hip (16x16x32 MFMA, tap pairs); the 1x1 layers and the other
+// arithmetic modes stay on the 32x32x16 kernel of this file.  Pack and launch ask the same question (use_k32).
 int tsr_conv_k32(const ConvArgs& a, int cout, int ks, bool ext, hipStream_t st);      // conv_mfma_k32.hip
 int tsr_conv_k32_fuse1x1(const ConvArgs& a, int ks, hipStream_t st);
 // C_out = 64 convs run the K = 32 kernel too since round 3 (4 images x all 64 channels per workgroup): 3x3 eval 1.62 ->
 // 1.46 ms per launch at B = 4096, train (B = 2048) 3x3 dgrad 1.02 -> 0.96 ms, 5x5 forward 1.61 -> 1.45, 5x5 dgrad
 // 1.74 -> 1.63.  In round 2 the training instantiation of the 5x5 form ran 3x slower: one of the kernel's lambdas was
 // not inlined there, so its by-reference captures (the argument block, the staging index arrays) lived in scratch;
-// the lambdas are always_inline now.  TSR_CONV_K32_NO64=1 keeps C_out = 64 on the 32x32x16 kernel (A/B).
+// the lambdas are always_inline now.
 static bool use_k32(int ks, int kdim, int cout) {
-  static const bool off = getenv("TSR_CONV_M32") != nullptr;
-  static const bool no64 = getenv("TSR_CONV_K32_NO64") != nullptr;
   (void)kdim;          // an odd channel-block count is padded with a zero-weight block (pack) / a re-read block (kernel)
-  return !off && ks > 1 && (cout == 128 || (cout == 64 && !no64));
+  return ks > 1 && (cout == 128 || cout == 64);
 }
 // images per workgroup (= statistics-slab entries per workgroup) of the fp16x3 kernel that runs (cout, ks)
 int tsr_conv_k32_images(int cout);            // conv_mfma_k32.hip
@@ -784,10 +755,9 @@ static int launch_b16_ex(const ConvArgs& a, hipStream_t st) {
   // The streaming form runs the `confusion` FORWARD (256 -> 64, plain epilogue: 0.96 -> 0.81 ms at B = 2048); its dgrad
   // launches (64 -> 128 with the mask / BatchNorm-sum epilogue, 8-B epilogue accesses on bf16 tensors) measured slower
   // streamed (0.94 vs 0.77 ms) and stay on the tiled kernel -- which also keeps the 2-image statistics-slab numbering
-  // of every 1x1 launch that writes slabs.  TSR_B16_1X1_TILED=1: the tiled kernel for the forward too (A/B).
-  static const bool tiled = getenv("TSR_B16_1X1_TILED") != nullptr;
+  // of every 1x1 launch that writes slabs.
   if constexpr (COUT == 64) {
-    if (!tiled && a.epi_mode == 0) return launch_1x1_b16_ex<COUT>(a, st);
+    if (a.epi_mode == 0) return launch_1x1_b16_ex<COUT>(a, st);
   }
   const int grid = ((a.B + 1) / 2) * a.tiles_x * a.tiles_y;
   hipLaunchKernelGGL((conv_mfma_split16_kernel<KS, COUT, 1, true, false, 2, false, true>), dim3(grid), dim3(256), 0, st, a);

@@ -11,7 +11,6 @@
 //  * layout converters NCHW <-> CB16 (test / probe plumbing).
 #include "tsr_common.h"
 #include "conv_epilogue.h"      // quad_transpose
-#include <stdlib.h>
 
 // ATen upsample_bilinear2d (align_corners=False) source index.
 __device__ __forceinline__ void bilin_src(int dst, float scale, int n_in, int& i0, int& i1, float& lam) {
@@ -221,81 +220,11 @@ extern "C" int tsr_stem_fwd_b16(const float* lr, int lr_ctot, int lr_coff, int a
 }
 
 // ---------------------------------------------------------------------------------------
-// Thread = (pixel, channel quad): the four lanes of a pixel read the four 16-B quarters of each 64-B CB16 line, so a
-// load instruction consumes whole lines (a lane per pixel reads every line in four instructions: 4x the L1 tag
-// work on an HBM-read-bound kernel); the partial dot products meet through two DPP adds.
-template <bool IN16>
-__global__ __launch_bounds__(256) void head_kernel(const float* __restrict__ in, int in_ctot, int cin,
-                                                   const float* __restrict__ w,   // OIHW (1,cin,3,3)
-                                                   float* __restrict__ out, int relu, int B, int H, int W) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];   // [cin/16][9][16]
-  const int tid = threadIdx.x;
-  const int nblk = cin >> 4;
-  for (int i = tid; i < nblk * 9 * 16; i += 256) {
-    const int j = i & 15, r = i >> 4;
-    const int tap = r % 9, blk = r / 9;
-    wl[i] = w[(blk * 16 + j) * 9 + tap];
-  }
-  __syncthreads();
-  const int HW = H * W;
-  // XCD-aware order (speed only): the 64-pixel workgroups of one image read each other's 3x3 halo rows.  Dealt
-  // round-robin over the 8 XCDs they sat in 8 different L2s and every halo row came from HBM again (r01 PMC: 6.71 GB
-  // per launch against 3.36 GB algorithmic); remapped, an XCD works through a contiguous range of images and the
-  // re-reads hit its L2.
-  int b, chunk;
-  {
-    const int per_img = gridDim.x, nwg = gridDim.x * gridDim.y;
-    const int flat = blockIdx.y * per_img + blockIdx.x;
-    const int qn = nwg >> 3, rn = nwg & 7, xcd = flat & 7, idx = flat >> 3;
-    const int logical = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
-    b = logical / per_img;
-    chunk = logical - b * per_img;
-  }
-  const int q = tid & 3;
-  const int p = chunk * 64 + (tid >> 2);
-  const bool live = p < HW;                      // (no early return: the quad reduction below needs all four lanes)
-  const int pc = live ? p : HW - 1;
-  const int y = pc / W, x = pc - y * W;
-  const int in_blocks = in_ctot >> 4;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f;            // one accumulator per kernel row: three independent FMA chains
-  for (int blk = 0; blk < nblk; ++blk) {
-    const size_t pidx = ((size_t)b * in_blocks + blk) * HW * 16 + 4 * q;
-    const float* plane = in + pidx;
-    const __bf16* plane16 = (const __bf16*)in + pidx;
-    const float* wb = wl + blk * 9 * 16 + 4 * q;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int gy = y + kh - 1;
-      if (gy < 0 || gy >= H) continue;
-      float s = 0.f;
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int gx = x + kw - 1;
-        if (gx < 0 || gx >= W) continue;
-        f32x4 v;
-        if (IN16) {
-          const sh_bf16x4 hvv = *(const sh_bf16x4*)(plane16 + (size_t)(gy * W + gx) * 16);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = (float)hvv[c];
-        } else {
-          v = *(const f32x4*)(plane + (size_t)(gy * W + gx) * 16);
-        }
-        const f32x4 wv = *(const f32x4*)(wb + (kh * 3 + kw) * 16);
-        s = fmaf(v[0], wv[0], fmaf(v[1], wv[1], fmaf(v[2], wv[2], fmaf(v[3], wv[3], s))));
-      }
-      if (kh == 0) a0 += s; else if (kh == 1) a1 += s; else a2 += s;
-    }
-  }
-  float v = (a0 + a1) + a2;
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // lane ^ 1
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // lane ^ 2
-  if (relu) v = tsr_relu(v);
-  if (live && q == 0) out[(size_t)b * HW + p] = v;
-}
-
-// LDS-tiled form (round 3, default): the kernel above asks L1 / the texture path for every input line nine times (once
-// per tap: 72 16-B load instructions per thread) and ran at 2.1 TB/s = 0.26 of HBM although its HBM traffic is the
-// algorithmic 3.36 GB (the re-reads hit L2).  Here a workgroup owns an 8x8 pixel patch of one image, stages the 10x10
+// Head (conv 128 -> 1, 3x3).  Thread = (pixel, channel quad): the four lanes of a pixel read the four 16-B quarters of
+// each 64-B CB16 line; the partial dot products meet through two DPP adds.
+// LDS-tiled form: a thread-per-pixel kernel that reads its nine taps straight from global memory asks L1 / the texture
+// path for every input line nine times (72 16-B load instructions per thread; rounds 1-2 ran that at 2.1 TB/s = 0.26 of
+// HBM although its HBM traffic was the algorithmic 3.36 GB).  Here a workgroup owns an 8x8 pixel patch of one image, stages the 10x10
 // halo of one 16-channel block per step (1.6 global loads per thread instead of 9; double-buffered, one barrier per
 // block) and takes the nine taps from LDS: thread = (pixel, channel quad) as before, so a 16-lane group reads 256
 // contiguous bytes (4 pixels x 64 B): bank-conflict free without padding.
@@ -390,13 +319,6 @@ __global__ __launch_bounds__(256) void head_lds_kernel(const float* __restrict__
 template <bool IN16>
 static int head_launch(const float* in, int in_ctot, int cin, const float* w_oihw, float* out_nchw, int relu, int B, int H,
                        int W, void* stream) {
-  static const bool old = getenv("TSR_HEAD_OLD") != nullptr;       // A/B: the round-1/2 kernel (nine global reads per line)
-  if (old) {
-    dim3 grid((H * W + 63) / 64, B);
-    hipLaunchKernelGGL(head_kernel<IN16>, grid, dim3(256), (size_t)cin * 9 * 4, (hipStream_t)stream, in, in_ctot, cin,
-                       w_oihw, out_nchw, relu, B, H, W);
-    return tsr_check_launch();
-  }
   const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
   const size_t smem = (size_t)cin * 9 * 4 + 2 * 1600 * 4;
   hipLaunchKernelGGL(head_lds_kernel<IN16>, dim3(B * tiles_x * tiles_y), dim3(256), smem, (hipStream_t)stream, in, in_ctot,

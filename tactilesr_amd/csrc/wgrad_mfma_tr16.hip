@@ -22,7 +22,6 @@
 // apart (pixel counts padded to 4 mod 8), i.e. complementary halves of the 64-bank row for ANY start pixel: conflict
 // free for every tap.  Staging writes are 8 B per lane, 512 contiguous bytes per wave: conflict free.
 #include "tsr_common.h"
-#include <stdlib.h>
 #include <type_traits>
 
 typedef __bf16 tb16x8 __attribute__((ext_vector_type(8)));
@@ -39,16 +38,7 @@ template <> struct TPlane<false> {
 template <> struct TPlane<true> {
   typedef _Float16 T; typedef th16x8 V8; typedef th16x4 V4;
   static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
-#ifdef TSR_EXP_MFMA16   // timing experiment only (wrong results): the same FLOPs as two 16x16x32 instructions
-    f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
-    c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
-    c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
-    return c;
-#else
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-#endif
   }
 };
 
@@ -96,15 +86,13 @@ struct WgradTGeom {
   static_assert(NT % 16 == 0 && (NT / 16) % (CO / 16) == 0 && (NT / 16) % (CI / 16) == 0 && A_PX % 4 == 0, "staging map");
 };
 
-// SPEC: role-specialised workgroup of 2 x NWAVE waves -- waves [0, NWAVE) only run the MFMA loop (one per SIMD for the
-// 4-wave tiles: the matrix pipe is theirs alone), waves [NWAVE, 2 NWAVE) only stage (global loads, fp32 -> fp16-plane
-// conversion, LDS writes) one item ahead.  In the symmetric form the two waves of a SIMD run the same code in
-// lockstep and its VALU time (32 %) adds to its MFMA time (59 %); with different programs they overlap.
+// (A role-specialised form -- 4 MFMA-only waves + 4 staging-only waves per workgroup -- was measured in round 2 and is gone:
+// 3.91 vs 3.46 ms at 5x5 128x128)
 // IO16 (NS = 1, bf16): `a` and `dz` are bf16 CB16 tensors (training with bf16 activation storage): staging copies 8-B
 // quads as they are (dz, and `a` without a fused transform) or applies relu(a*scale+shift) in fp32 and rounds back.
-template <int KS, int KHW, int CO, int CI, int WM, int NS, bool F16, bool SPEC = false, bool IO16 = false>
-__global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) void wgrad_tr16_kernel(const WgradTArgs g) {
-  static_assert(!IO16 || (NS == 1 && !F16 && !SPEC), "bf16 tensors: one bf16 plane");
+template <int KS, int KHW, int CO, int CI, int WM, int NS, bool F16, bool IO16 = false>
+__global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_tr16_kernel(const WgradTArgs g) {
+  static_assert(!IO16 || (NS == 1 && !F16), "bf16 tensors: one bf16 plane");
   typedef WgradTGeom<KS, KHW, CO, CI, WM, NS, F16> G;
   typedef typename TPlane<F16>::T PT;
   typedef typename TPlane<F16>::V8 PV8;
@@ -112,7 +100,7 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
   typedef __attribute__((address_space(3))) tv4i16* lds_v4;
   constexpr int P = KS / 2;
   constexpr int NT = G::NT, MT = G::MT;            // NT = staging threads (= MFMA threads)
-  constexpr int NTT = SPEC ? 2 * NT : NT;            // threads of the workgroup
+  constexpr int NTT = NT;                            // threads of the workgroup
   constexpr int NPROD = NS == 3 ? 6 : (NS == 2 ? 3 : 1);
   // products ordered small -> large (plane 0 = most significant)
   constexpr int PA[6] = {NS == 3 ? 2 : (NS == 2 ? 1 : 0), 0, NS == 3 ? 1 : 0, 1, 0, 0};
@@ -121,11 +109,8 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
   __shared__ __attribute__((aligned(16))) char lds[G::LDSB];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool stager = !SPEC || __builtin_amdgcn_readfirstlane(wave) >= G::NWAVE;     // this wave stages tiles
-  const bool mmaer = !SPEC || !stager;                                               // this wave runs the MFMAs
-  const int tid = SPEC ? (threadIdx.x & (NT - 1)) : threadIdx.x;                      // index within its role
-  const int wrole = SPEC ? (wave % G::NWAVE) : wave;
-  const int wm = wrole / G::NWN, wn = wrole - wm * G::NWN;
+  const int tid = threadIdx.x;
+  const int wm = wave / G::NWN, wn = wave - wm * G::NWN;
   const int h = lane >> 5, li = lane & 31;
 
   const int nci = g.cin / CI, nco = g.cout / CO;
@@ -399,11 +384,7 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
       const int s = u / G::NTAP, tap = u - s * G::NTAP;
       const int cb = u & 1;
       const bool seam = tap == G::NTAP - 1 && s == 0;       // the staging block sits between the two K steps
-#ifdef TSR_ABL_WG_NOBREAD
-      if (u == 0) load_b(bf[1], 0, 1);
-#else
       if (u + 1 < NU && !seam) load_b(bf[cb ^ 1], (u + 1) / G::NTAP, (u + 1) % G::NTAP);
-#endif
       // (a short last row group computes its missing rows on zero-weighted garbage-free data: the rows exist in the
       // staged tile, their products are simply not written out)
 #pragma unroll
@@ -411,7 +392,6 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
 #pragma unroll
         for (int m = 0; m < MT; ++m)
           acc[m][tap] = TPlane<F16>::mfma(af[m][PA[6 - NPROD + t]], bf[cb][PB[6 - NPROD + t]], acc[m][tap]);
-#ifndef TSR_ABL_WG_NOFENCE
       if (u + 1 < NU && !seam) {
         constexpr int NRD = 2 * NS, NMF = NPROD * MT, PER = NMF / NRD > 0 ? NMF / NRD : 1;
 #pragma unroll
@@ -421,14 +401,11 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-#endif
       if (seam) {       // no fragment is prefetched across the staging block: its registers are needed there
         between_steps();
         __builtin_amdgcn_sched_barrier(0);
         load_a(af, 1);
-#ifndef TSR_ABL_WG_NOBREAD
         load_b(bf[cb ^ 1], 1, 0);
-#endif
       }
     }
   };
@@ -454,67 +431,29 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64 * (SPEC ? 2 : 1), 2) voi
       }
   };
 
-  if (it0 < it1 && stager) {
+  if (it0 < it1) {
     load_item();
     store_item(0);
-#ifdef TSR_WG_LOAD_AT_ITEM_START
-    if (SPEC && it0 + 1 < it1) load_item();          // specialised stagers run one item ahead with the loads in flight
-#else
-    if (it0 + 1 < it1) load_item();                  // item + 1 in flight from here on (both forms)
-#endif
+    if (it0 + 1 < it1) load_item();                  // item + 1 in flight from here on
   }
   __syncthreads();
   int cur = 0;
-  if (!SPEC) {
-    zero_acc();
-    for (int item = it0; item < it1; ++item) {
-      const bool more = item + 1 < it1;
-#if !defined(TSR_ABL_WG_NOLOAD) && defined(TSR_WG_LOAD_AT_ITEM_START)
-      if (more) load_item();               // (former order: item + 1 requested at the start of item)
-#endif
-#ifndef TSR_ABL_WG_NOMMA
-      mma_item(cur, [&]() {
-#endif
-#ifndef TSR_ABL_WG_NOSTORE
-        if (more) store_item(cur ^ 1);     // the other buffer: its last readers passed the previous barrier
-#else
-        asm volatile("" :: "v"(hd[0][0]), "v"(ha[0][0]), "v"(ha[G::NIT_A - 1][3]), "v"(hd[G::NIT_DZ - 1][3]));
-#endif
-#if !defined(TSR_ABL_WG_NOLOAD) && !defined(TSR_WG_LOAD_AT_ITEM_START)
-        if (item + 2 < it1) load_item();   // the staging registers are free again: item + 2 flies for a whole item
-#endif
-#ifndef TSR_ABL_WG_NOMMA
-      });
-#endif
-      __syncthreads();
-      cur ^= 1;
-    }
-    write_slab();
-  } else if (stager) {
-    for (int item = it0; item < it1; ++item) {
-      if (item + 1 < it1) {
-        store_item(cur ^ 1);               // item + 1: loaded during the previous iteration
-        if (item + 2 < it1) load_item();   // item + 2: in flight for a whole item
-      }
-      __syncthreads();
-      cur ^= 1;
-    }
-  } else {
-    zero_acc();
-    for (int item = it0; item < it1; ++item) {
-      mma_item(cur, [&]() {});
-      __syncthreads();
-      cur ^= 1;
-    }
-    write_slab();
+  zero_acc();
+  for (int item = it0; item < it1; ++item) {
+    const bool more = item + 1 < it1;
+    mma_item(cur, [&]() {
+      if (more) store_item(cur ^ 1);       // the other buffer: its last readers passed the previous barrier
+      if (item + 2 < it1) load_item();     // the staging registers are free again: item + 2 flies for a whole item
+    });
+    __syncthreads();
+    cur ^= 1;
   }
+  write_slab();
 
   if (do_bias) {       // thread slot j holds the sums of 4 channels of (pixel, block): reduce the 32 pixels
     float* bred = (float*)lds;                 // [pixel slot = 4 pgd + spl][CO]
-    if (stager) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) bred[(pgd * 4 + spl) * CO + blkd * 16 + sq * 4 + c] = bsum[c];
-    }
+    for (int c = 0; c < 4; ++c) bred[(pgd * 4 + spl) * CO + blkd * 16 + sq * 4 + c] = bsum[c];
     __syncthreads();
     for (int c = threadIdx.x; c < CO; c += NTT) {
       float s = 0.f;
@@ -697,16 +636,6 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
   };
 
   auto split_store = [&](f32x4 v, char* dst, int plane_stride, float mult) {
-#ifdef TSR_ABL_WG_NOCVT      // timing ablation (wrong results): the staging path as a pure copy of pre-split data, no VALU.
-    // Measured (round 3, B = 2048): 5x5 128->128 6.27 -> 5.66 ms, 3x3 128->128 2.62 -> 2.35, 5x5 64->64 2.28 -> 2.04: the
-    // ceiling of an operand format pre-split by the producers is -10 % of wgrad (~3 % of the train step).
-    // (the bits are masked into small finite fp16 values: NaN / Inf operands would change the chip's power and clock)
-    uint2 w0 = {__float_as_uint(v[0]) & 0x33ff33ffu, __float_as_uint(v[1]) & 0x33ff33ffu};
-    uint2 w1 = {__float_as_uint(v[2]) & 0x33ff33ffu, __float_as_uint(v[3]) & 0x33ff33ffu};
-    *(uint2*)(dst) = w0;
-    *(uint2*)(dst + plane_stride) = w1;
-    (void)mult;
-#else
 #pragma unroll
     for (int c = 0; c < 4; ++c) v[c] *= mult;
 #pragma unroll
@@ -717,13 +646,8 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
         qv[c] = (PT)v[c];
         v[c] -= (float)qv[c];
       }
-#ifdef TSR_ABL_WG_NODSW      // timing ablation: conversions kept, LDS writes dropped
-      asm volatile("" :: "v"(qv));
-#else
       *(PV4*)(dst + p * plane_stride) = qv;
-#endif
     }
-#endif
   };
 
   auto store_item = [&](int buf) {
@@ -806,24 +730,16 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
             acc[m][n][tap] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf[cb][n], acc[m][n][tap], 0, 0, 0);
         if (tap + 1 < G::NTAP) {
           constexpr int NMF = MT * 2, PER = NMF / 4 > 0 ? NMF / 4 : 1;
-#if defined(TSR_WG_SPREAD_READS)      // the former schedule: one read after every PER MFMAs (5x5 128x128 7.15 vs 7.05 ms)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
-          }
-#else
           __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // the next tap's reads first: a whole tap of cover
           __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
           (void)PER;
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       // the staging block: no fragment is live across it.  (Measured and dropped: staging the upper four waves of an
       // 8-wave tile one sweep later, so that the two waves of a SIMD convert and multiply at different times -- as a
       // wave-uniform run-time branch, without spills: 5x5 128x128 6.69 -> 6.87 ms, 3x3 128x64 2.40 -> 2.55.  The
-      // position itself (after sweep 0 / 1 / 2 for all waves) is neutral or worse as well: TSR_WG_STAGE_EARLY.)
+      // position itself (after sweep 0 / 1 / 2 for all waves) is neutral or worse as well.)
       if (sw == stage_after) {
         between_sweeps();
         __builtin_amdgcn_sched_barrier(0);
@@ -835,40 +751,13 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
   if (it0 < it1) {
     load_item();
     store_item(0);
-#ifndef TSR_WG_LOAD_AT_ITEM_START
     if (it0 + 1 < it1) load_item();
-#endif
   }
   __syncthreads();
   auto sweep_items = [&](auto late_c) __attribute__((always_inline)) {
     int cur = 0;
     for (int item = it0; item < it1; ++item) {
       const bool more = item + 1 < it1;
-#if defined(TSR_ABL_WG_NOSTAGE)          // timing ablations (wrong results): no staging at all / no global loads / no barrier
-      mma_item(cur, late_c, [&]() {});
-      __syncthreads();
-#elif defined(TSR_ABL_WG_NOLOAD)      // no global loads; the stale registers are made opaque so that the conversions stay in the loop
-#pragma unroll
-      for (int j = 0; j < G::NIT_DZ; ++j) asm volatile("" : "+v"(hd[j]));
-#pragma unroll
-      for (int j = 0; j < G::NIT_A; ++j) asm volatile("" : "+v"(ha[j]));
-      mma_item(cur, late_c, [&]() {
-        if (more) store_item(cur ^ 1);
-      });
-      __syncthreads();
-#elif defined(TSR_ABL_WG_NOBAR)
-      if (more) load_item();
-      mma_item(cur, late_c, [&]() {
-        if (more) store_item(cur ^ 1);
-      });
-      __builtin_amdgcn_sched_barrier(0);
-#elif defined(TSR_WG_LOAD_AT_ITEM_START)
-      if (more) load_item();
-      mma_item(cur, late_c, [&]() {
-        if (more) store_item(cur ^ 1);
-      });
-      __syncthreads();
-#else
       // item + 1 is in the staging registers (requested a whole item ago); as soon as they have been converted into the
       // other LDS buffer they are reloaded with item + 2
       mma_item(cur, late_c, [&]() {
@@ -876,24 +765,10 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
         if (item + 2 < it1) load_item();
       });
       __syncthreads();
-#endif
       cur ^= 1;
     }
   };
-  // Two copies of the item loop (each with its own register allocation), chosen per wave: see the staging block above.
-#ifndef TSR_WG_STAGE_EARLY
-#define TSR_WG_STAGE_EARLY 0
-#endif
-#ifndef TSR_WG_STAGE_LATE
-#define TSR_WG_STAGE_LATE TSR_WG_STAGE_EARLY
-#endif
-  if constexpr (TSR_WG_STAGE_EARLY != TSR_WG_STAGE_LATE) {
-    const bool late_wave = G::NWAVE == 8 && __builtin_amdgcn_readfirstlane(wave) >= 4;
-    if (late_wave) sweep_items(std::integral_constant<int, TSR_WG_STAGE_LATE>());
-    else sweep_items(std::integral_constant<int, TSR_WG_STAGE_EARLY>());
-  } else {
-    sweep_items(std::integral_constant<int, TSR_WG_STAGE_EARLY>());
-  }
+  sweep_items(std::integral_constant<int, 0>());        // the staging block sits after sweep 0
 
   {   // this split's partial dW: slab[sp][co][ci][kh][kw]
     constexpr int T = KS * KS;
@@ -942,62 +817,39 @@ __global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, 2) void wgrad_k32_kerne
 template <int KS, int NS> struct WgradTCfg {
   static constexpr bool wide = NS <= 2;
   static constexpr int KHW_BIG = !wide ? 1 : (KS == 3 ? 3 : 1);
-#ifdef TSR_EXP_WG_5X5_2WG
-  static constexpr int CI_BIG = !wide ? 64 : (KS == 1 ? 128 : 64);
-#else
   static constexpr int CI_BIG = !wide ? 64 : (KS == 3 ? 64 : 128);
-#endif
   static constexpr int WM_BIG = !wide ? 32 : (KS == 3 ? 32 : 64);
   static constexpr int KHW_SMALL = !wide ? 1 : (KS == 5 ? 2 : (KS == 3 ? 3 : 1));
 };
 
 static bool tr16_big(int cout, int cin, int ci_big) { return (cout % 128) == 0 && (cin % ci_big) == 0; }
 
-static bool tr16_spec() {
-  static const bool on = getenv("TSR_WGRAD_SPEC") != nullptr;
-  return on;
-}
-
-static bool tr16_m32() {       // TSR_WGRAD_M32=1: the 32x32x16 kernel for the fp16x3 path too (A/B measurements)
-  static const bool on = getenv("TSR_WGRAD_M32") != nullptr;
-  return on;
-}
-
 template <int KS, int NS, bool F16, bool IO16 = false>
 static int launch_tr16(const WgradTArgs& g, hipStream_t st) {
   typedef WgradTCfg<KS, NS> C;
-  if constexpr (F16 && NS == 2) {
-    if (!tr16_m32() && !tr16_spec()) {
-      if (tr16_big(g.cout, g.cin, C::CI_BIG)) {
-        typedef WgradKGeom<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG> G;
-        const int grid = g.nsplit * G::NKG * (g.cout / 128) * (g.cin / C::CI_BIG);
-        hipLaunchKernelGGL((wgrad_k32_kernel<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG>), dim3(grid), dim3(G::NT), 0, st, g);
-        return tsr_check_launch();
-      }
-      typedef WgradKGeom<KS, C::KHW_SMALL, 64, 64, 32> G;
-      const int grid = g.nsplit * G::NKG * (g.cout / 64) * (g.cin / 64);
-      hipLaunchKernelGGL((wgrad_k32_kernel<KS, C::KHW_SMALL, 64, 64, 32>), dim3(grid), dim3(G::NT), 0, st, g);
+  if constexpr (F16 && NS == 2) {            // fp16x3: the K = 32 (16x16x32 MFMA) form
+    if (tr16_big(g.cout, g.cin, C::CI_BIG)) {
+      typedef WgradKGeom<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG> G;
+      const int grid = g.nsplit * G::NKG * (g.cout / 128) * (g.cin / C::CI_BIG);
+      hipLaunchKernelGGL((wgrad_k32_kernel<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG>), dim3(grid), dim3(G::NT), 0, st, g);
       return tsr_check_launch();
     }
-  }
-  if constexpr (KS == 5 && F16) {
-    if (tr16_spec() && (g.cout % 128) == 0 && (g.cin % 64) == 0) {      // role-specialised 128 x 64 tile (4 + 4 waves)
-      typedef WgradTGeom<KS, 1, 128, 64, 64, NS, F16> G;
-      const int grid = g.nsplit * G::NKG * (g.cout / 128) * (g.cin / 64);
-      hipLaunchKernelGGL((wgrad_tr16_kernel<KS, 1, 128, 64, 64, NS, F16, true>), dim3(grid), dim3(2 * G::NT), 0, st, g);
+    typedef WgradKGeom<KS, C::KHW_SMALL, 64, 64, 32> G;
+    const int grid = g.nsplit * G::NKG * (g.cout / 64) * (g.cin / 64);
+    hipLaunchKernelGGL((wgrad_k32_kernel<KS, C::KHW_SMALL, 64, 64, 32>), dim3(grid), dim3(G::NT), 0, st, g);
+    return tsr_check_launch();
+  } else {                                    // bf16x6 (NS = 3) and one-plane bf16 (NS = 1, fp32 or bf16 tensors)
+    if (tr16_big(g.cout, g.cin, C::CI_BIG)) {
+      typedef WgradTGeom<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG, NS, F16> G;
+      const int grid = g.nsplit * G::NKG * (g.cout / 128) * (g.cin / C::CI_BIG);
+      hipLaunchKernelGGL((wgrad_tr16_kernel<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG, NS, F16, IO16>), dim3(grid), dim3(G::NT), 0, st, g);
       return tsr_check_launch();
     }
-  }
-  if (tr16_big(g.cout, g.cin, C::CI_BIG)) {
-    typedef WgradTGeom<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG, NS, F16> G;
-    const int grid = g.nsplit * G::NKG * (g.cout / 128) * (g.cin / C::CI_BIG);
-    hipLaunchKernelGGL((wgrad_tr16_kernel<KS, C::KHW_BIG, 128, C::CI_BIG, C::WM_BIG, NS, F16, false, IO16>), dim3(grid), dim3(G::NT), 0, st, g);
+    typedef WgradTGeom<KS, C::KHW_SMALL, 64, 64, 32, NS, F16> G;
+    const int grid = g.nsplit * G::NKG * (g.cout / 64) * (g.cin / 64);
+    hipLaunchKernelGGL((wgrad_tr16_kernel<KS, C::KHW_SMALL, 64, 64, 32, NS, F16, IO16>), dim3(grid), dim3(G::NT), 0, st, g);
     return tsr_check_launch();
   }
-  typedef WgradTGeom<KS, C::KHW_SMALL, 64, 64, 32, NS, F16> G;
-  const int grid = g.nsplit * G::NKG * (g.cout / 64) * (g.cin / 64);
-  hipLaunchKernelGGL((wgrad_tr16_kernel<KS, C::KHW_SMALL, 64, 64, 32, NS, F16, false, IO16>), dim3(grid), dim3(G::NT), 0, st, g);
-  return tsr_check_launch();
 }
 
 template <int KS> static int tr16_wgs(int cout, int cin, int planes) {
@@ -1013,7 +865,6 @@ template <int KS> static int tr16_wgs(int cout, int cin, int planes) {
 
 // workgroups one batch split of this layer launches (the caller sizes nsplit so that splits x this fills the chip)
 extern "C" int tsr_conv2d_wgrad_wgs_per_split(int cout, int cin, int ks, int planes) {
-  if (ks == 5 && planes == -2 && tr16_spec() && (cout % 128) == 0 && (cin % 64) == 0) return 5 * (cout / 128) * (cin / 64);
   return ks == 1 ? tr16_wgs<1>(cout, cin, planes) : (ks == 3 ? tr16_wgs<3>(cout, cin, planes) : tr16_wgs<5>(cout, cin, planes));
 }
 
@@ -1021,13 +872,8 @@ extern "C" int tsr_conv2d_wgrad_wgs_per_split(int cout, int cin, int ks, int pla
 // ones), never more than there are (image, patch) work items
 extern "C" int tsr_conv2d_wgrad_splits(int cout, int cin, int ks, int planes, int B, int H, int W) {
   const int wgs = tsr_conv2d_wgrad_wgs_per_split(cout, cin, ks, planes);
-#ifdef TSR_EXP_WG_5X5_2WG
-  const int ci_big = planes == 3 ? 64 : (ks == 1 ? 128 : 64);
-  const bool big = tr16_big(cout, cin, ci_big) && ks != 5;
-#else
   const int ci_big = planes == 3 ? 64 : (ks == 3 ? 64 : 128);
   const bool big = tr16_big(cout, cin, ci_big);
-#endif
   const long items = (long)B * ((H + 3) / 4) * ((W + 7) / 8);
   long ns = (big ? 256 : 512) / wgs;
   if (ns < 1) ns = 1;
@@ -1063,4 +909,27 @@ int tsr_conv2d_wgrad_tr16(const float* a, int a_ctot, int a_coff, int cin, const
   if (ks == 1) return launch_tr16<1, 2, true>(g, st);
   if (ks == 3) return launch_tr16<3, 2, true>(g, st);
   return launch_tr16<5, 2, true>(g, st);
+}
+
+// C-ABI entry of the 16-bit-MFMA weight gradient (every `planes` form lands in launch_tr16 above)
+extern "C" int tsr_conv2d_wgrad_bf16s(const float* a, int a_ctot, int a_coff, int cin,
+                                      const float* a_scale, const float* a_shift,
+                                      const float* dz, int dz_ctot, int dz_coff, int cout, int ks, int planes,
+                                      const float* a_amax, const float* dz_amax,
+                                      float* slab, float* bias_slab, int nsplit, int B, int H, int W, void* stream) {
+  // planes = 3: bf16 (fp32-equivalent, a_amax/dz_amax unused); planes = 1: plain bf16 operands (reduced
+  // precision, the "bf16" configurations); planes = -2: fp16 two-plane split with the
+  // power-of-two scales derived from the device scalars a_amax = max|a| (raw) and dz_amax = max|dz|
+  // planes = -1: plain bf16 operands read from bf16 CB16 TENSORS (`a`, `dz` address bf16 elements): training with bf16
+  // activation storage
+  if (!a || !dz || !slab || B <= 0 || H <= 0 || W <= 0 || nsplit <= 0 ||
+      (planes != 3 && planes != 1 && planes != -2 && planes != -1))
+    return TSR_ERR_ARG;
+  if (planes == -2 && (!a_amax || !dz_amax)) return TSR_ERR_ARG;
+  if ((cin & 63) || (cout & 63) || (a_ctot & 15) || (a_coff & 15) || (dz_ctot & 15) || (dz_coff & 15) ||
+      a_coff + cin > a_ctot || dz_coff + cout > dz_ctot || (ks != 1 && ks != 3 && ks != 5))
+    return TSR_ERR_ARG;
+  if ((a_scale != nullptr) != (a_shift != nullptr)) return TSR_ERR_ARG;
+  return tsr_conv2d_wgrad_tr16(a, a_ctot, a_coff, cin, a_scale, a_shift, dz, dz_ctot, dz_coff, cout, ks, planes, a_amax,
+                               dz_amax, slab, bias_slab, nsplit, B, H, W, (hipStream_t)stream);
 }

@@ -22,6 +22,7 @@ decides how early the first byte leaves, not the step time.
 """
 from __future__ import annotations
 
+import weakref
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -110,6 +111,16 @@ class GradArena:
         return self.flat[a:b]
 
 
+def note_forward(owner, token) -> None:
+    """An autograd forward of engine ``owner`` that WILL be differentiated registers its context object here (weakly:
+    a graph that is dropped without a backward un-registers itself).  ``GradSink`` reads the set to find out whether
+    the backward it serves is the only outstanding application of the engine -- see its ``shared`` case."""
+    live = getattr(owner, "_live_forwards", None)
+    if live is None:
+        live = owner._live_forwards = weakref.WeakSet()
+    live.add(token)
+
+
 class GradSink:
     """What a backward engine writes its parameter gradients through (one per backward call).
 
@@ -120,21 +131,38 @@ class GradSink:
       first   -- no arena yet: gradients land in fresh tensors while the order is recorded; ``finalize`` builds the
                  arena in that order, moves them in and binds the GradSync (buckets are reduced in ``finish``);
       accum   -- some .grad is set (gradient accumulation, ``zero_grad(set_to_none=False)``): fresh tensors are
-                 returned so autograd can add them to the existing .grad; nothing is issued early.
+                 returned so autograd can add them to the existing .grad; nothing is issued early;
+      shared  -- the engine was applied MORE THAN ONCE inside the graph being differentiated (``f(m(a)) + f(m(b))``, a
+                 shared block called twice): autograd sums the per-application gradients only AFTER all of them have
+                 run, so none of them may own the arena slots (the second would overwrite the first's views before the
+                 sum).  ``token`` is the context object the forward registered with ``note_forward``; a backward whose
+                 token is not the only live one -- and every later backward of that graph, down to the one that finds
+                 itself alone again -- returns fresh tensors like ``accum``; ``GradSync.finish`` then reduces the summed
+                 ``.grad`` tensors.
     """
 
-    def __init__(self, owner, named_params: Dict[str, torch.nn.Parameter], device):
+    def __init__(self, owner, named_params: Dict[str, torch.nn.Parameter], device, token=None):
         self.owner, self.device = owner, device
         arena = getattr(owner, "arena", None)
         if arena is not None and any(n not in named_params or named_params[n].shape != arena.shapes[n]
                                      for n in arena.names):
             arena = owner.arena = None                                   # the module tree changed: lay out again
-        self.first = arena is None
-        self.direct = arena is not None and all(p.grad is None for p in named_params.values())
+        live = getattr(owner, "_live_forwards", None)
+        alone = True
+        if live is not None:
+            alone = not any(t is not token for t in live)
+            if token is not None:
+                live.discard(token)
+        self.shared = bool(getattr(owner, "_shared_graph", False)) or not alone
+        owner._shared_graph = self.shared and not alone                  # the graph's last backward clears the mark
+        self.first = arena is None and not self.shared
+        self.direct = (arena is not None and not self.shared
+                       and all(p.grad is None for p in named_params.values()))
         self.arena = arena if self.direct else None
         sync = getattr(owner, "grad_sync", None)
         if sync is not None:
-            sync.backward_started("first" if self.first else ("direct" if self.direct else "accum"), device)
+            sync.backward_started("first" if self.first else ("direct" if self.direct else
+                                                              ("shared" if self.shared else "accum")), device)
         if self.direct:
             arena.begin()
         self.out: Dict[str, torch.Tensor] = {}
@@ -282,10 +310,24 @@ class GradSync:
         """grad <- mean over ranks.  Call between backward() and optimizer.step().  Buckets that were not issued
         from inside backward (first step: the arena is built at its end; gradients accumulated over micro-batches
         under no_sync(); gradients accumulated into foreign tensors) are reduced here."""
-        if self.world == 1 or self.arena is None:
+        if self.world == 1:
             return
         if self._defer:
             raise RuntimeError("GradSync.finish() inside no_sync(): leave the context before the last micro-batch")
+        if self.arena is None:
+            # no backward has laid the arena out yet (every one so far served a graph that applies the engine more than
+            # once): reduce the gradient tensors autograd summed, as one flat buffer
+            gs = [p.grad for p in self.module.parameters() if p.requires_grad and p.grad is not None]
+            if gs:
+                flat = torch.cat([g.reshape(-1) for g in gs])
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                flat.div_(self.world)
+                off = 0
+                for g in gs:
+                    g.copy_(flat[off:off + g.numel()].view_as(g))
+                    off += g.numel()
+            self.events.append(("finish_flat", len(gs)))
+            return
         import time
         arena = self.arena
         named = dict(self.module.named_parameters())

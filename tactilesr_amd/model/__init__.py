@@ -1,1 +1,1 @@
-from .tactileSR_model import TactileSR, MSRB, ResBlock  # noqa: F401
+from .tactileSR_model import TactileSR, TactileSRCNN, MSRB, ResBlock  # noqa: F401

@@ -123,6 +123,9 @@ def _pack_dgrad(w, cout, cin, ks, ci0, nprime, nsplit=0, w_amax=None):
     return wp
 
 
+TRAIN_IMPLS = {"f32": 0, "bf16x6": 3, "fp16x3": -2, "bf16": -1, "bf16op": 1}
+
+
 class _Ctx:
     """Everything backward needs (device buffers stay alive through this object)."""
 
@@ -130,7 +133,7 @@ class _Ctx:
 class TrainEngine:
     """Runs one train-mode forward / backward of a ``TactileSR`` module."""
 
-    def __init__(self, model):
+    def __init__(self, model, impl: str = "fp16x3"):
         self.m = model
         self.debug = None        # tools may set a dict: backward then stores clones of dz tensors in it
         self.keep_ctx = False    # tests: keep the last forward's context alive in `last_ctx` (activation_masks)
@@ -142,14 +145,17 @@ class TrainEngine:
         self.grad_sync = None
         self.n_buckets = 8
         self.profile = None      # bench.py: dict -> HIP-event brackets per launch family, on the launch stream
-        import os
-        # conv arithmetic of the train path: 0 = fp32 MFMA, 3 = split-bf16 (six products, fp32-equivalent),
+        # conv arithmetic of the train path (chosen EXPLICITLY: `TactileSR(train_impl=...)` / `model.train_impl = ...`;
+        # no environment variable changes it): 0 = fp32 MFMA, 3 = split-bf16 (six products, fp32-equivalent),
         # -2 = two scaled fp16 planes (three products; operand scales from device-side max|.| scalars),
         # -1 = "bf16": BASELINE's "bf16" configurations -- every stored activation / gradient tensor is bf16 CB16 (saved
         #      pre-activations z, dz, dgrad outputs), plain bf16 MFMA operands, fp32 accumulation, fp32 master weights,
         #      BatchNorm statistics, weight gradients and Adam (the reference's reduced-precision switch is the unused
         #      fp16 autocast of cpu/trainer.py:96,203,346-362); 1 = "bf16op": bf16 operands on fp32 tensors (A/B only)
-        self.nsplit = {"f32": 0, "bf16x6": 3, "fp16x3": -2, "bf16": -1, "bf16op": 1}[os.environ.get("TSR_TRAIN_IMPL", "fp16x3")]
+        if impl not in TRAIN_IMPLS:
+            raise _lib.TactileSRHipError(f"train_impl {impl!r}: expected one of {sorted(TRAIN_IMPLS)}")
+        self.impl = impl
+        self.nsplit = TRAIN_IMPLS[impl]
         self.f16 = self.nsplit == -2
         self.io16 = self.nsplit == -1
         self.act_dtype = torch.bfloat16 if self.io16 else torch.float32
@@ -572,7 +578,7 @@ class TrainEngine:
         dev = dout.device
         B, H, W, HW = c.B, c.H, c.W, c.HW
         from ..ddp import GradSink
-        grads = GradSink(self, dict(m.named_parameters()), dev)
+        grads = GradSink(self, dict(m.named_parameters()), dev, token=c)
 
         def buf(ch):
             return torch.empty(B * ch * HW, dtype=self.act_dtype, device=dev)
@@ -670,6 +676,9 @@ class TactileSRTrainFn(torch.autograd.Function):
     def forward(ctx, engine: TrainEngine, names, x, *params):
         out, c = engine.forward(x)
         ctx.engine, ctx.c, ctx.names = engine, c, names
+        if any(ctx.needs_input_grad):
+            from ..ddp import note_forward
+            note_forward(engine, c)          # the arena is handed out only to the sole outstanding application
         return out
 
     @staticmethod
@@ -688,8 +697,8 @@ class BlockEngine(TrainEngine):
     whole-network engine, with NCHW <-> CB16 conversion at the boundary and the gradient w.r.t. the block input
     returned unmasked."""
 
-    def __init__(self, block, kind: str):
-        super().__init__(None)
+    def __init__(self, block, kind: str, impl: str = "fp16x3"):
+        super().__init__(None, impl)
         assert kind in ("msrb", "res")
         self.block, self.kind = block, kind
 
@@ -737,7 +746,7 @@ class BlockEngine(TrainEngine):
         from .tactileSR_model import to_cb16, from_cb16
         dev = dout.device
         B, H, W = c.B, c.H, c.W
-        grads = GradSink(self, dict(self.block.named_parameters()), dev)
+        grads = GradSink(self, dict(self.block.named_parameters()), dev, token=c)
         new_amax = self._amax_pool(c, dev)
 
         def buf(ch):
@@ -764,6 +773,9 @@ class BlockTrainFn(torch.autograd.Function):
     def forward(ctx, engine: BlockEngine, names, x, *params):
         out, c = engine.forward(x)
         ctx.engine, ctx.c, ctx.names = engine, c, names
+        if any(ctx.needs_input_grad):
+            from ..ddp import note_forward
+            note_forward(engine, c)
         return out
 
     @staticmethod

@@ -55,8 +55,9 @@ class _TPSFFn(torch.autograd.Function):
         LRd = torch.empty(B, 1, 4, 4, dtype=torch.float32, device=x.device)
         psf = torch.empty(B, 1, 99, 99, dtype=torch.float32, device=x.device)
         call("tpsf_forward", ptr(d), ptr(ab), ptr(HR), ptr(LRd), ptr(psf), _I(B), stream())
-        ctx.h, ctx.d, ctx.params, ctx.HR = h, d, params, HR       # HR: the backward's reductions read the stored output
-        ctx.mark_non_differentiable(HR, psf)
+        ctx.h, ctx.d, ctx.params = h, d, params
+        ctx.save_for_backward(HR)          # the backward's reductions read the stored output: an in-place edit of the
+        ctx.mark_non_differentiable(HR, psf)      # returned HR before backward() trips autograd's version check
         return HR, LRd, psf, ab.view(B, 1, 3).clone()
 
     @staticmethod
@@ -67,7 +68,7 @@ class _TPSFFn(torch.autograd.Function):
         dab = torch.zeros(B, 3, dtype=torch.float32, device=d.device)
         if gLR is not None:
             work = torch.empty(B * 10000, dtype=torch.float32, device=d.device)
-            call("tpsf_backward", ptr(d), ptr(h[-1]), ptr(ctx.HR), ptr(gLR.contiguous().float()), ptr(dab), ptr(work),
+            call("tpsf_backward", ptr(d), ptr(h[-1]), ptr(ctx.saved_tensors[0]), ptr(gLR.contiguous().float()), ptr(dab), ptr(work),
                  _I(B), stream())
         if gab is not None:
             dab = dab + gab.reshape(B, 3)

@@ -47,9 +47,13 @@ class _StandaloneBlock(nn.Module):
     _profile = None
 
     def _standalone_init(self):
-        import os
-        self.conv_impl = os.environ.get("TSR_CONV_IMPL", "fp16x3")
+        # arithmetic of the eval / train launches: attributes, set explicitly (no environment variable changes them)
+        self.conv_impl = "fp16x3"
+        self.train_impl = "fp16x3"
         self._plan = self._plan_key = self._block_engine = None
+
+    def extra_repr(self):
+        return f"arithmetic: eval conv_impl={self.conv_impl!r}, train_impl={self.train_impl!r}"
 
     def _param_key(self):
         return (self.conv_impl, _lib.param_epoch()) + tuple((t.data_ptr(), t._version)
@@ -62,9 +66,16 @@ class _StandaloneBlock(nn.Module):
         return self._plan
 
     def block_engine(self):
-        if self._block_engine is None:
+        if self.train_impl not in ("fp16x3", "bf16x6", "f32"):
+            # the bf16-storage step is only pinned for the whole network (against the bf16-emulating oracle)
+            raise _lib.TactileSRHipError(f"standalone {type(self).__name__}: train_impl {self.train_impl!r} is not "
+                                         "available (fp16x3, bf16x6, f32)")
+        if self._block_engine is None or self._block_engine.impl != self.train_impl:
             from ._train import BlockEngine
-            self._block_engine = BlockEngine(self, self._kind)
+            old = self._block_engine
+            self._block_engine = BlockEngine(self, self._kind, self.train_impl)
+            if old is not None:
+                self._block_engine.keep_ctx, self._block_engine.grad_sync = old.keep_ctx, old.grad_sync
         return self._block_engine
 
     def forward(self, x):
@@ -114,15 +125,22 @@ class MSRB(_StandaloneBlock):
                 _PackedConv(self.confusion, None, ns), None)
 
     def _eval_forward(self, x):
-        c31, c51, c32, c52, conf, halves = self._get_plan()
         B, _, H, W = x.shape
-        dev = x.device
         f16 = CONV_IMPLS[self.conv_impl] == -2
-        am = torch.zeros(4, dtype=torch.float32, device=dev) if f16 else None
-        s_x, s_c1, s_c2, s_o = (am[i:i + 1] for i in range(4)) if f16 else (None,) * 4
+        am = torch.zeros(2, dtype=torch.float32, device=x.device) if f16 else None
+        s_x, s_o = (am[0:1], am[1:2]) if f16 else (None, None)
         if f16:
             s_x.copy_(x.abs().amax())
-        xa = to_cb16(x)
+        return from_cb16(self._eval_cb16(to_cb16(x), B, H, W, s_x, s_o), B, 64, H, W)
+
+    def _eval_cb16(self, xa, B, H, W, s_x, s_o):
+        """The block on a CB16 fp32 buffer (B, 64, H, W) -> a new CB16 buffer; ``s_x`` / ``s_o``: the device scalars
+        holding max|input| / receiving max|output| (fp16x3 operand scales; None for the other arithmetic modes)."""
+        c31, c51, c32, c52, conf, halves = self._get_plan()
+        dev = xa.device
+        f16 = CONV_IMPLS[self.conv_impl] == -2
+        am = torch.zeros(2, dtype=torch.float32, device=dev) if f16 else None
+        s_c1, s_c2 = (am[0:1], am[1:2]) if f16 else (None, None)
         cat1 = torch.empty(B * 128 * H * W, dtype=torch.float32, device=dev)
         out = torch.empty(B * 64 * H * W, dtype=torch.float32, device=dev)
         if halves is not None:
@@ -138,7 +156,7 @@ class MSRB(_StandaloneBlock):
             TactileSR._conv(self, c52, cat1, 128, 0, cat2, 256, 128, True, B, H, W, amax_in=s_c1, amax_out=s_c2)
             TactileSR._conv(self, conf, cat2, 256, 0, out, 64, 0, True, B, H, W, res=xa, r_ctot=64, r_coff=0,
                             amax_in=s_c2, amax_out=s_o)
-        return from_cb16(out, B, 64, H, W)
+        return out
 
 
 class ResBlock(_StandaloneBlock):
@@ -286,7 +304,7 @@ class TactileSR(nn.Module):
     """
 
     def __init__(self, scale_factor=10, seqsCnt=1, axisCnt=3, patternFeatureExtraLayerCnt=6,
-                 forceFeatureExtraLayerCnt=1):
+                 forceFeatureExtraLayerCnt=1, *, conv_impl: str = "fp16x3", train_impl: str = "fp16x3"):
         super().__init__()
         self.taxel_cnt = 4
         self.scale_factor = scale_factor
@@ -322,16 +340,22 @@ class TactileSR(nn.Module):
         #   "bf16x3"           reduced precision (never the parity path)
         #   "bf16"             BASELINE's "bf16" configurations: bf16 ACTIVATION STORAGE in HBM + plain bf16 MFMA operands,
         #                      fp32 accumulate (tolerance 2e-2; never the parity path)
-        import os
-        self.conv_impl = os.environ.get("TSR_CONV_IMPL", "fp16x3")
-        assert self.conv_impl in CONV_IMPLS, self.conv_impl
+        # The arithmetic is chosen EXPLICITLY -- the two keyword-only constructor arguments above or these attributes --
+        # and printed by repr(model); no environment variable changes it (a stray TSR_* variable on a user's box must not
+        # silently change precision).  The defaults are the parity paths.
+        if conv_impl not in CONV_IMPLS:
+            raise _lib.TactileSRHipError(f"conv_impl {conv_impl!r}: expected one of {sorted(CONV_IMPLS)}")
+        self.conv_impl = conv_impl
+        # train-step arithmetic (model/_train.py): "fp16x3" (default, fp32-grade), "bf16x6", "f32", "bf16" = bf16 activation /
+        # gradient STORAGE + bf16 MFMA operands (BASELINE's "bf16" configurations; reduced precision), "bf16op"
+        self.train_impl = train_impl
         # arithmetic of output_layer.0 (the 128->128 conv in front of the cancellation-heavy 128->1 head); None = conv_impl
-        self.head_impl = os.environ.get("TSR_HEAD_IMPL") or None
+        self.head_impl = None
         # fp16x3 eval: apply each half of an MSRB's 1x1 `confusion` inside the stage-2 conv that produced its input
-        # (csrc/conv_fuse1x1.h): `cat2` never exists in HBM.  TSR_FUSE1X1=0 keeps the separate 1x1 launches (A/B).
-        self.fuse_1x1 = os.environ.get("TSR_FUSE1X1", "1") != "0"
-        # eval, fp16x3: the two stage-1 convs of an MSRB as one launch on one staged halo (TSR_FUSE_PAIR=0: two launches)
-        self.fuse_pair = os.environ.get("TSR_FUSE_PAIR", "1") != "0"
+        # (csrc/conv_fuse1x1.h): `cat2` never exists in HBM.  False keeps the separate 1x1 launches (same arithmetic).
+        self.fuse_1x1 = True
+        # eval, fp16x3: the two stage-1 convs of an MSRB as one launch on one staged halo (False: two launches)
+        self.fuse_pair = True
         self.max_images_per_pass = 4096   # workspace bound: ~6.6 MB of CB16 activations per image
 
     def make_layer(self, block, num_of_layer):
@@ -614,11 +638,27 @@ class TactileSR(nn.Module):
         return out
 
     def train_engine(self):
-        """The module's HIP training engine (created on first use)."""
-        if self._train_engine is None:
+        """The module's HIP training engine for the current ``train_impl`` (created on first use; a changed
+        ``train_impl`` gets a fresh engine that inherits the gradient arena / GradSync wiring -- a forward already
+        recorded by autograd keeps the engine it ran on)."""
+        eng = self._train_engine
+        if eng is None or eng.impl != self.train_impl:
             from ._train import TrainEngine
-            self._train_engine = TrainEngine(self)
+            new = TrainEngine(self, self.train_impl)
+            if eng is not None:
+                new.keep_ctx, new.profile, new.n_buckets = eng.keep_ctx, eng.profile, eng.n_buckets
+                new.arena, new.grad_sync = eng.arena, eng.grad_sync
+            self._train_engine = new
         return self._train_engine
+
+    def extra_repr(self):
+        """First line of repr(model): the ACTIVE arithmetic of both modes."""
+        grade = {"fp16x3": "fp32-grade: 2 scaled fp16 planes x 3 MFMA products", "bf16x6": "fp32-equivalent: 3 bf16 planes x 6",
+                 "f32": "strict fp32 MFMA", "bf16": "REDUCED precision: bf16 storage + operands", "bf16x3": "REDUCED precision",
+                 "bf16op": "REDUCED precision: bf16 operands"}
+        head = f", head_impl={self.head_impl!r}" if self.head_impl else ""
+        return (f"arithmetic: eval conv_impl={self.conv_impl!r} ({grade.get(self.conv_impl, '?')}){head}, "
+                f"train_impl={self.train_impl!r} ({grade.get(self.train_impl, '?')}); fp32 accumulate everywhere")
 
     @torch.no_grad()
     def forward_with_stages(self, x):
@@ -643,6 +683,80 @@ class TactileSR(nn.Module):
             c = 64 if name != "head0" else 128
             stages[name] = _to_nchw(t, B, c, H * W, ctot, coff).view(B, c, H, W)
         return out, stages
+
+
+class TactileSRCNN(nn.Module):
+    """``TactileSRCNN`` of the reference (model/tactileSR_model.py:101-153): bilinear x10 -> three conv3x3+BN+ReLU
+    (3->64, 64->64, 64->64) -> six MSRBs -> conv 64->1 + ReLU.  Both reference trainers import the name
+    (train/tactileSR_train.py:24, train/tactileSRSeqs_train.py:24) and none instantiates it; it is exported so that
+    import line works verbatim.  Same constructor (no arguments), submodule names, ``state_dict`` keys and seeded init.
+    EVAL forward only, composed from the hot path's kernels (stem kernel, K = 32 conv, the MSRB launches, head kernel);
+    train mode raises: the class is not on the path the trainers run."""
+
+    def __init__(self):
+        super().__init__()
+        self.msrb_layer = nn.Sequential(*[MSRB() for _ in range(6)])
+        self.input_zyx = nn.Sequential(
+            nn.Conv2d(3, 64, 3, stride=1, padding=1, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+            nn.Conv2d(64, 64, 3, stride=1, padding=1, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+            nn.Conv2d(64, 64, 3, stride=1, padding=1, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True))
+        self.upSample = nn.Upsample(scale_factor=10, mode="bilinear", align_corners=False)
+        self.output = nn.Sequential(nn.Conv2d(64, 1, 3, stride=1, padding=1, bias=False), nn.ReLU(inplace=True))
+        _reference_init(self)
+        self.conv_impl = "fp16x3"            # explicit attribute, like TactileSR's (fp16x3 | bf16x6 | f32)
+        self._profile = None
+        self._plan = self._plan_key = None
+
+    def extra_repr(self):
+        return f"arithmetic: eval conv_impl={self.conv_impl!r} (train mode not available)"
+
+    def _get_plan(self):
+        key = (self.conv_impl, _lib.param_epoch()) + tuple((t.data_ptr(), t._version) for t in
+                                                           list(self.input_zyx.parameters()) + list(self.input_zyx.buffers())
+                                                           + list(self.output.parameters()))
+        if self._plan is None or key != self._plan_key:
+            ns = CONV_IMPLS[self.conv_impl]
+            z = self.input_zyx
+            s1, sh1 = _fold(None, z[1], 64, z[0].weight.device)
+            self._plan = (z[0].weight.detach().float().contiguous(), s1, sh1, _PackedConv(z[3], z[4], ns),
+                          _PackedConv(z[6], z[7], ns), self.output[0].weight.detach().float().contiguous())
+            self._plan_key = key
+        return self._plan
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise _lib.TactileSRHipError("TactileSRCNN (tactilesr_amd) runs on MI355X only (no CPU fallback)")
+        if self.training:
+            raise _lib.TactileSRHipError(
+                "TactileSRCNN: train mode is not on the MI355X path -- the reference's trainers import this class "
+                "(train/tactileSR_train.py:24) but never instantiate it; only the eval forward is provided "
+                "(call .eval()), TactileSR is the trainable model")
+        if self.conv_impl not in ("fp16x3", "bf16x6", "f32"):
+            raise _lib.TactileSRHipError(f"TactileSRCNN: conv_impl {self.conv_impl!r} is not available (fp16x3, bf16x6, f32)")
+        assert x.dim() == 4 and x.shape[1] == 3, "TactileSRCNN takes (B, 3, h, w) taxel frames"
+        x = x.detach().float().contiguous()
+        with torch.no_grad():
+            w1, s1, sh1, pc2, pc3, wh = self._get_plan()
+            B, _, hin, win = x.shape
+            H, W = hin * 10, win * 10
+            dev = x.device
+            f16 = CONV_IMPLS[self.conv_impl] == -2
+            am = torch.zeros(4 + len(self.msrb_layer), dtype=torch.float32, device=dev) if f16 else None
+            sl = [am[i:i + 1] for i in range(am.numel())] if f16 else [None] * (4 + len(self.msrb_layer))
+            a, b = (torch.empty(B * 64 * H * W, dtype=torch.float32, device=dev) for _ in range(2))
+            call("tsr_stem_fwd", ptr(x), _I(3), _I(0), _I(3), _I(hin), _I(win), _I(10), ptr(w1), ptr(s1), ptr(sh1), ptr(a),
+                 _I(64), _I(0), _I(1), _I(B), ptr(sl[0]), stream())
+            TactileSR._conv(self, pc2, a, 64, 0, b, 64, 0, True, B, H, W, amax_in=sl[0], amax_out=sl[1])
+            TactileSR._conv(self, pc3, b, 64, 0, a, 64, 0, True, B, H, W, amax_in=sl[1], amax_out=sl[2])
+            cur, s_cur = a, sl[2]
+            del b
+            for i, blk in enumerate(self.msrb_layer):
+                blk.conv_impl = self.conv_impl
+                cur = blk._eval_cb16(cur, B, H, W, s_cur, sl[3 + i])
+                s_cur = sl[3 + i]
+            out = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
+            call("tsr_head_fwd", ptr(cur), _I(64), _I(64), ptr(wh), ptr(out), _I(1), _I(B), _I(H), _I(W), stream())
+            return out
 
 
 def _to_nchw(t, B, C, HW, ctot, coff):

@@ -33,7 +33,7 @@ class Adam(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._tables = {}           # key -> (device table, n_chunks, the tensors the table points into)
+        self._tables = {}           # key (every address the table holds) -> (device table, n_chunks)
         self.launches = 0           # kernel launches issued so far (tests: one per step)
         self.table_builds = 0       # device tables built so far (steady state with the gradient arena: exactly one)
 
@@ -42,7 +42,7 @@ class Adam(torch.optim.Optimizer):
                     for p, g, st in items)
         hit = self._tables.get(key)
         if hit is not None:
-            return hit[:2]
+            return hit
         recs = []
         for p, g, st in items:
             n = p.numel()
@@ -55,12 +55,13 @@ class Adam(torch.optim.Optimizer):
         dev = host.to(items[0][0].device)
         if len(self._tables) > 8:
             self._tables.clear()
-        # the cached table holds raw device addresses: keep every tensor it points into alive with it, so that an address
-        # in the key can never be recycled for another tensor while the entry exists
-        keep = [t for p, g, st in items for t in (p, g, st["exp_avg"], st["exp_avg_sq"])]
-        self._tables[key] = (dev, len(recs), keep)
+        # The key IS the table: every address a record holds (param, grad, exp_avg, exp_avg_sq of every tensor) is part
+        # of it, so a hit is valid whatever lived at those addresses in between -- no tensor has to be kept alive for
+        # it (holding the gradients here pinned up to nine stale gradient sets of a model whose gradients are fresh
+        # autograd tensors every step).
+        self._tables[key] = (dev, len(recs))
         self.table_builds += 1
-        return self._tables[key][:2]
+        return self._tables[key]
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -10,6 +10,7 @@ sha256 of their bytes is stored to detect drift.
 
     PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
 """
+import copy
 import hashlib
 import os
 import sys
@@ -343,6 +344,40 @@ def gen_lr():
     np.savez_compressed(os.path.join(HERE, "lr_schedule.npz"), **out)
 
 
+def gen_srcnn():
+    """TactileSRCNN (model/tactileSR_model.py:101-153; imported at train/tactileSR_train.py:24, instantiated nowhere):
+    the seeded construction (state_dict hash: init RNG order) and an eval forward with randomised parameters."""
+    from model.tactileSR_model import TactileSRCNN
+    out = {}
+    torch.manual_seed(42)
+    m = TactileSRCNN()
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(O.tactilesrcnn_state_shapes().keys()), "state_dict key order mismatch"
+    out["init_sha"] = np.frombuffer(bytes.fromhex(sd_hash(sd)), dtype=np.uint8)
+    rs = O.random_state_dict(O.tactilesrcnn_state_shapes(), 909)
+    m.load_state_dict(rs, strict=True)
+    m.eval()
+    g = torch.Generator().manual_seed(910)
+    x = torch.rand(2, 3, 4, 4, generator=g) * 8
+    with torch.no_grad():
+        y = m(x)
+        y64 = copy.deepcopy(m).double()(x.double())
+    out.update(seed=np.int64(909), x=x.numpy(), y=y.numpy(), y64=y64.numpy())
+    np.savez_compressed(os.path.join(HERE, "srcnn.npz"), **out)
+
+
+def gen_lr_short():
+    """A SHORT schedule of the reference's own LRWarmupScheduler for the -m gpu trainer-loop test (the shipped one needs
+    2000 iterations before StepLR shows): 'auto' warm-up over 8 iterations in front of StepLR(1, 0.8), epoch_len = 6,
+    3 epochs; one value after every iter_update / epoch_update, like gen_lr."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_lr", "/root/reference/cpu/lr_scheduler.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    np.savez_compressed(os.path.join(HERE, "lr_schedule_short.npz"),
+                        short_auto=lr_sequence(ref.LRWarmupScheduler, dict(LR_SHORT), 3, 6))
+
+
 def gen_config():
     """Keys and values of the reference's three config dicts (config/default.py:8-96).  The module cannot be imported
     (it shells out to nvidia-smi at import, :101-104), so its dict literals are evaluated from the file's text up to
@@ -403,6 +438,10 @@ LR_CASES = {
 }
 
 
+LR_SHORT = dict(lr=1e-4, step=1, by_epoch=True, warmup_t=8, warmup_by_epoch=False, warmup_mode='auto',
+                warmup_init_lr=1e-5, warmup_factor=1e-2)
+
+
 def lr_sequence(cls, cfg, epochs, epoch_len):
     p = torch.nn.Parameter(torch.zeros(1))
     opt = torch.optim.Adam([p], lr=cfg.pop('lr'))
@@ -420,7 +459,7 @@ def lr_sequence(cls, cfg, epochs, epoch_len):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["init", "eval", "train", "tpsf", "metrics", "lr", "lr_state", "config"]
+    which = sys.argv[1:] or ["init", "eval", "train", "tpsf", "metrics", "lr", "lr_short", "lr_state", "config", "srcnn"]
     for w in which:
         globals()["gen_" + w]()
         print("wrote", w)

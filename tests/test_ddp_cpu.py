@@ -30,10 +30,10 @@ class _ToyEngine:
         self.n_buckets = 3
         self.log = []                # ("backward_end",) markers, interleaved with the GradSync's events by the test
 
-    def backward(self, x, dy):
+    def backward(self, x, dy, token=None):
         from tactilesr_amd.ddp import GradSink
         named = dict(self.m.named_parameters())
-        sink = GradSink(self, named, x.device)
+        sink = GradSink(self, named, x.device, token=token)
         # y = (x @ W2^T + b2) summed with (x @ W1^T + b1): two independent linear layers, "layer 2" finishes first
         for name in ("l2", "l1"):
             lin = getattr(self.m, name)
@@ -48,16 +48,24 @@ class _ToyEngine:
         return out
 
 
+class _Token:
+    """Stands in for the engine's per-forward context object (weakly referenced by ddp.note_forward)."""
+
+
 class _ToyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, names, x, *params):
         m = engine.m
         ctx.engine, ctx.names, ctx.x = engine, names, x
+        ctx.token = _Token()
+        if any(ctx.needs_input_grad):
+            from tactilesr_amd.ddp import note_forward
+            note_forward(engine, ctx.token)            # like TactileSRTrainFn / BlockTrainFn do with their context
         return x @ m.l1.weight.t() + m.l1.bias + x @ m.l2.weight.t() + m.l2.bias + m.scale * 0
 
     @staticmethod
     def backward(ctx, dy):
-        g = ctx.engine.backward(ctx.x, dy.contiguous())
+        g = ctx.engine.backward(ctx.x, dy.contiguous(), ctx.token)
         return (None, None, None) + tuple(g[n] for n in ctx.names)
 
 
@@ -195,6 +203,26 @@ def _worker(rank, world, port, q):
     except RuntimeError as e:
         res["step5_raised"] = "no_sync" in str(e)
     sync.finish()                       # drain the collectives of micro-batch 1 on both ranks
+    # step 6: the engine applied TWICE inside one graph (f(m(a)) + f(m(b))): autograd sums the two applications'
+    # gradients only after both backward passes ran, so neither may write the arena slots; nothing leaves from inside
+    # backward, finish() reduces the summed gradients: mean over ranks of (g(a) + g(b))
+    for p in model.parameters():
+        p.grad = None
+    sync.events.clear()
+    (model(xs[0]).pow(2).mean() + model(xs[1]).pow(2).mean()).backward()
+    res["shared_events"] = [e for e in sync.events if e[0].startswith("enqueue")]
+    sync.finish()
+    got6 = torch.cat([named[n].grad.flatten() for n in sorted(want)])
+    res["step6_ok"] = bool(torch.allclose(got6, expect_mean(want), atol=1e-6))
+    # ... and the step after it is a plain direct step again
+    for p in model.parameters():
+        p.grad = None
+    sync.events.clear()
+    model(xs[0]).pow(2).mean().backward()
+    res["after_shared_events"] = [e for e in sync.events if e[0] == "enqueue"]
+    sync.finish()
+    got7 = torch.cat([named[n].grad.flatten() for n in sorted(want)])
+    res["step7_ok"] = bool(torch.allclose(got7, expect_mean(refs[0]), atol=1e-6))
     # broadcast_buffers=True (torch-DDP default): rank 0's BatchNorm statistics before every forward
     with torch.no_grad():
         model.bn.running_mean.fill_(10.0 + rank)
@@ -243,7 +271,61 @@ def test_gradsync_gloo_world2_overlapped_buckets_and_broadcast():
         # zero_grad; backward under no_sync; backward; finish == mean(g1 + g2), nothing on the wire during micro-batch 1
         assert r["step4_ok"] and r["nosync_events"] == []
         assert r["step5_raised"] is True
+        assert r["step6_ok"] and r["shared_events"] == [], r
+        assert r["step7_ok"] and r["after_shared_events"] == [("enqueue", 0), ("enqueue", 1), ("enqueue", 2)], r
         assert r["bb_off"] == (10.0 + r["rank"], 3 + r["rank"]) and r["bb_on"] == (10.0, 2.0, 3, 1)
+
+
+def test_engine_applied_twice_in_one_graph_sums_both_gradients():
+    """ADVICE r03 (ddp.py:133): with the arena built, `(f(m(x1)) + f(m(x2))).backward()` used to hand the SAME arena
+    slots to both backward passes -- the second overwrote the first's views before autograd summed them (l1.weight off by
+    ~1 max-abs).  Every application of a multiply-applied engine now returns fresh tensors; a graph dropped without a
+    backward does not leave the engine stuck in that mode; an un-differentiated forward (no_grad) does not count."""
+    torch.manual_seed(0)
+    m = _Toy()
+    g = torch.Generator().manual_seed(1)
+    x1, x2 = torch.randn(5, 40, generator=g), torch.randn(7, 40, generator=g)
+    names = ("l1.weight", "l1.bias", "l2.weight", "l2.bias")
+
+    def separate():
+        out = {}
+        for x in (x1, x2):
+            r = _Toy()
+            r.load_state_dict(m.state_dict())
+            r(x).pow(2).mean().backward()
+            for n, p in r.named_parameters():
+                if n in names:
+                    out[n] = out.get(n, 0) + p.grad
+        return out
+    want = separate()
+    named = dict(m.named_parameters())
+    for attempt in range(2):                             # no arena yet: a shared graph never lays it out
+        for p in m.parameters():
+            p.grad = None
+        (m(x1).pow(2).mean() + m(x2).pow(2).mean()).backward()
+        for n in names:
+            assert torch.allclose(named[n].grad, want[n], atol=1e-6), (attempt, n)
+        assert m.train_engine().arena is None
+    # a plain step builds the arena; then the shared graph again, now WITH an arena to (not) overwrite
+    for p in m.parameters():
+        p.grad = None
+    m(x1).pow(2).mean().backward()
+    arena = m.train_engine().arena
+    assert arena is not None
+    for p in m.parameters():
+        p.grad = None
+    (m(x1).pow(2).mean() + m(x2).pow(2).mean()).backward()
+    for n in names:
+        assert torch.allclose(named[n].grad, want[n], atol=1e-6), n
+    # a forward whose graph is dropped, and one under no_grad, leave nothing behind: the next step is direct again
+    y = m(x2)
+    del y
+    with torch.no_grad():
+        m(x2)
+    for p in m.parameters():
+        p.grad = None
+    m(x1).pow(2).mean().backward()
+    assert all(named[n].grad.data_ptr() == arena.flat.data_ptr() + 4 * arena.offsets[n] for n in arena.names)
 
 
 def test_shard_batch_covers_everything():

@@ -144,6 +144,70 @@ def test_standalone_block_train_forward_backward(kind, B, H, W):
     _block_train_check(kind, B, H, W, 31)
 
 
+@pytest.mark.parametrize("form", ["sum", "chain"])
+def test_shared_resblock_applied_twice_in_one_graph(form):
+    """ADVICE r03 (ddp.py:133) on the real engine: ONE ResBlock instance applied twice inside a single autograd graph --
+    `f(blk(a)) + f(blk(b))` and the weight-shared chain `blk(blk(x))`.  Once the block engine's gradient arena exists both
+    backward passes used to be handed the same arena slots (the second overwrote the first's gradient before autograd
+    summed them).  Checked against torch autograd on the CPU oracle in fp64 with the shared parameters, each application
+    on the ReLU pattern the device took for it: input gradients and every parameter gradient within 2e-5."""
+    import tactilesr_amd
+    from tactilesr_amd.model.tactileSR_model import from_cb16
+    torch.manual_seed(12)
+    blk = tactilesr_amd.ResBlock()
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    g = torch.Generator().manual_seed(13)
+    B, H, W = 2, 24, 16
+    xa, xb = torch.randn(B, 64, H, W, generator=g), torch.randn(B, 64, H, W, generator=g)
+    da, db = torch.randn(B, 64, H, W, generator=g), torch.randn(B, 64, H, W, generator=g)
+    blk = blk.cuda().train()
+    eng = blk.block_engine()
+    eng.keep_ctx = True
+    named = dict(blk.named_parameters())
+
+    def masks_of(c, y):
+        return {"b.conv1": from_cb16(c.s.F1.buf, B, 64, H, W).cpu() > 0, "b.out": y.detach().cpu() > 0}
+
+    def run():
+        for p in blk.parameters():
+            p.grad = None
+        a = xa.cuda().requires_grad_(True)
+        b = xb.cuda().requires_grad_(True)
+        y1 = blk(a)
+        c1 = eng.last_ctx
+        y2 = blk(b if form == "sum" else y1)
+        c2 = eng.last_ctx
+        loss = (y1 * da.cuda()).sum() + (y2 * db.cuda()).sum() if form == "sum" else (y2 * db.cuda()).sum()
+        loss.backward()
+        return a, b, y1, y2, masks_of(c1, y1), masks_of(c2, y2)
+
+    # step 1 builds nothing shared-safe by accident: run a PLAIN step first so that the arena exists, then the shared graph
+    (blk(xa.cuda()) * da.cuda()).sum().backward()
+    assert eng.arena is not None
+    a, b, y1, y2, m1, m2 = run()
+    p64 = {f"b.{k}": v.double().requires_grad_(True) for k, v in sd.items()}
+    a64, b64 = xa.double().requires_grad_(True), xb.double().requires_grad_(True)
+    r1 = O.resblock_forward(p64, "b", a64, tap=O.ReluTap(masks=m1))
+    r2 = O.resblock_forward(p64, "b", b64 if form == "sum" else r1, tap=O.ReluTap(masks=m2))
+    ref_loss = (r1 * da.double()).sum() + (r2 * db.double()).sum() if form == "sum" else (r2 * db.double()).sum()
+    leaves = list(p64.values())
+    ins = [a64, b64] if form == "sum" else [a64]
+    grads = torch.autograd.grad(ref_loss, ins + leaves)
+    assert relerr(y1, r1) < TOL and relerr(y2, r2) < TOL
+    assert relerr(a.grad, grads[0]) < 2e-5
+    if form == "sum":
+        assert relerr(b.grad, grads[1]) < 2e-5
+    for n, gr in zip(p64, grads[len(ins):]):
+        e = relerr(named[n[2:]].grad, gr)
+        assert e < 2e-5, (form, n, e)
+    # the step after a shared graph is a plain arena step again
+    for p in blk.parameters():
+        p.grad = None
+    (blk(xa.cuda()) * da.cuda()).sum().backward()
+    arena = eng.arena
+    assert all(named[n].grad.data_ptr() == arena.flat.data_ptr() + 4 * arena.offsets[n] for n in arena.names)
+
+
 def test_device_resident_loader_on_cuda_drives_the_trainer_step():
     """DeviceSRLoader(device="cuda"): two shuffled epochs of `train_one_iter` straight from device-resident tensors
     (no host batch, train/tactileSR_train.py:43 removed from the step), every sample seen once per epoch, the loss

@@ -1,8 +1,9 @@
 """Two data-parallel ranks of the REAL HIP engine on one MI355X (two processes sharing the card, gloo backend -- it
 moves CUDA tensors through the host; RCCL cannot put two ranks on one device and the pool leases one GPU).  What it
 pins: the gradient arena + in-backward bucket all-reduce of tactilesr_amd.ddp on the engine's own backward, across real
-process boundaries: synced gradient = mean of the per-rank gradients (rank-local BatchNorm statistics, SURVEY.md
-section 5), every bucket enqueued before backward returns from the second step on, identical weights on both ranks after
+process boundaries: synced gradient = mean over ranks of the per-shard fp64 ORACLE gradients (each rank's shard, its
+own BatchNorm batch statistics, the device's ReLU pattern: SURVEY.md section 5), max-norm 1e-5 on every parameter;
+every bucket enqueued before backward returns from the second step on, identical weights on both ranks after
 the fused Adam step, parameter AND buffer broadcast at start."""
 import os
 import socket
@@ -36,14 +37,35 @@ def _worker(rank, world, port, q):
     LR, HR = torch.rand(6, 3, 4, 4, generator=g) * 8, torch.rand(6, 1, 40, 40, generator=g) * 25
     a, b = ddp.shard_batch(6, rank, world)
     x, y = LR[a:b].cuda(), HR[a:b].cuda()
-    # this rank's un-synced gradient on its shard (fresh replica, same weights)
+    # What the synced gradient must equal: the MEAN over ranks of the CPU oracle's gradient on each
+    # rank's own shard -- fp64, train-mode BatchNorm on that shard's batch statistics (rank-local BN), evaluated on the
+    # ReLU pattern this rank's device forward took (tests/_gradcheck.py).  A fresh replica with the same weights gives
+    # the pattern; its pattern must itself agree with the fp64 oracle's up to rounding-zero flips.
+    import _gradcheck as GC
     ref = tactilesr_amd.TactileSR(**cfg).cuda().train()
     ref.load_state_dict(sd0)
-    F.mse_loss(ref(x), y).backward()
-    local = torch.cat([p.grad.flatten() for p in ref.parameters()])
+    eng = ref.train_engine()
+    eng.keep_ctx = True
+    ref_loss = F.mse_loss(ref(x), y)
+    ref_loss.backward()
+    masks = {k: v.cpu() for k, v in eng.activation_masks(eng.last_ctx).items()}
+    sd_cpu = {k: v.detach().cpu() for k, v in sd0.items()}
+    l64, _, _, pre64 = GC.oracle_grads(sd_cpu, LR[a:b], HR[a:b], record=True)
+    flips = GC.check_pattern(masks, pre64)
+    _, g64m, _, _ = GC.oracle_grads(sd_cpu, LR[a:b], HR[a:b], masks=masks)
+    names = [k for k, _ in m.named_parameters()]
+    assert set(names) == set(g64m)
+    local = torch.cat([g64m[k].flatten() for k in names])                 # fp64, CPU: gloo moves it as is
     gathered = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
-    expect = sum(gathered) / world
+    expect = {}
+    off = 0
+    mean = sum(gathered) / world
+    for k in names:
+        n = g64m[k].numel()
+        expect[k] = mean[off:off + n].view_as(g64m[k])
+        off += n
+    loss_ok = abs(float(ref_loss) - l64) < 1e-5 * abs(l64)
     opt = optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-2)
     res = {"rank": rank, "bn_mean": float(next(iter(sd0[k] for k in sd0 if k.endswith("running_mean")))[0]),
            "w0": float(torch.cat([v.flatten().double() for k, v in sd0.items() if v.is_floating_point()]).sum())}
@@ -55,14 +77,18 @@ def _worker(rank, world, port, q):
         F.mse_loss(m(x), y).backward()
         events.append(list(sync.events))
         sync.finish()
-        got = torch.cat([p.grad.flatten() for p in m.parameters()])
-        ok.append(bool(torch.allclose(got, expect, rtol=0, atol=1e-6 * float(expect.abs().max()))))
+        try:
+            worst = GC.check_grads({k: p.grad for k, p in m.named_parameters()}, expect, tol=1e-5)
+            ok.append(True)
+        except AssertionError as e:
+            worst = (float("nan"), str(e)[:300])
+            ok.append(False)
     opt.step()
     torch.cuda.synchronize()
     w1 = torch.cat([p.detach().flatten() for p in m.parameters()])
     both = [torch.zeros_like(w1) for _ in range(world)]
     dist.all_gather(both, w1)
-    res.update(ok=ok, events=events, nb=len(m.train_engine().arena.buckets),
+    res.update(ok=ok, events=events, worst=worst, flips=flips, loss_ok=loss_ok, nb=len(m.train_engine().arena.buckets),
                same_weights=bool(torch.equal(both[0], both[1])), moved=bool(not torch.equal(w1, torch.cat(
                    [sd0[k].flatten() for k, _ in m.named_parameters()]))))
     q.put(res)
@@ -86,7 +112,9 @@ def test_two_rank_engine_gradsync_on_one_gpu():
         assert p.exitcode == 0
     assert res[0]["w0"] == res[1]["w0"] and res[1]["bn_mean"] == 0.25            # params + buffers = rank 0's
     for r in res:
-        assert r["ok"] == [True, True], r
+        assert r["ok"] == [True, True] and r["loss_ok"], r
+        print(f"[ddp vs per-shard oracle] rank {r['rank']}: {r['flips']} ReLU flips vs fp64 on its shard; synced gradient "
+              f"vs mean of the per-shard fp64 oracle gradients: worst max-norm error {r['worst'][0]:.2e} ({r['worst'][1]})")
         nb = r["nb"]
         assert r["events"][0] == []                                              # first step: arena laid out at its end
         assert r["events"][1] == [("enqueue", k) for k in range(nb)], r["events"] # then: all buckets from inside backward

@@ -789,3 +789,29 @@ def test_fused_and_unfused_1x1_paths_agree(T, golden):
     m.fuse_1x1 = False
     y0 = m(LR)
     assert not torch.equal(y0, y1) and relerr(y1, y0) < 2 * TOL
+
+
+@pytest.mark.parametrize("impl", ["fp16x3", "f32", "bf16x6"])
+def test_tactilesrcnn_eval_forward_vs_reference_golden(golden, impl):
+    """`TactileSRCNN` (reference model/tactileSR_model.py:101-153; the trainers import the name, train/tactileSR_train.py:24)
+    composed from the hot path's kernels: eval forward against the reference's own output (tests/golden/srcnn.npz: its
+    fp32 and fp64 runs on randomised parameters), flat 1e-5; train mode raises."""
+    import tactilesr_amd
+    from tactilesr_amd.model.tactileSR_model import TactileSR, TactileSRCNN   # noqa: F401  (the reference's import line)
+    g = golden("srcnn")
+    sd = O.random_state_dict(O.tactilesrcnn_state_shapes(), int(g["seed"]))
+    m = TactileSRCNN()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    m.conv_impl = impl
+    x = torch.from_numpy(g["x"]).cuda()
+    y = m(x)
+    e32, e64 = relerr(y, torch.from_numpy(g["y"])), relerr(y, torch.from_numpy(g["y64"]))
+    print(f"[TactileSRCNN {impl}] vs reference fp32 {e32:.2e}, vs reference fp64 {e64:.2e}")
+    assert y.shape == (2, 1, 40, 40) and e32 < 1e-5 and e64 < 1e-5
+    with torch.no_grad():                                   # in-place parameter change -> plans are rebuilt
+        m.output[0].weight.mul_(0.5)
+    assert relerr(m(x), torch.from_numpy(g["y"]) * 0.5) < 1e-5
+    m.train()
+    with pytest.raises(tactilesr_amd._lib.TactileSRHipError, match="train mode is not on the MI355X path"):
+        m(x)

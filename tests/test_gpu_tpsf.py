@@ -61,14 +61,43 @@ def test_tpsf_large_batch_properties():
     assert HR[5, 0][m].unique().numel() == 1
 
 
+def test_inplace_edit_of_returned_HR_before_backward_is_caught():
+    """The backward's reductions read the STORED forward output (model/tPSFNet.py:58): normalising / clamping
+    the returned HR in place between forward and backward must trip autograd's version check instead of silently changing
+    d(alpha, beta, gamma); an out-of-place edit leaves the gradients untouched."""
+    import tactilesr_amd
+    torch.manual_seed(7)
+    net = tactilesr_amd.tPSFNet(1.4, None).cuda()
+    g = torch.Generator().manual_seed(8)
+    depth = (torch.rand(3, 1, 100, 100, generator=g) > 0.7).float().cuda()
+    x = (torch.rand(3, 3, 4, 4, generator=g) * 8).cuda()
+    HR, LRd, _, _ = net(x, depth)
+    HR2 = HR / HR.amax()                       # out of place: fine
+    LRd.sum().backward()
+    ref = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad()
+    HR, LRd, _, _ = net(x, depth)
+    HR.div_(HR.amax())
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        LRd.sum().backward()
+    net.zero_grad()
+    HR, LRd, _, _ = net(x, depth)
+    LRd.sum().backward()
+    assert all(torch.equal(p.grad, r) for p, r in zip(net.parameters(), ref)) and HR2.isfinite().all()
+
+
 def test_dataset_generator_matches_batch1_loop(tmp_path):
     """The batched generator (data/SRdataset/depth2tactile.py:104-160 rewritten without the batch-1 loop)
-    writes, per sample, exactly what a batch-1 forward produces, in the reference's file format."""
+    writes, per sample, exactly what a batch-1 forward produces, in the reference's file format -- and every WRITTEN
+    entry (read back from the .npy like utility/load_tactile_dataset.py:39-47 reads it) holds what the CPU oracle's
+    tPSFNet forward (direct 99x99 conv per sample, reference :107-119) computes for that sample: HR, LR_degrade,
+    alphaBeta within 1e-5, LR = LR_raw / scale_num and depth bit-exact."""
     import os
     import tactilesr_amd
     from tactilesr_amd.data import depth2tactile as D
     torch.manual_seed(2)
     net = tactilesr_amd.tPSFNet(1.4, None).cuda()
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     g = torch.Generator().manual_seed(3)
     LR_raw = torch.rand(9, 3, 4, 4, generator=g) * 800
     depth = (torch.rand(9, 100, 100, generator=g) > 0.7).float()
@@ -84,6 +113,13 @@ def test_dataset_generator_matches_batch1_loop(tmp_path):
             assert torch.equal(it["HR"], HR[0].cpu()) and torch.equal(it["LR_degrade"], LRd[0].cpu())
             assert torch.equal(it["alphaBeta"], ab[0, 0].cpu()) and it["depth"].shape == (1, 100, 100)
             assert torch.allclose(it["LR"], LR_raw[i] / 100)
+        rHR, rLRd, _, rab = O.tpsf_forward(sd, LR_raw / 100, depth.unsqueeze(1))
+    for i in range(9):
+        it = ds[i].item()
+        assert set(it) == {"LR", "depth", "HR", "LR_degrade", "alphaBeta"}
+        assert relerr(it["HR"], rHR[i]) < 1e-5 and relerr(it["LR_degrade"], rLRd[i]) < 1e-5, i
+        assert relerr(it["alphaBeta"], rab[i, 0]) < 1e-5 and it["alphaBeta"].shape == (3,), i
+        assert torch.equal(it["LR"], LR_raw[i] / 100) and torch.equal(it["depth"], depth[i].unsqueeze(0)), i
 
 
 @pytest.mark.parametrize("M,N,K,act,ta,tb", [
@@ -200,6 +236,7 @@ def test_seqs_dataset_generator_matches_the_batch1_loop(tmp_path):
     from tactilesr_amd.data import seqs_depth2tactile as S
     torch.manual_seed(4)
     net = tactilesr_amd.tPSFNet(1.4, None).cuda()
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     nc, nt, sc = 2, 3, 4
     N = nc * 81 * sc
     g = torch.Generator().manual_seed(5)
@@ -222,6 +259,9 @@ def test_seqs_dataset_generator_matches_the_batch1_loop(tmp_path):
                     assert torch.equal(e["LR"], torch.cat(lr[::-1], dim=0))               # newest first
                     assert torch.equal(e["depth"], depth[taps[6]].unsqueeze(0))
                     assert torch.equal(e["HR"], HR[0].cpu())
+                    # ... and the stored HR is what the CPU oracle computes for the 30-degree tap (direct 99x99 conv)
+                    rHR, _, _, _ = O.tpsf_forward(sd, lr[6].unsqueeze(0), depth[taps[6]].view(1, 1, 100, 100))
+                    assert relerr(e["HR"], rHR[0]) < 1e-5, (c, t, s)
     path = os.path.join(tmp_path, "SRdataset_train_32.npy")
     S.save_seqs_dataset(path, out["train"])
     ds = np.load(path, allow_pickle=True)

@@ -14,11 +14,9 @@ pytestmark = pytest.mark.gpu
 def _debug_engine(m):
     """Create the module's train engine with `keep_ctx` armed (forward then keeps its context alive so the test can
     read the activation pattern back)."""
-    from tactilesr_amd.model._train import TrainEngine
-    if m._train_engine is None:
-        m._train_engine = TrainEngine(m)
-    m._train_engine.keep_ctx = True
-    return m._train_engine
+    eng = m.train_engine()
+    eng.keep_ctx = True
+    return eng
 
 
 def relerr(a, b):
@@ -137,12 +135,12 @@ def _subs(t, k=512):
 
 
 @pytest.mark.parametrize("impl", ["bf16x6", "fp16x3", "f32"])
-def test_train_forward_backward_vs_reference_golden(T, golden, impl, monkeypatch):
-    monkeypatch.setenv("TSR_TRAIN_IMPL", impl)
+def test_train_forward_backward_vs_reference_golden(T, golden, impl):
     g = golden("train")
     cfg = dict(patternFeatureExtraLayerCnt=2)
     sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), int(g["seed"]))
     m = T.TactileSR(**cfg)
+    m.train_impl = impl            # explicit arithmetic choice (no environment switch)
     m.load_state_dict(sd, strict=True)
     m = m.cuda().train()
     _debug_engine(m)
@@ -191,16 +189,16 @@ def test_train_forward_backward_vs_reference_golden(T, golden, impl, monkeypatch
 
 
 @pytest.mark.parametrize("impl", ["bf16x6", "fp16x3"])
-def test_full_step_adam_vs_reference_golden(T, golden, impl, monkeypatch):
+def test_full_step_adam_vs_reference_golden(T, golden, impl):
     """train_cal_loss + zero_grad/backward/Adam(L2) step through the HIP path, twice; post-step weights,
     running stats and the second-step loss vs the reference's own run."""
     from tactilesr_amd import optim
     from tactilesr_amd.train import tactileSR_train as TR
-    monkeypatch.setenv("TSR_TRAIN_IMPL", impl)
     g = golden("train")
     cfg = dict(patternFeatureExtraLayerCnt=2)
     sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), int(g["seed"]))
     m = T.TactileSR(**cfg)
+    m.train_impl = impl            # explicit arithmetic choice (no environment switch)
     m.load_state_dict(sd, strict=True)
     m = m.cuda().train()
     opt = optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-2)
@@ -359,10 +357,9 @@ def test_train_step_seqs_T8_sf25_vs_oracle(T, B):
     _train_step_vs_oracle(T, dict(seqsCnt=8, scale_factor=25, patternFeatureExtraLayerCnt=2), B, 1977, tol=2e-5)
 
 
-def test_train_step_seqs_T8_sf25_bf16_reduced_precision(T, monkeypatch):
+def test_train_step_seqs_T8_sf25_bf16_reduced_precision(T):
     """configs[4] as BASELINE words it ("bf16"): plain bf16 conv operands, fp32 accumulate/parameters.  Not the
     parity path; bar 2e-2 on the loss and cosine > 0.95 per gradient tensor against fp64."""
-    monkeypatch.setenv("TSR_TRAIN_IMPL", "bf16")
     cfg = dict(seqsCnt=8, scale_factor=25, patternFeatureExtraLayerCnt=2)
     sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), 1977)
     g = torch.Generator().manual_seed(1978)
@@ -370,6 +367,7 @@ def test_train_step_seqs_T8_sf25_bf16_reduced_precision(T, monkeypatch):
     HR = torch.rand(2, 1, 100, 100, generator=g) * 25
     l64, g64, _, _ = GC.oracle_grads(sd, LR, HR, scale_factor=25)
     m = T.TactileSR(**cfg)
+    m.train_impl = "bf16"            # explicit arithmetic choice (no environment switch)
     m.load_state_dict(sd, strict=True)
     m = m.cuda().train()
     loss = F.mse_loss(m(LR.cuda()), HR.cuda())
@@ -384,36 +382,37 @@ def test_train_step_seqs_T8_sf25_bf16_reduced_precision(T, monkeypatch):
         assert cos > 0.95, (k, cos)      # measured worst 0.978 (a stem weight: 8 plain-bf16 stems feed a 512-ch fuse conv)
 
 
-def _tiled_train_step(T, reps, cfg, seed, tol=1e-5):
-    """Size-independent property at a large batch (B = 32 base frames tiled `reps` times): batch statistics, the MSE
-    loss and hence every gradient of a tiled batch equal those of the 32 base frames, which the CPU oracle can run.
-    The activation pattern of the first 32 frames must equal fp64's up to rounding-zero flips, all replicas must
+def _tiled_train_step(T, reps, cfg, seed, tol=1e-5, base=32):
+    """Size-independent property at a large batch (`base` frames tiled `reps` times): batch statistics, the MSE
+    loss and hence every gradient of a tiled batch equal those of the base frames, which the CPU oracle can run.
+    The activation pattern of the first `base` frames must equal fp64's up to rounding-zero flips, all replicas must
     carry the SAME pattern, and every gradient meets the max-norm bar on that pattern."""
+    sf, Tn = cfg.get("scale_factor", 10), cfg.get("seqsCnt", 1)
     torch.manual_seed(seed)
     m = T.TactileSR(**cfg)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     g = torch.Generator().manual_seed(seed + 1)
-    LRb, HRb = torch.rand(32, 3, 4, 4, generator=g) * 8, torch.rand(32, 1, 40, 40, generator=g) * 25
+    LRb, HRb = torch.rand(base, 3 * Tn, 4, 4, generator=g) * 8, torch.rand(base, 1, 4 * sf, 4 * sf, generator=g) * 25
     m = m.cuda().train()
     eng = _debug_engine(m)
     out = m(LRb.repeat(reps, 1, 1, 1).cuda())
     loss = F.mse_loss(out, HRb.repeat(reps, 1, 1, 1).cuda())
     loss.backward()
     torch.cuda.synchronize()
-    l64, _, _, pre64 = GC.oracle_grads(sd, LRb, HRb, record=True)
+    l64, _, _, pre64 = GC.oracle_grads(sd, LRb, HRb, scale_factor=sf, record=True)
     assert abs(loss.item() - l64) < 1e-5 * l64
-    o = out.view(reps, 32, -1)
+    o = out.view(reps, base, -1)
     assert torch.equal(o, o[:1].expand_as(o))                 # replicas are bit-identical in train mode too
     ctx = eng.last_ctx
-    masks = {k: v.cpu() for k, v in eng.activation_masks(ctx, 0, 32).items()}
-    for k, v in eng.activation_masks(ctx, 32 * (reps - 1), 32).items():      # last replica: same pattern
+    masks = {k: v.cpu() for k, v in eng.activation_masks(ctx, 0, base).items()}
+    for k, v in eng.activation_masks(ctx, base * (reps - 1), base).items():      # last replica: same pattern
         assert torch.equal(v.cpu(), masks[k]), k
     del ctx
     eng.last_ctx = None
     flips = GC.check_pattern(masks, pre64)
-    _, g64m, _, _ = GC.oracle_grads(sd, LRb, HRb, masks=masks)
+    _, g64m, _, _ = GC.oracle_grads(sd, LRb, HRb, scale_factor=sf, masks=masks)
     worst = GC.check_grads({k: p.grad for k, p in m.named_parameters()}, g64m, tol=tol)
-    print(f"[tiled x{reps}] {flips} ReLU flips; worst on-pattern grad error {worst[0]:.2e} ({worst[1]})")
+    print(f"[tiled {base} x{reps} {cfg}] {flips} ReLU flips; worst on-pattern grad error {worst[0]:.2e} ({worst[1]})")
     return m
 
 
@@ -432,15 +431,91 @@ def test_train_step_B8192_tiling_invariance(T):
     torch.cuda.empty_cache()
 
 
-def test_bf16_train_mode_is_a_reduced_precision_of_the_same_step(T, golden, monkeypatch):
+def test_seqs_train_step_B256_full_size_tiling_invariance(T):
+    """BASELINE configs[4] at the size bench.py's `seqs_train_b256` leg runs: the FULL TactileSR(scale_factor=25,
+    seqsCnt=8) (6 MSRBs, 100x100 output) train step at B = 256 = 2 base frame-stacks x 128.  Replicas bit-identical,
+    loss 1e-5 against the fp64 oracle on the base frames, the ReLU pattern fp64's up to rounding-zero flips and the same
+    in the last replica, every parameter gradient on that pattern within 2e-5 (the bar of the small Seqs test)."""
+    torch.cuda.empty_cache()
+    m = _tiled_train_step(T, 128, dict(scale_factor=25, seqsCnt=8), 4242, tol=2e-5, base=2)
+    del m
+    torch.cuda.empty_cache()
+
+
+def test_seqs_eval_B512_full_size_tiling_invariance(T):
+    """... and the `seqs_eval_b512` leg's size: eval forward of the full sf = 25 / T = 8 model at B = 512 = 4 distinct
+    frame-stacks x 128, trained-like BatchNorm statistics.  Frames are independent in eval mode: every replica is
+    bit-identical to the first, and the 4 distinct outputs meet 1e-5 against the CPU oracle."""
+    cfg = dict(scale_factor=25, seqsCnt=8)
+    sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), 5125)
+    g = torch.Generator().manual_seed(5126)
+    LRb = torch.rand(4, 24, 4, 4, generator=g) * 8
+    m = T.TactileSR(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        out = m(LRb.repeat(128, 1, 1, 1).cuda())
+        ref = O.tactilesr_forward(sd, LRb, scale_factor=25)
+    assert out.shape == (512, 1, 100, 100)
+    o = out.view(128, 4, -1)
+    assert torch.equal(o, o[:1].expand_as(o))
+    e = relerr(out[:4], ref)
+    print(f"[seqs eval B=512] base frames vs oracle {e:.2e}")
+    assert e < 1e-5
+
+
+def test_bf16_storage_train_step_B8192_full_size_tiling_invariance(T):
+    """BASELINE configs[2] at the size bench.py's `train_bf16_b8192` leg runs: the full 6-MSRB model, every activation /
+    gradient tensor stored as bf16 CB16, B = 8192 = 32 frames x 256 (84 GB of saved tensors).  Replicas bit-identical;
+    loss within 2e-3 of the bf16-EMULATING oracle's loss on the 32 base frames (the yardstick of every bf16 test: the
+    reference has no bf16 numerics); every parameter gradient pointing the emulated one's way (cosine >= 0.995) with the
+    norm within 5 %; running statistics within 2e-3."""
+    torch.cuda.empty_cache()
+    torch.manual_seed(42)
+    m = T.TactileSR()
+    m.train_impl = "bf16"            # explicit arithmetic choice (no environment switch)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(43)
+    LRb, HRb = torch.rand(32, 3, 4, 4, generator=g) * 8, torch.rand(32, 1, 40, 40, generator=g) * 25
+    m = m.cuda().train()
+    out = m(LRb.repeat(256, 1, 1, 1).cuda())
+    assert m.train_engine().io16
+    loss = F.mse_loss(out, HRb.repeat(256, 1, 1, 1).cuda())
+    loss.backward()
+    o = out.view(256, 32, -1)
+    assert torch.equal(o, o[:1].expand_as(o))
+    l_e, g_e, ns_e, _ = _emulated_step(sd, LRb, HRb)
+    assert abs(loss.item() - l_e) <= 2e-3 * abs(l_e), (loss.item(), l_e)
+    new_sd = m.state_dict()
+    for k, v in ns_e.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert relerr(new_sd[k], v) < 2e-3, k
+    worst = 1.0
+    gmax = float(max(v.abs().max() for v in g_e.values()))
+    for k, p in m.named_parameters():
+        ref = g_e[k].double().flatten()
+        if float(ref.abs().max()) < 1e-6 * gmax:
+            continue
+        got = p.grad.detach().cpu().double().flatten()
+        cos = float(got @ ref / (got.norm() * ref.norm()).clamp_min(1e-30))
+        worst = min(worst, cos)
+        assert cos >= 0.995, (k, cos)
+        assert abs(float(got.norm() / ref.norm()) - 1.0) < 5e-2, (k, float(got.norm() / ref.norm()))
+    print(f"[bf16-storage train B=8192] loss {abs(loss.item() - l_e) / abs(l_e):.2e} from the emulated loss, worst gradient "
+          f"cosine {worst:.5f}")
+    del m, out, loss
+    torch.cuda.empty_cache()
+
+
+def test_bf16_train_mode_is_a_reduced_precision_of_the_same_step(T, golden):
     """TSR_TRAIN_IMPL=bf16 (BASELINE's "bf16" configurations: bf16 conv operands, fp32 accumulation, parameters and
     activations) is NOT the parity path; it must still be the same computation: loss within 2e-2 of the reference's,
     every gradient pointing the same way (cosine > 0.98 against the fp64 yardstick)."""
-    monkeypatch.setenv("TSR_TRAIN_IMPL", "bf16")
     g = golden("train")
     cfg = dict(patternFeatureExtraLayerCnt=2)
     sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), int(g["seed"]))
     m = T.TactileSR(**cfg)
+    m.train_impl = "bf16"            # explicit arithmetic choice (no environment switch)
     m.load_state_dict(sd, strict=True)
     m = m.cuda().train()
     LR, HR = torch.from_numpy(g["LR"]).cuda(), torch.from_numpy(g["HR_prepared"]).cuda()
@@ -474,7 +549,7 @@ def _emulated_step(sd, LR, HR, **kw):
 @pytest.mark.parametrize("cfg,B,seed", [(dict(patternFeatureExtraLayerCnt=2), 4, 211),
                                         (dict(seqsCnt=2, patternFeatureExtraLayerCnt=1), 3, 977),
                                         (dict(seqsCnt=8, scale_factor=25, patternFeatureExtraLayerCnt=1), 2, 1977)])
-def test_train_step_bf16_storage_vs_bf16_emulating_oracle(T, cfg, B, seed, monkeypatch):
+def test_train_step_bf16_storage_vs_bf16_emulating_oracle(T, cfg, B, seed):
     """TSR_TRAIN_IMPL=bf16 -- BASELINE's "bf16" train configurations: every stored activation / gradient tensor is bf16
     CB16 (saved pre-activations z, dz, dgrad outputs), bf16 MFMA operands, fp32 accumulation, fp32 master weights /
     BatchNorm statistics / weight gradients -- against the oracle's restatement of THAT arithmetic in the forward pass
@@ -482,7 +557,6 @@ def test_train_step_bf16_storage_vs_bf16_emulating_oracle(T, cfg, B, seed, monke
     the reference has no bf16 numerics): loss within 2e-3, output max-norm within 2^-6 (two bf16 evaluations decorrelate
     to about one ulp RMS, see the eval test), running statistics within 2e-3, every parameter gradient pointing the same way as the
     emulated one (cosine >= 0.995; the oracle's backward keeps fp32 gradient tensors, the device rounds them to bf16)."""
-    monkeypatch.setenv("TSR_TRAIN_IMPL", "bf16")
     sf, Tn = cfg.get("scale_factor", 10), cfg.get("seqsCnt", 1)
     sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), seed)
     g = torch.Generator().manual_seed(seed + 1)
@@ -490,6 +564,7 @@ def test_train_step_bf16_storage_vs_bf16_emulating_oracle(T, cfg, B, seed, monke
     HR = torch.rand(B, 1, 4 * sf, 4 * sf, generator=g) * 25
     l_e, g_e, ns_e, out_e = _emulated_step(sd, LR, HR, scale_factor=sf)
     m = T.TactileSR(**cfg)
+    m.train_impl = "bf16"            # explicit arithmetic choice (no environment switch)
     m.load_state_dict(sd, strict=True)
     m = m.cuda().train()
     eng = _debug_engine(m)
@@ -519,12 +594,12 @@ def test_train_step_bf16_storage_vs_bf16_emulating_oracle(T, cfg, B, seed, monke
           f"worst gradient cosine {worst:.5f}")
 
 
-def test_bf16_storage_train_step_tiling_invariance(T, monkeypatch):
+def test_bf16_storage_train_step_tiling_invariance(T):
     """Larger batch through the bf16-storage train path (B = 512 = 32 frames x 16): replicas bit-identical, loss equal to
     the oracle's emulated loss on the 32 base frames within 2e-3."""
-    monkeypatch.setenv("TSR_TRAIN_IMPL", "bf16")
     torch.manual_seed(5)
     m = T.TactileSR(patternFeatureExtraLayerCnt=2)
+    m.train_impl = "bf16"            # explicit arithmetic choice (no environment switch)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     g = torch.Generator().manual_seed(6)
     LRb, HRb = torch.rand(32, 3, 4, 4, generator=g) * 8, torch.rand(32, 1, 40, 40, generator=g) * 25
@@ -595,6 +670,63 @@ def test_multi_step_loss_trajectory_tracks_the_oracle(T):
     print("[trajectory]", ["%.1e" % r for r in rel])
     assert ref[-1] < 0.8 * ref[0]                     # the curve is alive
     assert max(rel[:3]) < 1e-5 and max(rel) < 1e-3, rel
+
+
+@pytest.mark.filterwarnings("ignore:Detected call of")
+def test_trainer_loop_under_warmup_steplr_tracks_the_oracle(T, golden):
+    """SURVEY 8(f2) on hardware: three short epochs of the trainer step (train_cal_loss -> zero_grad -> backward -> fused
+    Adam-L2) with the learning rate driven by LRWarmupScheduler('auto') in front of StepLR(1, 0.8) exactly as the
+    reference's hooks drive it (iter_update after every iteration, epoch_update after every epoch:
+    cpu/lr_scheduler.py:97-166, train/tactileSR_train.py:215-228).  The rate the optimizer holds before every iteration
+    must be BIT-EQUAL to the sequence the reference's own scheduler class produced (tests/golden/lr_schedule_short.npz:
+    warm-up crossing the first epoch end, two StepLR decays), and the loss curve follows the CPU oracle's
+    `train_one_iter` fed THAT golden sequence: 1e-5 for the first three steps, 1e-4 per step throughout."""
+    from tactilesr_amd import optim
+    from tactilesr_amd.train import tactileSR_train as TR
+    from tactilesr_amd.train.lr_scheduler import LRWarmupScheduler
+    seq = golden("lr_schedule_short")["short_auto"]
+    epochs, epoch_len = 3, 6
+    assert seq.shape == (1 + epochs * (epoch_len + 1),)
+    cfg = dict(patternFeatureExtraLayerCnt=2)
+    sd = O.random_state_dict(O.tactilesr_state_shapes(**cfg), 42)
+    g = torch.Generator().manual_seed(2)
+    B = 8
+    batches = []
+    for _ in range(epoch_len):                                   # a 6-batch "loader", replayed every epoch
+        LR = torch.rand(B, 3, 4, 4, generator=g) * 8
+        batches.append((LR, F.interpolate(LR.mean(1, keepdim=True), size=(100, 100), mode="bilinear") * 30))
+    # oracle: the golden rate of iteration (e, j) is the entry after the previous update, index e*(epoch_len+1)+j
+    p, state, ref, step = {k: v.clone() for k, v in sd.items()}, {}, [], 0
+    for e in range(epochs):
+        for j, (LR, HR) in enumerate(batches):
+            step += 1
+            loss, _ = O.train_one_iter(p, state, step, LR, HR, lr=float(seq[e * (epoch_len + 1) + j]), weight_decay=1e-2)
+            ref.append(loss)
+    m = T.TactileSR(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    opt = optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-2)
+    sch = LRWarmupScheduler(torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.8), by_epoch=True,
+                            epoch_len=epoch_len, warmup_t=8, warmup_by_epoch=False, warmup_mode="auto",
+                            warmup_init_lr=1e-5, warmup_factor=1e-2)
+    conf = TR.default_config()
+    got, used = [], []
+    for e in range(epochs):
+        for j, batch in enumerate(batches):
+            used.append(opt.param_groups[0]["lr"])
+            assert used[-1] == seq[e * (epoch_len + 1) + j], (e, j, used[-1])
+            got.append(float(TR.train_one_iter(m, opt, batch, conf)["total_loss"]))
+            sch.iter_update()
+        sch.epoch_update()
+    assert opt.param_groups[0]["lr"] == seq[-1]
+    assert len(set(used)) >= 9                                    # the rate really moved: ramp + two decays
+    rel = [abs(a - b) / abs(a) for a, b in zip(ref, got)]
+    print("[trainer loop under warm-up + StepLR]", ["%.1e" % r for r in rel])
+    assert max(rel[:3]) < 1e-5 and max(rel) < 1e-4, rel
+    # the weights the schedule produced: post-loop running statistics agree with the oracle's
+    new_sd = m.state_dict()
+    for k in [k for k in p if k.endswith("running_mean") or k.endswith("running_var")]:
+        assert relerr(new_sd[k], p[k]) < 1e-4, k
 
 
 def test_seqs_transplant_forward_backward_frozen_blocks(T):

@@ -94,3 +94,54 @@ def test_tpsfnet_interface_and_cpu_refusal():
         net(torch.zeros(2, 3, 4, 4), torch.zeros(3, 1, 100, 100))
     with pytest.raises(_lib.TactileSRHipError, match="no CPU fallback"):
         net(torch.zeros(2, 3, 4, 4), torch.zeros(2, 1, 100, 100))
+
+
+def test_reference_import_line_and_tactilesrcnn_init(golden):
+    """The reference trainers' import line works verbatim against the drop-in module (train/tactileSR_train.py:24,
+    train/tactileSRSeqs_train.py:24): `TactileSRCNN` exists with the reference's constructor, state_dict key order and
+    seeded init (model/tactileSR_model.py:101-145; sha256 of the reference's own seed-42 construction in
+    tests/golden/srcnn.npz); it refuses CPU tensors and train mode loudly."""
+    from tactilesr_amd.model.tactileSR_model import TactileSR, TactileSRCNN   # noqa: F401  (the reference's line)
+    g = golden("srcnn")
+    torch.manual_seed(42)
+    m = TactileSRCNN()
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(O.tactilesrcnn_state_shapes().keys())
+    assert sd_hash(sd) == bytes(g["init_sha"]).hex()
+    assert "conv_impl='fp16x3'" in repr(m)
+    with pytest.raises(_lib.TactileSRHipError, match="no CPU fallback"):
+        m.eval()(torch.zeros(1, 3, 4, 4))
+
+
+def test_default_environment_selects_the_parity_arithmetic(monkeypatch):
+    """the arithmetic is an explicit constructor / attribute choice printed by repr(model); the
+    defaults are the parity paths and NO environment variable changes them (the former TSR_CONV_IMPL / TSR_TRAIN_IMPL /
+    TSR_HEAD_IMPL / TSR_FUSE* switches are gone; the library holds no getenv at all)."""
+    for k, v in (("TSR_CONV_IMPL", "bf16"), ("TSR_TRAIN_IMPL", "bf16"), ("TSR_HEAD_IMPL", "bf16"), ("TSR_FUSE1X1", "0"),
+                 ("TSR_FUSE_PAIR", "0"), ("TSR_CONV_M32", "1"), ("TSR_WGRAD_OLD", "1")):
+        monkeypatch.setenv(k, v)
+    m = tactilesr_amd.TactileSR(patternFeatureExtraLayerCnt=1)
+    assert (m.conv_impl, m.train_impl, m.head_impl, m.fuse_1x1, m.fuse_pair) == ("fp16x3", "fp16x3", None, True, True)
+    assert m.train_engine().impl == "fp16x3" and m.train_engine().nsplit == -2
+    r = repr(m).splitlines()[1]
+    assert "conv_impl='fp16x3'" in r and "train_impl='fp16x3'" in r and "fp32-grade" in r
+    blk = tactilesr_amd.MSRB()
+    assert (blk.conv_impl, blk.train_impl) == ("fp16x3", "fp16x3")
+    # explicit choices: constructor keywords (after the reference's positional arguments) or attributes
+    m2 = tactilesr_amd.TactileSR(10, 1, 3, 1, 1, conv_impl="bf16", train_impl="bf16")
+    assert "REDUCED precision" in repr(m2) and m2.train_engine().io16
+    m2.train_impl = "f32"
+    assert m2.train_engine().impl == "f32" and not m2.train_engine().io16
+    with pytest.raises(_lib.TactileSRHipError, match="conv_impl"):
+        tactilesr_amd.TactileSR(conv_impl="fp8")
+    m2.train_impl = "int4"
+    with pytest.raises(_lib.TactileSRHipError, match="train_impl"):
+        m2.train_engine()
+    blk.train_impl = "bf16"                  # only pinned for the whole network (bf16-emulating oracle): refused here
+    with pytest.raises(_lib.TactileSRHipError, match="train_impl"):
+        blk.block_engine()
+    # the shipped library reads no environment variable and is not a variant build
+    src = "".join(open(os.path.join(REPO, "tactilesr_amd", "csrc", f)).read()
+                  for f in os.listdir(os.path.join(REPO, "tactilesr_amd", "csrc")))
+    assert "getenv" not in src and not re.search(r"TSR_ABL_|TSR_EXP_", src)
+    assert _lib.build_flags() == 0

@@ -54,6 +54,19 @@ def test_lr_warmup_matches_reference_sequence(golden, name):
     assert st["n_iter"] == (0 if CASES[name]["warmup_by_epoch"] else 3000)   # epoch warm-up ignores iter_update
 
 
+LR_SHORT = dict(lr=1e-4, step=1, by_epoch=True, warmup_t=8, warmup_by_epoch=False, warmup_mode='auto',
+                warmup_init_lr=1e-5, warmup_factor=1e-2)
+
+
+@pytest.mark.filterwarnings("ignore:Detected call of")
+def test_lr_warmup_short_schedule_matches_reference_sequence(golden):
+    """The short schedule the -m gpu trainer-loop test runs under (warm-up crossing an epoch end, then StepLR(1, 0.8)):
+    bit-equal to the reference class's own sequence (tests/golden/lr_schedule_short.npz)."""
+    ref = golden("lr_schedule_short")["short_auto"]
+    got, _ = lr_sequence(LRWarmupScheduler, dict(LR_SHORT), 3, 6)
+    assert np.array_equal(got, ref)
+
+
 @pytest.mark.filterwarnings("ignore:Detected call of")
 @pytest.mark.parametrize("name", ["auto_shipped", "by_epoch"])
 @pytest.mark.parametrize("layout", ["own", "reference"])

@@ -6,5 +6,5 @@ P='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); pri
 for v in ${ABL_LIST:-cur}; do
   echo "== $v"
   if [ $v = cur ]; then python bench.py --mode train --batch 2048 --no-legs --no-cpu-baseline --steps 3 --warmup 1 "$@" | python -c "$P";
-  else TSR_LIB_OVERRIDE=tactilesr_amd/lib/exp/$v/libtactilesr_hip.so python bench.py --mode train --batch 2048 --no-legs --no-cpu-baseline --steps 3 --warmup 1 "$@" | python -c "$P"; fi
+  else TSR_ALLOW_VARIANT=1 TSR_LIB_OVERRIDE=tactilesr_amd/lib/exp/$v/libtactilesr_hip.so python bench.py --mode train --batch 2048 --no-legs --no-cpu-baseline --steps 3 --warmup 1 "$@" | python -c "$P"; fi
 done

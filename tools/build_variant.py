@@ -3,7 +3,8 @@
 
     python tools/build_variant.py NAME -DTSR_EXP_FOO [-D...]
 
--> tactilesr_amd/lib/exp/NAME/libtactilesr_hip.so (select it with TSR_LIB_OVERRIDE=<that path>).
+-> tactilesr_amd/lib/exp/NAME/libtactilesr_hip.so (select it with TSR_LIB_OVERRIDE=<that path> TSR_ALLOW_VARIANT=1: a
+variant library reports itself through tsr_build_flags() and the binding refuses it otherwise).
 Only the sources that mention a given macro are recompiled; the other objects are reused.
 """
 import os
@@ -15,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tactilesr_amd import build as B  # noqa: E402
 
-name, defs = sys.argv[1], sys.argv[2:]
+name, defs = sys.argv[1], sys.argv[2:] + ["-DTSR_VARIANT_BUILD=1"]       # api.hip: tsr_build_flags() reports the variant
 B.build(verbose=False)
 out = os.path.join(B.LIBDIR, "exp", name)
 os.makedirs(out, exist_ok=True)

@@ -26,7 +26,7 @@ loss=F.mse_loss(out,HR.double()); loss.backward()
 F.conv2d=orig
 print("n conv", len(rec), [tuple(r.shape[1:2]) for r in rec])
 m=M.TactileSR(**cfg); m.load_state_dict(sd); m=m.cuda().train()
-m._train_engine=TrainEngine(m); m._train_engine.debug={}
+m.train_engine().debug={}
 o=m(LR.cuda()); l=F.mse_loss(o,HR.cuda()); l.backward()
 dbg=m._train_engine.debug
 # conv order in oracle: stem conv1, stem conv2, fuse, c31, c51, c32, c52, conf, force stem, res1, res2, head0, head
