@@ -111,10 +111,16 @@ def pmc_traffic(kernel_substr, mode="eval"):
     if not files:
         return None, None
     d = json.load(open(files[-1]))
+    rel = os.path.relpath(files[-1], REPO)
+    from tactilesr_amd import build as _b
+    took, now = d.get("_meta", {}).get("csrc_sha16"), _b.source_hash()
+    if took != now:
+        # the kernels changed since the counters were collected (or the pass predates the hash): do not quote them
+        return None, f"stale: {rel} was collected on kernel sources {took}, this build is {now} -- re-collect (tools/collect_profiles.sh)"
     for k, v in d.items():
-        if kernel_substr in k and "hbm_bytes_per_launch" in v:
-            return v["hbm_bytes_per_launch"], os.path.relpath(files[-1], REPO)
-    return None, None
+        if not k.startswith("_") and kernel_substr in k and "hbm_bytes_per_launch" in v:
+            return v["hbm_bytes_per_launch"], f"{rel} (kernel '{k}', sources {took}, commit {d['_meta'].get('summarized_at_commit')})"
+    return None, f"no kernel matching '{kernel_substr}' in {rel}"
 
 
 def main():
@@ -196,7 +202,8 @@ def run_legs(args, dev):
             gc.collect()
             torch.cuda.empty_cache()
 
-    leg("train_b2048", run_train, mode="train", steps=5, warmup=2)
+    leg("train_b32", run_train, mode="train", batch=32, steps=20, warmup=3)      # the reference's train_batch_size (config/default.py:46)
+    leg("train_b2048", run_train, mode="train", steps=5, warmup=2, no_cpu_baseline=True)
     leg("train_b8192", run_train, mode="train", batch=8192, steps=2, warmup=1, no_cpu_baseline=True)
     leg("eval_bf16_storage", run_infer, impl="bf16", impl_given=True, steps=10, warmup=2, no_cpu_baseline=True)
     leg("train_bf16_b8192", run_train, mode="train", impl="bf16", impl_given=True, batch=8192, steps=2, warmup=1,
@@ -506,11 +513,17 @@ def cpu_train_baseline(steps=3):
 def tpsf_traffic(B):
     """HBM bytes per tpsf_fwd_mfma_kernel launch from the committed PMC passes (same B only)."""
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_tpsf_pmc.json")))
-    if not files:
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_tpsf_pmc_summary.json")))
+    if not files or B != 8192:
         return None
-    d = json.load(open(files[-1])).get("tpsf_fwd_mfma_kernel")
-    return d["hbm_bytes_per_launch"] if d and d.get("samples_per_launch") == B else None
+    d = json.load(open(files[-1]))
+    from tactilesr_amd import build as _b
+    if d.get("_meta", {}).get("csrc_sha16") != _b.source_hash():
+        return None                      # kernels changed since the pass: stale
+    for k, v in d.items():
+        if "tpsf_fwd" in k and "hbm_bytes_per_launch" in v:
+            return v["hbm_bytes_per_launch"]
+    return None
 
 
 def run_tpsf(args, world, rank, dev):
@@ -578,7 +591,7 @@ def run_tpsf(args, world, rank, dev):
             "forward_only": {"samples_per_s": round(vf, 1), "ms_per_batch": round(dtf / args.steps * 1e3, 3)},
             "roofline": {"bound": "hbm", "achieved": round(vf / world * fwd_bytes / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(vf / world * fwd_bytes / 8e12, 4), "traffic": tpsf_traffic(B),
-                         "traffic_unit": "bytes/launch (PMC, profiles/r*_tpsf_pmc.json)",
+                         "traffic_unit": "bytes/launch (PMC, profiles/rNN_tpsf_pmc_summary.json; null when the kernel sources changed since)",
                          "algorithmic_bytes_per_launch": B * fwd_bytes,
                          "kernel": "tpsf_fwd_mfma_kernel (+ the MLP launches: forward-only rate x %d algorithmic bytes/sample)" % fwd_bytes},
             "loss": float(loss.detach()),

@@ -28,6 +28,20 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def source_hash() -> str:
+    """sha256[:16] over every kernel source (csrc/*.hip, csrc/*.h, include/*.h): bench.py compares it with the hash a
+    committed PMC profile was taken at, so `roofline.traffic` is never quoted for kernels that have changed since."""
+    import hashlib
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    h = hashlib.sha256()
+    for d in (CSRC, inc):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".h")):
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _newer(path, deps):
     if not os.path.exists(path):
         return True
@@ -65,4 +79,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--source-hash" in sys.argv:
+        print(source_hash())
+    else:
+        print(build(force="--force" in sys.argv))

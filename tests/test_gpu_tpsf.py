@@ -119,7 +119,8 @@ def test_dataset_generator_matches_batch1_loop(tmp_path):
         assert set(it) == {"LR", "depth", "HR", "LR_degrade", "alphaBeta"}
         assert relerr(it["HR"], rHR[i]) < 1e-5 and relerr(it["LR_degrade"], rLRd[i]) < 1e-5, i
         assert relerr(it["alphaBeta"], rab[i, 0]) < 1e-5 and it["alphaBeta"].shape == (3,), i
-        assert torch.equal(it["LR"], LR_raw[i] / 100) and torch.equal(it["depth"], depth[i].unsqueeze(0)), i
+        # (LR is divided on the device: its fp32 division may differ from the host's in the last bit)
+        assert relerr(it["LR"], LR_raw[i] / 100) < 2e-7 and torch.equal(it["depth"], depth[i].unsqueeze(0)), i
 
 
 @pytest.mark.parametrize("M,N,K,act,ta,tb", [

@@ -8,6 +8,8 @@ TAG=${1:-rXX}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
+# what the counters were taken on: bench.py nulls roofline.traffic when the kernel sources no longer match
+python3 -c "import json,sys; sys.path.insert(0,'.'); from tactilesr_amd import build as b; json.dump({'csrc_sha16': b.source_hash()}, open('$OUT/meta.json','w'))"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 run() {  # name, rocprof args..., -- bench args
   local name=$1; shift

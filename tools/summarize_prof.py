@@ -44,6 +44,17 @@ for run in sorted(os.listdir(src)):
             shutil.copy(f, os.path.join(dst, f"{tag}_{run[:-6]}_kernel_stats.csv"))
 
 
+meta = {}
+if os.path.exists(os.path.join(src, "meta.json")):
+    meta = json.load(open(os.path.join(src, "meta.json")))
+try:
+    import subprocess
+    meta["summarized_at_commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                                                  cwd=os.path.dirname(dst)).stdout.strip()
+except OSError:
+    pass
+
+
 def collect(runs):
     pmc = collections.defaultdict(lambda: collections.defaultdict(list))
     for run in runs:
@@ -71,6 +82,7 @@ for mode in ("eval", "train", "tpsf", "bf16", "trainbf16"):
             e["hbm_bytes_per_launch"] = (2 * e["FETCH_SIZE_KiB_per_launch"] + e["WRITE_SIZE_KiB_per_launch"]) * 1024
         out[k] = e
     if out:
+        out["_meta"] = dict(meta)         # kernel-source hash of the build the counters were collected on
         name = f"{tag}_pmc_summary.json" if mode == "eval" else f"{tag}_{mode}_pmc_summary.json"
         json.dump(out, open(os.path.join(dst, name), "w"), indent=1, sort_keys=True)
 
