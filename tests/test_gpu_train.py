@@ -724,7 +724,7 @@ def test_trainer_loop_under_warmup_steplr_tracks_the_oracle(T, golden):
 
     golden_rate = lambda e, j: float(seq[e * (epoch_len + 1) + j])            # noqa: E731
     ref, p = oracle_curve(golden_rate)
-    ref64, _ = oracle_curve(golden_rate, f64=True)
+    ref64, p64 = oracle_curve(golden_rate, f64=True)
     # control: the same loop WITHOUT the StepLR decays (the rate held at its end-of-warm-up value)
     held, _ = oracle_curve(lambda e, j: float(seq[min(e * (epoch_len + 1) + j, 9)]))
     m = T.TactileSR(**cfg)
@@ -764,10 +764,12 @@ def test_trainer_loop_under_warmup_steplr_tracks_the_oracle(T, golden):
     miss = abs(held[-1] - ref[-1]) / abs(ref[-1])
     print(f"[trainer loop under warm-up + StepLR] final loss without the StepLR decays: {miss:.1e} away")
     assert ref[-1] < 0.7 * ref[0] and miss > 10 * max(rel[-1], rel64[-1]), (miss, rel[-1])
-    # the weights the schedule produced: post-loop running statistics agree with the oracle's
+    # the weights the schedule produced: the post-loop running statistics agree with the oracle's to the same yardstick
+    # (the oracle's own fp32-vs-fp64 distance on that tensor after the 18 steps, x3, floor 1e-4)
     new_sd = m.state_dict()
     for k in [k for k in p if k.endswith("running_mean") or k.endswith("running_var")]:
-        assert relerr(new_sd[k], p[k]) < 1e-4, k
+        bar = max(1e-4, 3 * relerr(p[k], p64[k]))
+        assert relerr(new_sd[k], p[k]) <= bar, (k, relerr(new_sd[k], p[k]), bar)
 
 
 def test_seqs_transplant_forward_backward_frozen_blocks(T):
