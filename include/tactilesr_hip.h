@@ -339,6 +339,18 @@ int tsr_sgemm(const float* A, long long sa0, long long sa1, const float* B, long
  * receives the partial product of K range s (no bias / activation); add the slabs with tsr_reduce_splits. */
 int tsr_sgemm_splitk(const float* A, long long sa0, long long sa1, const float* B, long long sb0, long long sb1,
                      float* slab, int M, int N, int K, int nsplit, void* stream);
+/* dx GEMM of a layer with the ReLU backward of the layer below fused: C[i][j] = (sum_k A(i,k)B(k,j)) if mask_ref[i][j] > 0
+ * else 0 (mask_ref = the stored ReLU output the gradient flows back through, row-major [M][N]). */
+int tsr_sgemm_masked(const float* A, long long sa0, long long sa1, const float* B, long long sb0, long long sb1,
+                     const float* mask_ref, float* C, int M, int N, int K, void* stream);
+/* tsr_sgemm_splitk with a caller-chosen distance between the partial results (split s lands at slab + s*split_stride,
+ * split_stride >= M*N): the partials of several GEMMs share one [nsplit][total] buffer that ONE tsr_reduce_splits call
+ * adds into a flat gradient buffer. */
+int tsr_sgemm_splitk_strided(const float* A, long long sa0, long long sa1, const float* B, long long sb0, long long sb1,
+                             float* slab, long long split_stride, int M, int N, int K, int nsplit, void* stream);
+/* Column sums of Y[M][N] per row range (db = 1^T dy over the same K ranges as the split-K GEMM with K = M):
+ * slab[s*split_stride + j] = sum of rows of range s. */
+int tsr_colsum_splitk(const float* Y, float* slab, long long split_stride, int M, int N, int nsplit, void* stream);
 /* dy *= act'(.) in place from the stored activation output (1 ReLU, 2 Softplus). */
 int tsr_act_bwd(float* dy, const float* y, long long n, int mode, void* stream);
 

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TSR_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libtactilesr_hip.so")   # override: kernel A/B experiments
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _P, _I, _F, _L = c_void_p, c_int, c_float, c_longlong
 
@@ -73,6 +73,9 @@ SIGNATURES = {
     "tpsf_backward": [_P, _P, _P, _P, _P, _P, _I, _P],
     "tsr_sgemm": [_P, _L, _L, _P, _L, _L, _P, _P, _I, _I, _I, _I, _P],
     "tsr_sgemm_splitk": [_P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _I, _P],
+    "tsr_sgemm_masked": [_P, _L, _L, _P, _L, _L, _P, _P, _I, _I, _I, _P],
+    "tsr_sgemm_splitk_strided": [_P, _L, _L, _P, _L, _L, _P, _L, _I, _I, _I, _I, _P],
+    "tsr_colsum_splitk": [_P, _P, _L, _I, _I, _I, _P],
     "tsr_act_bwd": [_P, _P, _L, _I, _P],
     "tsr_nchw_to_cb16": [_P, _P, _I, _I, _I, _I, _I, _P],
     "tsr_cb16_to_nchw": [_P, _P, _I, _I, _I, _I, _I, _P],

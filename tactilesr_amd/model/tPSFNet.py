@@ -30,20 +30,52 @@ def _linear(x, w, b, act):
     return y
 
 
-def _splitk(a, sa0, sa1, b, sb0, sb1, out, M, N, K):
-    """out[M][N] = sum_k a(i,k) b(k,j) with K split over enough workgroups to fill the chip; the partial slabs
-    are added in a fixed order (tsr_reduce_splits)."""
-    tiles = ((M + 63) // 64) * ((N + 63) // 64)
-    ns = max(1, min((1024 + tiles - 1) // tiles, (K + 63) // 64))
-    slab = torch.empty(ns * M * N, dtype=torch.float32, device=out.device)
-    call("tsr_sgemm_splitk", ptr(a), _L(sa0), _L(sa1), ptr(b), _L(sb0), _L(sb1), ptr(slab), _I(M), _I(N), _I(K), _I(ns),
-         stream())
-    call("tsr_reduce_splits", ptr(slab), ptr(out), _L(M * N), _I(ns), _lib.c_float(1.0), stream())
+_ALIGN = 64      # gradient slots start on 256-B boundaries (the fused Adam kernel's 16-B accesses)
+
+
+class _GradPlan:
+    """Where the MLP's parameter gradients land: ONE flat fp32 buffer holding the eight tensors in parameter order (slot
+    offsets 256-B aligned) and ONE split-K slab `[nsplit][total]` that every dW / db launch of a backward writes its
+    partial sums into, so that a single ``tsr_reduce_splits`` adds all of them in a fixed order.  ``p.grad`` aliases the
+    flat buffer (autograd adopts the fresh views it is handed), so the addresses the fused Adam table holds never change:
+    the table is built once (gradients that are fresh autograd tensors every step re-built it per step)."""
+
+    def __init__(self, params, device):
+        self.shapes = [tuple(p.shape) for p in params]
+        self.offsets = []
+        off = 0
+        for p in params:
+            self.offsets.append(off)
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.total = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.slab = None
+        self.nsplit = 0
+
+    def matches(self, params, device):
+        return self.flat.device == device and self.shapes == [tuple(p.shape) for p in params]
+
+    def slab_for(self, nsplit):
+        if self.slab is None or self.nsplit != nsplit:
+            self.slab = torch.zeros(nsplit * self.total, dtype=torch.float32, device=self.flat.device)
+            self.nsplit = nsplit
+        return self.slab
+
+    def view(self, i, buf=None):
+        buf = self.flat if buf is None else buf
+        n = 1
+        for d in self.shapes[i]:
+            n *= d
+        return buf[self.offsets[i]:self.offsets[i] + n].view(self.shapes[i])
+
+
+class _Token:
+    """Identity of one differentiable forward (weakly referenced by ddp.note_forward)."""
 
 
 class _TPSFFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, depth, *params):
+    def forward(ctx, owner, x, depth, *params):
         ws, bs = params[0::2], params[1::2]
         B = x.shape[0]
         h = [x.reshape(B, -1).float().contiguous()]
@@ -55,41 +87,66 @@ class _TPSFFn(torch.autograd.Function):
         LRd = torch.empty(B, 1, 4, 4, dtype=torch.float32, device=x.device)
         psf = torch.empty(B, 1, 99, 99, dtype=torch.float32, device=x.device)
         call("tpsf_forward", ptr(d), ptr(ab), ptr(HR), ptr(LRd), ptr(psf), _I(B), stream())
-        ctx.h, ctx.d, ctx.params = h, d, params
+        ctx.h, ctx.d, ctx.params, ctx.owner = h, d, params, owner
+        ctx.token = _Token()
+        if any(ctx.needs_input_grad):
+            from ..ddp import note_forward
+            note_forward(owner, ctx.token)     # the flat gradient buffer goes only to the sole pending backward
         ctx.save_for_backward(HR)          # the backward's reductions read the stored output: an in-place edit of the
         ctx.mark_non_differentiable(HR, psf)      # returned HR before backward() trips autograd's version check
+        ctx.set_materialize_grads(False)   # no zero-filled (B,1,100,100) / (B,1,99,99) gradients for the unused outputs
         return HR, LRd, psf, ab.view(B, 1, 3).clone()
 
     @staticmethod
     def backward(ctx, gHR, gLR, gpsf, gab):
-        h, d, params = ctx.h, ctx.d, ctx.params
+        h, d, params, owner = ctx.h, ctx.d, ctx.params, ctx.owner
         ws = params[0::2]
         B = h[0].shape[0]
-        dab = torch.zeros(B, 3, dtype=torch.float32, device=d.device)
+        dev = d.device
+        dab = torch.empty(B, 3, dtype=torch.float32, device=dev)
         if gLR is not None:
-            work = torch.empty(B * 10000, dtype=torch.float32, device=d.device)
-            call("tpsf_backward", ptr(d), ptr(h[-1]), ptr(ctx.saved_tensors[0]), ptr(gLR.contiguous().float()), ptr(dab), ptr(work),
-                 _I(B), stream())
+            work = torch.empty(B * 10000, dtype=torch.float32, device=dev)
+            call("tpsf_backward", ptr(d), ptr(h[-1]), ptr(ctx.saved_tensors[0]), ptr(gLR.contiguous().float()), ptr(dab),
+                 ptr(work), _I(B), stream())
+        else:
+            dab.zero_()
         if gab is not None:
             dab = dab + gab.reshape(B, 3)
-        grads = []
+        # gradient plan: the flat buffer is handed to autograd only when no .grad exists yet (zero_grad()'s default) and
+        # no other backward of this module is pending; otherwise (accumulation, a module applied twice in one graph)
+        # fresh tensors, which autograd adds up itself
+        plan = owner._grad_plan
+        if plan is None or not plan.matches(params, dev):
+            plan = owner._grad_plan = _GradPlan(params, dev)
+        live = getattr(owner, "_live_forwards", None)
+        alone = True
+        if live is not None:
+            alone = not any(t is not ctx.token for t in live)
+            live.discard(ctx.token)
+        shared = owner._shared_graph or not alone
+        owner._shared_graph = shared and not alone
+        direct = not shared and all(p.grad is None for p in params)
+        out = plan.flat if direct else torch.empty_like(plan.flat)
+        ns = max(1, min(32, (B + 15) // 16))
+        slab = plan.slab_for(ns)
+        tot = plan.total
         dy = dab.contiguous()
-        ones = torch.ones(B, 1, dtype=torch.float32, device=d.device)
+        call("tsr_act_bwd", ptr(dy), ptr(h[4]), _L(dy.numel()), _I(2), stream())           # Softplus'
         for i in reversed(range(4)):
-            call("tsr_act_bwd", ptr(dy), ptr(h[i + 1]), _L(dy.numel()), _I(1 if i < 3 else 2), stream())
             w = ws[i].detach().contiguous()
             N, K = w.shape
-            gw = torch.empty(N, K, dtype=torch.float32, device=d.device)      # dW = dy^T x   (reduction over the batch)
-            _splitk(dy, 1, N, h[i], K, 1, gw, N, K, B)
-            gb = torch.empty(1, N, dtype=torch.float32, device=d.device)      # db = 1^T dy
-            _splitk(ones, 1, 1, dy, N, 1, gb, 1, N, B)
-            grads = [gw, gb.view(N)] + grads
+            # dW = dy^T x and db = 1^T dy (reductions over the batch): partial sums per batch range into the shared slab
+            call("tsr_sgemm_splitk_strided", ptr(dy), _L(1), _L(N), ptr(h[i]), _L(K), _L(1),
+                 ptr(slab[plan.offsets[2 * i]:]), _L(tot), _I(N), _I(K), _I(B), _I(ns), stream())
+            call("tsr_colsum_splitk", ptr(dy), ptr(slab[plan.offsets[2 * i + 1]:]), _L(tot), _I(B), _I(N), _I(ns), stream())
             if i > 0:
-                dx = torch.empty(B, K, dtype=torch.float32, device=d.device)  # dx = dy W
-                call("tsr_sgemm", ptr(dy), _L(N), _L(1), ptr(w), _L(K), _L(1), ptr(None), ptr(dx), _I(B), _I(K), _I(N),
-                     _I(0), stream())
+                # dx = (dy W) masked by the ReLU of the layer below (its stored output h[i]): one launch
+                dx = torch.empty(B, K, dtype=torch.float32, device=dev)
+                call("tsr_sgemm_masked", ptr(dy), _L(N), _L(1), ptr(w), _L(K), _L(1), ptr(h[i]), ptr(dx), _I(B), _I(K),
+                     _I(N), stream())
                 dy = dx
-        return (None, None) + tuple(grads)
+        call("tsr_reduce_splits", ptr(slab), ptr(out), _L(tot), _I(ns), _lib.c_float(1.0), stream())
+        return (None, None, None) + tuple(plan.view(i, out) for i in range(8))
 
 
 class tPSFNet(nn.Module):
@@ -116,6 +173,8 @@ class tPSFNet(nn.Module):
             for b in range(4):
                 m[a, b] = ((xs.view(-1, 1) - (12 + 25 * a)) ** 2 + (xs.view(1, -1) - (12 + 25 * b)) ** 2) ** 0.5
         self.LR_masking_sdf = 10 * (m - m.min()) / (m.max() - m.min())
+        self._grad_plan = None            # flat gradient buffer + split-K slab (created by the first backward)
+        self._shared_graph = False
         assert abs(float(sdf.max()) - math.sqrt(4802.0)) < 1e-3 and abs(float(m.max()) - math.sqrt(15138.0)) < 1e-3
 
     def forward(self, x, depth):
@@ -126,4 +185,4 @@ class tPSFNet(nn.Module):
         params = []
         for l in lin:
             params += [l.weight, l.bias]
-        return _TPSFFn.apply(x, depth, *params)
+        return _TPSFFn.apply(self, x, depth, *params)

@@ -86,6 +86,48 @@ def test_inplace_edit_of_returned_HR_before_backward_is_caught():
     assert all(torch.equal(p.grad, r) for p, r in zip(net.parameters(), ref)) and HR2.isfinite().all()
 
 
+def test_mlp_gradients_live_in_one_flat_buffer_and_adam_builds_its_table_once():
+    """ADVICE r03 (optim.py:60): tPSFNet's parameter gradients used to be fresh autograd tensors every step, so the fused
+    Adam re-built its device table (a blocking host-to-device copy) per step.  They now land in one flat buffer that
+    `p.grad` aliases: over several zero_grad / backward / step rounds the table is built ONCE; gradient accumulation
+    (no zero_grad) and two applications of the module inside one graph still sum correctly."""
+    import tactilesr_amd
+    from tactilesr_amd import optim
+    from tactilesr_amd.train import tPSFNet_train as TP
+    torch.manual_seed(9)
+    net = tactilesr_amd.tPSFNet(1.4, None).cuda()
+    opt = optim.Adam(net.parameters(), lr=1e-4, weight_decay=1e-5)
+    g = torch.Generator().manual_seed(10)
+    LR = torch.rand(6, 3, 4, 4, generator=g) * 800
+    depth = (torch.rand(6, 100, 100, generator=g) > 0.7).float()
+    for _ in range(4):
+        loss, _ = TP.train_cal_loss(net, (LR.cuda(), depth.cuda()), 100.0)
+        opt.zero_grad()
+        loss.backward()
+        flat = net._grad_plan.flat
+        assert all(flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + 4 * flat.numel() for p in net.parameters())
+        opt.step()
+    assert opt.table_builds == 1 and opt.launches == 4
+    # accumulation: backward twice without zero_grad == 2 x the gradient; shared graph: f(net(a)) + f(net(b))
+    def grads(fn):
+        for p in net.parameters():
+            p.grad = None
+        fn()
+        return [p.grad.clone() for p in net.parameters()]
+    def one(lo, hi):
+        return TP.train_cal_loss(net, (LR[lo:hi].cuda(), depth[lo:hi].cuda()), 100.0)[0]
+    g_a, g_b = grads(lambda: one(0, 3).backward()), grads(lambda: one(3, 6).backward())
+    def twice():
+        one(0, 3).backward()
+        one(0, 3).backward()
+    for x, y in zip(grads(twice), g_a):
+        assert relerr(x, 2 * y) < 1e-6
+    for x, y, z in zip(grads(lambda: (one(0, 3) + one(3, 6)).backward()), g_a, g_b):
+        assert relerr(x, y + z) < 1e-6
+    for x, y in zip(grads(lambda: one(0, 3).backward()), g_a):      # and a plain step afterwards is a plain step
+        assert torch.equal(x, y)
+
+
 def test_dataset_generator_matches_batch1_loop(tmp_path):
     """The batched generator (data/SRdataset/depth2tactile.py:104-160 rewritten without the batch-1 loop)
     writes, per sample, exactly what a batch-1 forward produces, in the reference's file format -- and every WRITTEN
@@ -126,6 +168,10 @@ def test_dataset_generator_matches_batch1_loop(tmp_path):
 @pytest.mark.parametrize("M,N,K,act,ta,tb", [
     (37, 3, 256, 2, False, True), (130, 256, 48, 1, False, True), (64, 64, 16, 0, False, False),
     (100, 70, 33, 0, True, False), (1, 129, 300, 0, False, False), (257, 65, 1030, 1, True, True),
+    # the MLP's own shapes at a batch that runs whole 128-row tiles and the 16-B load paths: forward (k-fast x k-fast),
+    # dx (k-fast x n-fast), dW (m-fast x n-fast, K = batch), and ragged edges on every path
+    (640, 1024, 256, 1, False, True), (600, 256, 1024, 0, False, False), (1024, 256, 2048, 0, True, False),
+    (3, 256, 2048, 0, True, False), (515, 260, 132, 2, False, True), (260, 516, 1028, 0, True, False),
 ])
 def test_sgemm_mfma_strides_activations_and_splitk(M, N, K, act, ta, tb):
     """tsr_sgemm (fp32 matrix cores) with every stride form the MLP uses, ragged tiles, the three epilogues,
@@ -155,6 +201,23 @@ def test_sgemm_mfma_strides_activations_and_splitk(M, N, K, act, ta, tb):
         out = torch.empty(M, N, device="cuda")
         call("tsr_reduce_splits", ptr(slab), ptr(out), L(M * N), I(ns), Fl(1.0), stream())
         assert relerr(out, A64 @ B64) < 2e-6, ns
+    # fused ReLU-backward mask (tsr_sgemm_masked), a strided slab shared by two results + column sums (tsr_sgemm_splitk_strided,
+    # tsr_colsum_splitk): what the tPSFNet backward issues
+    ref_act = torch.randn(M, N, generator=g).cuda()
+    Cm = torch.empty(M, N, device="cuda")
+    call("tsr_sgemm_masked", ptr(A), L(sa[0]), L(sa[1]), ptr(Bm), L(sb[0]), L(sb[1]), ptr(ref_act), ptr(Cm), I(M), I(N), I(K),
+         stream())
+    assert relerr(Cm, (A64 @ B64) * (ref_act.cpu() > 0)) < 2e-6
+    ns, tot = 5, M * N + 64 + N
+    slab = torch.full((ns * tot,), float("nan"), device="cuda")
+    call("tsr_sgemm_splitk_strided", ptr(A), L(sa[0]), L(sa[1]), ptr(Bm), L(sb[0]), L(sb[1]), ptr(slab), L(tot), I(M), I(N), I(K),
+         I(ns), stream())
+    Y = torch.randn(K, N, generator=g).cuda()                 # column sums over K rows, same ranges
+    call("tsr_colsum_splitk", ptr(Y), ptr(slab[M * N + 64:]), L(tot), I(K), I(N), I(ns), stream())
+    sl = slab.view(ns, tot)
+    assert relerr(sl[:, :M * N].double().sum(0).view(M, N), A64 @ B64) < 2e-6
+    assert relerr(sl[:, M * N + 64:].double().sum(0), Y.double().cpu().sum(0)) < 2e-6
+    assert torch.isnan(sl[:, M * N:M * N + 64]).all()          # the gap between the two results is not touched
 
 
 def test_tpsf_kernels_wide_dynamic_range_batch():
