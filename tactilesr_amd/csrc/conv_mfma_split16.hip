@@ -58,7 +58,11 @@ __host__ __device__ constexpr int taps_per_step(int ks, int cout, int ns) {
   const int t = ks * ks;
   // measured: ns = 3 is fastest at 1 (occupancy), 2 and 1 gain from grouping; one plane x 128 channels: 2 taps keep
   // the 4-image workgroups of the bf16-storage path at two per CU
-  const int want = ns == 3 ? 1 : (ns == 2 ? 2 : (cout == 128 ? 2 : ks));
+  // (one plane x 128 channels x 3x3: 3 taps = a kernel row per step -- 9 taps in 3 steps with no zero-padded tap slot,
+  //  where 2 per step cost a fifth step with one wasted tap; 61.6 KB of LDS, still two workgroups per CU: bf16-storage eval
+  //  14.3 -> 13.1 ms per six launches, same-box A/B.  The 64-channel one-plane 3x3 stays at 3: a whole block per step (9)
+  //  needs 79 KB and loses the third resident workgroup per CU, 6.7 -> 7.9 ms)
+  const int want = ns == 3 ? 1 : (ns == 2 ? 2 : (cout == 128 ? (ks == 3 ? 3 : 2) : ks));
   return want < t ? want : t;
 }
 
@@ -863,16 +867,11 @@ static int launch_b16(const ConvArgs& a, hipStream_t st) {
     // (a double-buffered halo for the 3x3 form of this variant measured slower: 3x3 64->64 6.9 -> 8.5 ms)
     hipLaunchKernelGGL((conv_mfma_split16_kernel<KS, COUT, 1, false, false, 1, false, true>), dim3(grid4), dim3(256), 0, st, a);
     return tsr_check_launch();
+  } else {        // 1x1: two images per workgroup
+    const int grid = ((a.B + 1) / 2) * a.tiles_x * a.tiles_y;
+    hipLaunchKernelGGL((conv_mfma_split16_kernel<KS, COUT, 1, false, false, 2, false, true>), dim3(grid), dim3(256), 0, st, a);
+    return tsr_check_launch();
   }
-  const int grid = ((a.B + 1) / 2) * a.tiles_x * a.tiles_y;
-  if constexpr (KS == 3) {
-    if (((a.cin >> 4) & 1) == 0) {
-      hipLaunchKernelGGL((conv_mfma_split16_kernel<KS, COUT, 1, false, false, 2, true, true>), dim3(grid), dim3(256), 0, st, a);
-      return tsr_check_launch();
-    }
-  }
-  hipLaunchKernelGGL((conv_mfma_split16_kernel<KS, COUT, 1, false, false, 2, false, true>), dim3(grid), dim3(256), 0, st, a);
-  return tsr_check_launch();
 }
 
 extern "C" int tsr_conv2d_fwd_b16(const void* in, int in_ctot, int in_coff, int cin,
