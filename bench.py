@@ -239,9 +239,13 @@ def small_batch_latency(dev, B=8, n=100):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
     plain, replay = lat(lambda: m(x)), lat(lambda: gf(x))
-    return {"metric": "eval forward latency at the reference's eval batch", "batch": B, "unit": "ms per forward (back to back)",
+    return {"metric": "SR samples/sec (4x4->40x40) at the reference's eval batch (test_batch_size = 8, config/default.py:47)",
+            "value": round(B / plain * 1e3, 1), "unit": "samples/s", "ms_per_step": round(plain, 4), "batch": B,
             "plain_launches_ms": round(plain, 4), "hip_graph_replay_ms": round(replay, 4),
-            "samples_per_s_plain": round(B / plain * 1e3, 1), "forwards_timed": n}
+            "samples_per_s_plain": round(B / plain * 1e3, 1), "forwards_timed": n,
+            "diagnosis": "latency-bound on the device, not launch-bound: ~45 dependent launches of ~20 us, each a single "
+                         "partial wave of workgroups (100 on 256 CUs) running its whole serial K loop; HIP-graph replay "
+                         "(hip_graph_replay_ms) removes the host but not that chain"}
 
 
 def run_infer(args, world, rank, dev):
