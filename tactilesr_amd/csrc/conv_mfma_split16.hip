@@ -61,8 +61,10 @@ __host__ __device__ constexpr int taps_per_step(int ks, int cout, int ns) {
   // (one plane x 128 channels x 3x3: 3 taps = a kernel row per step -- 9 taps in 3 steps with no zero-padded tap slot,
   //  where 2 per step cost a fifth step with one wasted tap; 61.6 KB of LDS, still two workgroups per CU: bf16-storage eval
   //  14.3 -> 13.1 ms per six launches, same-box A/B.  The 64-channel one-plane 3x3 stays at 3: a whole block per step (9)
-  //  needs 79 KB and loses the third resident workgroup per CU, 6.7 -> 7.9 ms)
-  const int want = ns == 3 ? 1 : (ns == 2 ? 2 : (cout == 128 ? (ks == 3 ? 3 : 2) : ks));
+  //  needs 79 KB and loses the third resident workgroup per CU, 6.7 -> 7.9 ms.  5x5 x 128 channels: 3 taps per step too --
+  //  9 steps with two padded tap slots (7 % more MFMAs) still beat 13 steps of 2: 24.5 -> 23.7 ms per six launches; a whole
+  //  kernel row per step (5, no padding) would need a 60 KB ring + the 30.7 KB halo: one workgroup per CU)
+  const int want = ns == 3 ? 1 : (ns == 2 ? 2 : (cout == 128 ? 3 : ks));
   return want < t ? want : t;
 }
 
