@@ -138,6 +138,8 @@ def main():
                          "powers of two and split into 2 fp16 planes, 3 f16-MFMA products (fp32-grade, default); "
                          "bf16x6 = 3 bf16 planes, 6 products (fp32-equivalent); f32 = fp32 MFMA; "
                          "bf16x3 / bf16 = reduced precision (not the headline)")
+    ap.add_argument("--no-fuse-pair", action="store_true",
+                    help="eval: two launches per MSRB stage 1 instead of the one-launch pair form (same arithmetic; A/B)")
     ap.add_argument("--seqs", action="store_true",
                     help="tactileSRSeqs shape (BASELINE configs[4]): TactileSR(scale_factor=25, seqsCnt=8), 4x4x24 -> "
                          "100x100, for --mode infer / train (default batch 512 / 256 per GPU)")
@@ -256,6 +258,8 @@ def run_infer(args, world, rank, dev):
     model, cin_lr, side, _, fwd_flop = make_model(args)
     model = model.to(dev).eval()
     model.conv_impl = args.impl
+    if args.no_fuse_pair:
+        model.fuse_pair = False
     B = args.batch if not (args.seqs and args.batch == 4096) else 512
     model.max_images_per_pass = B
     g = torch.Generator().manual_seed(42 + rank)

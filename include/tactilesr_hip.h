@@ -136,6 +136,14 @@ int tsr_conv2d_fwd_b16_fuse1x1(const void* in, int in_ctot, int in_coff, int cin
                                const void* res, int res_ctot, int res_coff,
                                void* out, int out_ctot, int out_coff, int relu2,
                                int B, int H, int W, void* stream);
+/* ... and the stage-1 pair of an MSRB on bf16 tensors: conv_3_1 || conv_5_1 (each conv + BN + ReLU,
+ * model/tactileSR_model.py:167-175) and the first torch.cat (:200) as ONE launch on one staged halo.  w_packed =
+ * tsr_pack_conv_weight_bf16s(W, cout = 128, cin, ks = 5, nsplit = 1) of W = cat([3x3 weight zero-padded to 5x5, 5x5
+ * weight]) along C_out; scale / shift = the two convs' folded BatchNorm vectors concatenated (128); out = 128 channels in
+ * torch.cat order.  The 3x3 half's MFMAs on the 16 outer taps are not issued. */
+int tsr_conv2d_fwd_b16_pair(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed,
+                            const float* scale, const float* shift, void* out, int out_ctot, int out_coff,
+                            int relu, int B, int H, int W, void* stream);
 int tsr_stem_fwd_b16(const float* lr, int lr_ctot, int lr_coff, int axis_cnt, int hin, int win, int sf,
                      const float* w_oihw, const float* scale, const float* shift,
                      void* out_bf16, int out_ctot, int out_coff, int relu, int B, void* stream);

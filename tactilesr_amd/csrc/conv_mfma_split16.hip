@@ -84,8 +84,15 @@ constexpr int row_slots(int hh, int pixs, int rmod) {
 // (pixel, channel quad), no conversion), the epilogue rounds to bf16 on store.  BASELINE's "bf16" configurations.
 // FUSE2 (fp16x3, C_out = 128, inference): the MSRB's 1x1 `confusion` half is applied to the tile before it leaves the
 // workgroup (conv_fuse1x1.h); out / res then describe the 64-channel result.
-template <int KS, int COUT, int NS, bool EXT, bool F16, int WN, bool DBH = false, bool IO16 = false, bool FUSE2 = false>
+// PAIR (bf16 storage, 5x5 geometry, 128 output channels, inference): the two stage-1 convolutions of an MSRB -- 3x3 64->64
+// and 5x5 64->64 on the SAME input (model/tactileSR_model.py:167-175,198-200) -- as one launch on one staged halo: a 5x5
+// conv to 128 channels whose first 64 (the 3x3 conv: C_out blocks 0, 1 of every wave) have no weight on the 16 outer taps;
+// on those taps neither their weight fragments are read nor their MFMAs issued.  `cat1` comes out in torch.cat order.
+template <int KS, int COUT, int NS, bool EXT, bool F16, int WN, bool DBH = false, bool IO16 = false, bool FUSE2 = false,
+          bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArgs a) {
+  static_assert(!PAIR || (KS == 5 && COUT == 128 && NS == 1 && IO16 && WN == 1 && !EXT && !FUSE2 && !DBH),
+                "pair form: bf16 storage, 5x5 geometry, 4 images x 128 channels");
   static_assert(!IO16 || (NS == 1 && !F16), "bf16 activation storage: plain bf16 operands");
   static_assert(!FUSE2 || (!EXT && COUT == 128 && ((NS == 2 && F16 && WN == 2 && !IO16) || (NS == 1 && IO16 && WN == 1))),
                 "fused 1x1: 128 channels, inference; fp16x3 (2 images / workgroup) or bf16 storage (4 images)");
@@ -334,7 +341,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
       _Pragma("unroll") for (int mb = 0; mb < 2; ++mb)                                   \
         fa[set][p][mb] = *(const PV8*)(halo + (hb_) * HALO_B + laneA + (4 * mb + (kh_)) * ROWB + (kw_) * PIXB + p * 32); \
       _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                  \
-        fb[set][p][nb] = *(const PV8*)(wb_ + laneB + p * (2 * COUT * 16) + nb * (32 * 16)); \
+        if (!PAIR || nb >= 2 || ((kh_) >= 1 && (kh_) <= 3 && (kw_) >= 1 && (kw_) <= 3))  \
+          fb[set][p][nb] = *(const PV8*)(wb_ + laneB + p * (2 * COUT * 16) + nb * (32 * 16)); \
     }                                                                                    \
   }
 
@@ -389,19 +397,27 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
           } else if (c + 1 < nchunk) {
             load_halo(c + 1, hv); // next block's slab: global loads fly under this tap's MFMAs
           }
+          // pair form: the 3x3 conv (C_out blocks 0, 1) has no weight outside the inner 3x3 taps
+          const int ckh = t / KS, ckw = t - ckh * KS;
+          const bool inner = !PAIR || (ckh >= 1 && ckh <= 3 && ckw >= 1 && ckw <= 3);
+          const int nkh1 = (t + 1) / KS, nkw1 = (t + 1) - nkh1 * KS;
+          const bool inner_next = !PAIR || t + 1 >= T || (nkh1 >= 1 && nkh1 <= 3 && nkw1 >= 1 && nkw1 <= 3);
 #pragma unroll
           for (int q = 0; q < NPROD; ++q)
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
               for (int nb = 0; nb < NB; ++nb)
-                acc[mb][nb] = Plane<F16>::mfma(fa[cur][PA[6 - NPROD + q]][mb], fb[cur][PB[6 - NPROD + q]][nb],
-                                               acc[mb][nb]);
+                if (inner || nb >= 2)
+                  acc[mb][nb] = Plane<F16>::mfma(fa[cur][PA[6 - NPROD + q]][mb], fb[cur][PB[6 - NPROD + q]][nb],
+                                                 acc[mb][nb]);
           if (PF && (t + 1 < T || DBH)) {
             // interleave the next tap's fragment reads with this tap's MFMAs (hipcc otherwise sinks all ds_reads
             // below the MFMA block, exposing their latency in front of the barrier's lgkmcnt(0) every step)
             constexpr int MFX = 1;
-            constexpr int NRD = NS * (2 + NB), NMF = NPROD * 2 * NB, PER = (NMF / NRD > 0 ? NMF / NRD : 1) * MFX;
+            // (compile-time group sizes: the pair form's half-work taps simply leave some groups unfilled)
+            constexpr int NRD = NS * (2 + NB), NMF = NPROD * 2 * NB, PER = PAIR ? 1 : (NMF / NRD > 0 ? NMF / NRD : 1) * MFX;
+            (void)inner_next;
 #pragma unroll
             for (int i = 0; i < NRD; ++i) {
               __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);   // MFMA
@@ -933,6 +949,27 @@ extern "C" int tsr_conv2d_fwd_b16_fuse1x1(const void* in, int in_ctot, int in_co
     hipLaunchKernelGGL((conv_mfma_split16_kernel<5, 128, 1, false, false, 1, false, true, true>), dim3(grid4), dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL((conv_mfma_split16_kernel<3, 128, 1, false, false, 1, false, true, true>), dim3(grid4), dim3(256), 0, st, a);
+  return tsr_check_launch();
+}
+
+// Stage-1 pair of an MSRB on bf16 tensors: w_packed = tsr_pack_conv_weight_bf16s(cat([zero-pad(w3 -> 5x5), w5]), cout 128,
+// ks 5, nsplit 1); scale / shift = the two convs' folded BatchNorm vectors concatenated; out = 128 channels in cat order.
+extern "C" int tsr_conv2d_fwd_b16_pair(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed,
+                                       const float* scale, const float* shift, void* out, int out_ctot, int out_coff,
+                                       int relu, int B, int H, int W, void* stream) {
+  if (!in || !w_packed || !out || B <= 0 || H <= 0 || W <= 0) return TSR_ERR_ARG;
+  if ((cin & 15) || (in_ctot & 15) || (in_coff & 15) || (out_ctot & 15) || (out_coff & 15) || cin <= 0 ||
+      in_coff + cin > in_ctot || out_coff + 128 > out_ctot)
+    return TSR_ERR_ARG;
+  ConvArgs a = {};
+  a.in = (const float*)in; a.in_ctot = in_ctot; a.in_coff = in_coff; a.cin = cin;
+  a.wp = (const float*)w_packed; a.scale = scale; a.shift = shift;
+  a.out = (float*)out; a.out_ctot = out_ctot; a.out_coff = out_coff; a.relu = relu;
+  a.B = B; a.H = H; a.W = W;
+  a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8;
+  const int grid4 = ((B + 3) / 4) * a.tiles_x * a.tiles_y;
+  hipLaunchKernelGGL((conv_mfma_split16_kernel<5, 128, 1, false, false, 1, false, true, false, true>), dim3(grid4), dim3(256), 0,
+                     (hipStream_t)stream, a);
   return tsr_check_launch();
 }
 

@@ -261,6 +261,26 @@ class _PackedPair:
         self.shift = torch.cat([sh3, sh5])[self.perm].contiguous()
 
 
+class _PackedPairB16:
+    """Stage-1 pair of an MSRB for the bf16-storage path: ONE 5x5 conv to 128 channels whose first 64 output channels are
+    conv_3_1 (its 3x3 weight zero-padded to 5x5; the kernel skips those taps) and whose last 64 are conv_5_1 -- packed by
+    the ordinary one-plane pack -- with the two folded BatchNorm vectors concatenated.  `cat1` comes out in torch.cat order."""
+    __slots__ = ("w", "scale", "shift", "cin")
+
+    def __init__(self, seq3: nn.Sequential, seq5: nn.Sequential):
+        w3 = seq3[0].weight.detach().float()
+        w5 = seq5[0].weight.detach().float()
+        self.cin = w3.shape[1]
+        w = torch.cat([torch.nn.functional.pad(w3, (1, 1, 1, 1)), w5], dim=0).contiguous()
+        n = _lib.load().tsr_conv_weight_bf16s_elems(128, self.cin, 5, 1)
+        self.w = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+        call("tsr_pack_conv_weight_bf16s", ptr(w), ptr(self.w), _I(128), _I(self.cin), _I(5), _I(1), stream())
+        s3, sh3 = _fold(seq3[0].bias, seq3[1], 64, w.device)
+        s5, sh5 = _fold(seq5[0].bias, seq5[1], 64, w.device)
+        self.scale = torch.cat([s3, s5]).contiguous()
+        self.shift = torch.cat([sh3, sh5]).contiguous()
+
+
 class _PackedHalf:
     """One 64x128x1x1 half of an MSRB's `confusion` weight in the fp16 two-plane pack (fused 1x1 epilogue)."""
     __slots__ = ("w", "w_inv_scale")
@@ -403,6 +423,12 @@ class TactileSR(nn.Module):
                               _PackedConv(blk.conv_5_2[0], blk.conv_5_2[1], ns, cin_perm=pair.perm),
                               _PackedConv(blk.confusion, None, ns), halves))
                 continue
+            if self.fuse_pair and self.conv_impl == "bf16":
+                # bf16 storage: the same one-launch stage 1 (natural channel order: nothing to permute downstream)
+                msrbs.append((_PackedPairB16(blk.conv_3_1, blk.conv_5_1), None,
+                              _PackedConv(blk.conv_3_2[0], blk.conv_3_2[1], ns), _PackedConv(blk.conv_5_2[0], blk.conv_5_2[1], ns),
+                              _PackedConv(blk.confusion, None, ns), halves))
+                continue
             msrbs.append((_PackedConv(blk.conv_3_1[0], blk.conv_3_1[1], ns), _PackedConv(blk.conv_5_1[0], blk.conv_5_1[1], ns),
                           _PackedConv(blk.conv_3_2[0], blk.conv_3_2[1], ns), _PackedConv(blk.conv_5_2[0], blk.conv_5_2[1], ns),
                           _PackedConv(blk.confusion, None, ns), halves))
@@ -453,9 +479,13 @@ class TactileSR(nn.Module):
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        call("tsr_conv2d_fwd_f16s_pair", ptr(src), _I(64), _I(0), _I(pp.cin), ptr(pp.w), _lib.c_float(pp.w_inv_scale),
-             ptr(amax_in), ptr(amax_out), ptr(pp.scale), ptr(pp.shift), ptr(dst), _I(128), _I(0), _I(1),
-             _I(B), _I(H), _I(W), stream())
+        if isinstance(pp, _PackedPairB16):
+            call("tsr_conv2d_fwd_b16_pair", ptr(src), _I(64), _I(0), _I(pp.cin), ptr(pp.w), ptr(pp.scale), ptr(pp.shift),
+                 ptr(dst), _I(128), _I(0), _I(1), _I(B), _I(H), _I(W), stream())
+        else:
+            call("tsr_conv2d_fwd_f16s_pair", ptr(src), _I(64), _I(0), _I(pp.cin), ptr(pp.w), _lib.c_float(pp.w_inv_scale),
+                 ptr(amax_in), ptr(amax_out), ptr(pp.scale), ptr(pp.shift), ptr(dst), _I(128), _I(0), _I(1),
+                 _I(B), _I(H), _I(W), stream())
         if prof is not None:
             e1.record()
             prof.setdefault(("pair", 128), []).append((e0, e1))

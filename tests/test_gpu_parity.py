@@ -757,6 +757,60 @@ def test_conv2d_stage1_pair_kernel(T, cin, B, H, W):
     assert abs(float(amax_out) - float(got.abs().max())) == 0.0
 
 
+@pytest.mark.parametrize("cin,B,H,W", [(64, 5, 40, 40), (64, 2, 13, 21), (32, 1, 100, 100)])
+def test_conv2d_stage1_pair_kernel_bf16_storage(T, cin, B, H, W):
+    """tsr_conv2d_fwd_b16_pair: conv3x3 || conv5x5 (+ folded BN + ReLU) of one bf16 input as ONE launch (the 3x3 half's
+    outer-tap MFMAs are skipped), output = torch.cat order as a bf16 tensor.  Yardstick: fp64 convolutions of the
+    bf16-ROUNDED input and weights (exact products, wide accumulation) rounded to bf16 once -- the device differs only by its
+    fp32 accumulation order: >= 99 % of the elements identical, the rest within one bf16 ulp; and the result equals the
+    two-launch form (tsr_conv2d_fwd_b16 twice) up to the same one-ulp rounding-boundary flips."""
+    from tactilesr_amd._lib import call, ptr, stream, load, c_int as I
+    g = torch.Generator().manual_seed(cin + 7 * B + H)
+    x = (torch.randn(B, cin, H, W, generator=g).clamp_(min=0) * 3).bfloat16()
+    w3 = torch.randn(64, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    w5 = torch.randn(64, cin, 5, 5, generator=g) * (2.0 / (cin * 25)) ** 0.5
+    scale, shift = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.3
+    xq, w3q, w5q = x.double(), w3.bfloat16().double(), w5.bfloat16().double()
+    ref = torch.cat([F.conv2d(xq, w3q, padding=1), F.conv2d(xq, w5q, padding=2)], 1)
+    ref = F.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)).float().bfloat16()
+
+    def cb16_bf16(t):        # NCHW bf16 -> CB16 bf16
+        return T.to_cb16(t.float().cuda()).to(torch.bfloat16)
+
+    def pack(w, cout, ks):
+        n = load().tsr_conv_weight_bf16s_elems(cout, cin, ks, 1)
+        wp = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+        wd = w.cuda().contiguous()
+        call("tsr_pack_conv_weight_bf16s", ptr(wd), ptr(wp), I(cout), I(cin), I(ks), I(1), stream())
+        torch.cuda.synchronize()
+        return wp
+    xin = cb16_bf16(x)
+    wpair = pack(torch.cat([F.pad(w3, (1, 1, 1, 1)), w5], 0), 128, 5)
+    sc, sh = scale.cuda(), shift.cuda()
+    out = torch.empty(B * 128 * H * W, dtype=torch.bfloat16, device="cuda")
+    call("tsr_conv2d_fwd_b16_pair", ptr(xin), I(cin), I(0), I(cin), ptr(wpair), ptr(sc), ptr(sh), ptr(out), I(128), I(0), I(1),
+         I(B), I(H), I(W), stream())
+    got = T.from_cb16(out, B, 128, H, W).cpu()
+    ulp = (ref.float().abs() * 2.0 ** -7).clamp_min(1e-30)
+    d = (got - ref.float()).abs()
+    same = float((d == 0).float().mean())
+    # (near the ReLU's zero the output's own ulp is far smaller than the fp32 accumulation noise of the pre-activation:
+    #  there the bar is 3e-6 of the tensor maximum)
+    floor = 3e-6 * float(ref.float().abs().max())
+    bad = d > torch.maximum(1.01 * ulp, torch.full_like(ulp, floor))
+    print(f"[pair bf16] {cin}->64||64 B={B} {H}x{W}: identical {same:.5f}, beyond one ulp / the fp32-noise floor: {int(bad.sum())}")
+    assert same >= 0.99 and not bad.any()
+    # two-launch form into the two halves of the same buffer
+    out2 = torch.empty_like(out)
+    w3p, w5p = pack(w3, 64, 3), pack(w5, 64, 5)
+    for wp_, ks, off in ((w3p, 3, 0), (w5p, 5, 64)):
+        call("tsr_conv2d_fwd_b16", ptr(xin), I(cin), I(0), I(cin), ptr(wp_), I(64), I(ks), ptr(sc[off:off + 64]),
+             ptr(sh[off:off + 64]), ptr(None), I(0), I(0), ptr(out2), I(128), I(off), I(1), I(B), I(H), I(W), stream())
+    got2 = T.from_cb16(out2, B, 128, H, W).cpu()
+    d2 = (got - got2).abs()
+    assert float((d2 == 0).float().mean()) >= 0.99 and not (d2 > torch.maximum(1.01 * ulp, torch.full_like(ulp, floor))).any()
+
+
 def test_pair_and_two_launch_stage1_paths_agree(T, golden):
     """The whole eval forward with the stage-1 pair kernel (default) and with two launches per stage (the stage-2 weights
     then see their input channels in the other order)."""

@@ -2,18 +2,21 @@
 # Profile recipe of a round (run on the GPU box through gpurun; outputs under gpurun_out/prof_$TAG, condensed into
 # profiles/ by tools/summarize_prof.py).  Kernel timing and PMC counters are collected in SEPARATE runs; FETCH_SIZE and
 # WRITE_SIZE in separate passes (TCC slot limit); the program itself follows `--` (no env/bash hop under rocprofv3).
-#   usage: tools/collect_profiles.sh r02
+#   usage: tools/collect_profiles.sh r02 [groups]     groups: any of "eval train bf16 trainbf16 tpsf" (default all; a second
+#   call with other groups adds to the same directory -- one gpurun call is limited to 20 minutes)
 set -e -o pipefail
 TAG=${1:-rXX}
+GROUPS_=${2:-eval train bf16 trainbf16 tpsf}
 OUT=gpurun_out/prof_$TAG
-rm -rf $OUT
 mkdir -p $OUT
 # what the counters were taken on: bench.py nulls roofline.traffic when the kernel sources no longer match
 python3 -c "import json,sys; sys.path.insert(0,'.'); from tactilesr_amd import build as b; json.dump({'csrc_sha16': b.source_hash()}, open('$OUT/meta.json','w'))"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 run() {  # name, rocprof args..., -- bench args
   local name=$1; shift
+  case " $GROUPS_ " in *" ${name%%_*} "*) ;; *) return 0;; esac
   echo "== $name"
+  rm -rf $OUT/$name
   rocprofv3 "$@" > $OUT/$name.log 2>&1
 }
 EVAL="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-legs"
