@@ -113,13 +113,18 @@ def pmc_traffic(kernel_substr, mode="eval"):
     d = json.load(open(files[-1]))
     rel = os.path.relpath(files[-1], REPO)
     from tactilesr_amd import build as _b
-    took, now = d.get("_meta", {}).get("csrc_sha16"), _b.source_hash()
-    if took != now:
-        # the kernels changed since the counters were collected (or the pass predates the hash): do not quote them
-        return None, f"stale: {rel} was collected on kernel sources {took}, this build is {now} -- re-collect (tools/collect_profiles.sh)"
+    took = d.get("_meta", {}).get("files")
+    if not took:
+        return None, f"stale: {rel} predates the source hashes -- re-collect (tools/collect_profiles.sh)"
+    # the counters are quoted only while the file that defines the kernel and every shared header are what they were
+    # when the pass was taken
+    now = _b.kernel_source_state(kernel_substr)
+    changed = sorted(f for f, v in now.items() if took.get(f) != v)
+    if changed:
+        return None, f"stale: {', '.join(changed)} changed since {rel} was collected -- re-collect (tools/collect_profiles.sh)"
     for k, v in d.items():
         if not k.startswith("_") and kernel_substr in k and "hbm_bytes_per_launch" in v:
-            return v["hbm_bytes_per_launch"], f"{rel} (kernel '{k}', sources {took}, commit {d['_meta'].get('summarized_at_commit')})"
+            return v["hbm_bytes_per_launch"], f"{rel} (kernel '{k}', sources unchanged, commit {d['_meta'].get('summarized_at_commit')})"
     return None, f"no kernel matching '{kernel_substr}' in {rel}"
 
 
@@ -526,8 +531,9 @@ def tpsf_traffic(B):
         return None
     d = json.load(open(files[-1]))
     from tactilesr_amd import build as _b
-    if d.get("_meta", {}).get("csrc_sha16") != _b.source_hash():
-        return None                      # kernels changed since the pass: stale
+    took = d.get("_meta", {}).get("files") or {}
+    if any(took.get(f) != v for f, v in _b.kernel_source_state("tpsf_fwd_mfma_kernel").items()):
+        return None                      # kernel source changed since the pass: stale
     for k, v in d.items():
         if "tpsf_fwd" in k and "hbm_bytes_per_launch" in v:
             return v["hbm_bytes_per_launch"]

@@ -42,6 +42,32 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
+def source_hashes() -> dict:
+    """{file name: sha256[:16]} of every kernel source and header: a PMC profile records them, and bench.py quotes a
+    kernel's measured HBM traffic only while the file that defines the kernel and every shared header are unchanged."""
+    import hashlib
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    out = {}
+    for d in (CSRC, inc):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".h")):
+                out[f] = hashlib.sha256(open(os.path.join(d, f), "rb").read()).hexdigest()[:16]
+    return out
+
+
+def kernel_source_state(kernel_name: str, hashes: dict = None) -> dict:
+    """The subset of `source_hashes()` a kernel's code depends on: the .hip file that defines it + the csrc headers (the
+    public include/tactilesr_hip.h holds declarations and two host-facing structs; a new entry point there does not
+    change a kernel)."""
+    h = source_hashes() if hashes is None else hashes
+    base = kernel_name.split("<")[0].split("(")[0].replace("void ", "").strip()
+    dep = {f: v for f, v in h.items() if f.endswith(".h") and f != "tactilesr_hip.h"}
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(".hip") and base and base in open(os.path.join(CSRC, f)).read():
+            dep[f] = h.get(f)
+    return dep
+
+
 def _newer(path, deps):
     if not os.path.exists(path):
         return True

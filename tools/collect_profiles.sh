@@ -10,7 +10,7 @@ GROUPS_=${2:-eval train bf16 trainbf16 tpsf}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 # what the counters were taken on: bench.py nulls roofline.traffic when the kernel sources no longer match
-python3 -c "import json,sys; sys.path.insert(0,'.'); from tactilesr_amd import build as b; json.dump({'csrc_sha16': b.source_hash()}, open('$OUT/meta.json','w'))"
+python3 -c "import json,sys; sys.path.insert(0,'.'); from tactilesr_amd import build as b; json.dump({'csrc_sha16': b.source_hash(), 'files': b.source_hashes()}, open('$OUT/meta.json','w'))"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 run() {  # name, rocprof args..., -- bench args
   local name=$1; shift
