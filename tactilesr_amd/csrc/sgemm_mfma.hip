@@ -14,6 +14,9 @@
 // barrier per step).  blockIdx.z = K range (split-K partial sums for the reductions over the batch): partial s lands at
 // C + s * split_stride, to be added in a fixed order by tsr_reduce_splits (deterministic, no float atomics).
 // Operands whose unit-stride dimension is not 16-B loadable (ragged K, odd strides) take the scalar generic path.
+// Measured at B = 8192 (tools/sgemm_microbench.py): the six 8192 x 1024 x 256-sized GEMMs of a train step 53-65 us each =
+// 66-81 TF (the single-launch 64 x 64 x 16 kernel it replaces: 46-64 TF); K steps of 16, 64-row tiles everywhere and both
+// together measured 2-7 % slower (same-box A/B).
 #include "tsr_common.h"
 #include "tactilesr_hip.h"
 
