@@ -87,7 +87,7 @@ for mode in ("eval", "train", "tpsf", "bf16", "trainbf16"):
         json.dump(out, open(os.path.join(dst, name), "w"), indent=1, sort_keys=True)
 
 sq = {}
-for mode in ("eval", "train"):
+for mode in ("eval", "train", "bf16"):
     for k, d in collect([f"{mode}_sq"]).items():
         e = {c: per_launch(v)[0] for c, v in d.items()}
         wc = e.get("SQ_WAVE_CYCLES")
