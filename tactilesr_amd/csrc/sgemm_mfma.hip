@@ -276,30 +276,37 @@ extern "C" int tsr_sgemm_splitk_strided(const float* A, long long sa0, long long
   return sgemm_dispatch(g, nsplit, (hipStream_t)stream);
 }
 
-// Column sums over a row range per split (db = 1^T dy): slab[s * split_stride + j] = sum_{i in range s} Y[i][j], rows
-// walked in order by one thread per column (coalesced 256-B reads per wave and row); same K ranges as the split-K GEMM.
+// Column sums over a row range per split (db = 1^T dy): slab[s * split_stride + j] = sum_{i in range s} Y[i][j]; same K
+// ranges as the split-K GEMM.  A workgroup owns 64 columns of one range: 4 row phases x 64 columns (a wave reads one
+// 256-B row segment per instruction), four independent chains per thread, the phases added in a fixed order through LDS
+// (deterministic).  (One thread per column over the whole range left N = 1024 with 128 latency-bound workgroups: 19 us.)
 __global__ __launch_bounds__(256) void colsum_splitk_kernel(const float* __restrict__ Y, float* __restrict__ slab,
                                                             long split_stride, int M, int N, int kchunk) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float part[4][64];
+  const int c = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
   const int r0 = blockIdx.y * kchunk;
   const int r1 = r0 + kchunk < M ? r0 + kchunk : M;
-  if (j >= N) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int i = r0;
-  for (; i + 3 < r1; i += 4) {
-    s0 += Y[(size_t)i * N + j];
-    s1 += Y[(size_t)(i + 1) * N + j];
-    s2 += Y[(size_t)(i + 2) * N + j];
-    s3 += Y[(size_t)(i + 3) * N + j];
+  if (j < N) {
+    int i = r0 + ph;
+    for (; i + 12 < r1; i += 16) {
+      s0 += Y[(size_t)i * N + j];
+      s1 += Y[(size_t)(i + 4) * N + j];
+      s2 += Y[(size_t)(i + 8) * N + j];
+      s3 += Y[(size_t)(i + 12) * N + j];
+    }
+    for (; i < r1; i += 4) s0 += Y[(size_t)i * N + j];
   }
-  for (; i < r1; ++i) s0 += Y[(size_t)i * N + j];
-  slab[(size_t)blockIdx.y * split_stride + j] = (s0 + s1) + (s2 + s3);
+  part[ph][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ph == 0 && j < N) slab[(size_t)blockIdx.y * split_stride + j] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
 }
 
 extern "C" int tsr_colsum_splitk(const float* Y, float* slab, long long split_stride, int M, int N, int nsplit,
                                  void* stream) {
   if (!Y || !slab || M <= 0 || N <= 0 || nsplit <= 0 || nsplit > 65535 || split_stride < N) return TSR_ERR_ARG;
-  hipLaunchKernelGGL(colsum_splitk_kernel, dim3((N + 255) / 256, nsplit), dim3(256), 0, (hipStream_t)stream, Y, slab,
+  hipLaunchKernelGGL(colsum_splitk_kernel, dim3((N + 63) / 64, nsplit), dim3(256), 0, (hipStream_t)stream, Y, slab,
                      (long)split_stride, M, N, splitk_chunk(M, nsplit));
   return tsr_check_launch();
 }
