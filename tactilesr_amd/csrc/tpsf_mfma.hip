@@ -434,10 +434,15 @@ __global__ __launch_bounds__(256) void tpsf_bwd_pool_kernel(const float* __restr
     const float* dp = depth + (size_t)b * NPIX;
     const float* hp = HR + (size_t)b * NPIX;
     float mx = -INFINITY;                // pass 1: the plateau threshold (the rows are re-read from L2 in pass 2)
-#pragma unroll 8
-    for (int k = 0; k < 40; ++k) {
-      const int p = tid + 256 * k;
-      mx = fmaxf(mx, p < NPIX ? dp[p] : -INFINITY);
+    {
+      const f32x4* dp4 = (const f32x4*)dp;             // 40,000 B per sample: 16-B aligned; 2,500 quads, 10 per thread
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        const int q = tid + 256 * k;
+        const f32x4 v = dp4[q < NPIX / 4 ? q : 0];
+        const float m4 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        mx = fmaxf(mx, q < NPIX / 4 ? m4 : -INFINITY);
+      }
     }
     for (int i = tid; i < 400; i += 256) {
       const int a = i / 100, x = i - a * 100;
@@ -470,7 +475,7 @@ __global__ __launch_bounds__(256) void tpsf_bwd_pool_kernel(const float* __restr
     for (int k = 0; k < 40; ++k) {
       const int p = tid + 256 * k;
       if (p < NPIX) {
-        const int y = p / HS, x = p - y * HS;
+        const int y = (int)(((unsigned)p * 5243u) >> 19), x = p - y * HS;      // p / 100 for p < 43,698
         const float v = hp[p];                                   // stored HR: the plateau already holds its fill value
         const float ey[4] = {ea[y], ea[100 + y], ea[200 + y], ea[300 + y]};
         const float ey2[4] = {ea2[y], ea2[100 + y], ea2[200 + y], ea2[300 + y]};
@@ -500,8 +505,24 @@ __global__ __launch_bounds__(256) void tpsf_bwd_pool_kernel(const float* __restr
       for (int c = 0; c < 4; ++c) { vals[a * 4 + c] = (double)S[a][c]; vals[16 + a * 4 + c] = (double)Sd[a][c]; }
     vals[32] = (double)s0;
     vals[33] = (double)da;
+    // wave sums.  The 32 mask sums go through a reduce-SCATTER butterfly: at offset 32 a lane sends the half of its values
+    // its partner keeps and adds the half it receives, and so on down to offset 2 -- 16 + 8 + 4 + 2 + 1 exchanges -- after
+    // which lane l holds value (l >> 1) summed over half the wave, and one more exchange finishes it: 32 double shuffles
+    // instead of 32 x 6 (fixed order: deterministic).  s0 and da take the plain 6-step reduction.
 #pragma unroll
-    for (int i = 0; i < 34; ++i) {
+    for (int half = 16, o = 32; half >= 1; half >>= 1, o >>= 1) {
+      const bool up = (lane & o) != 0;
+#pragma unroll
+      for (int j = 0; j < half; ++j) {
+        const double send = up ? vals[j] : vals[j + half];
+        const double keep = up ? vals[j + half] : vals[j];
+        vals[j] = keep + __shfl_xor(send, o);
+      }
+    }
+    vals[0] += __shfl_xor(vals[0], 1);
+    if ((lane & 1) == 0) redd[w * 34 + (lane >> 1)] = vals[0];
+#pragma unroll
+    for (int i = 32; i < 34; ++i) {
       double v = vals[i];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -532,7 +553,7 @@ __global__ __launch_bounds__(256) void tpsf_bwd_pool_kernel(const float* __restr
 }
 
 #ifndef TPSF_BWD_OCC
-#define TPSF_BWD_OCC 2
+#define TPSF_BWD_OCC 1      // one workgroup per CU: the 512-register budget holds the prefetched weights + depth rows unspilled
 #endif
 // (no __restrict__ on the inputs: hipcc treats loads through restrict-const pointers as invariant, hoists the 128 weight
 // loads of the two reductions and the depth rows of the second row GEMM to the top of the sample iteration -- across the
@@ -618,29 +639,41 @@ __global__ __launch_bounds__(256, TPSF_BWD_OCC) void tpsf_bwd_dhb_kernel(const f
     __syncthreads();                                                      // (2) table copies
 
     // sum over this lane's accumulator pixels of wgt * acc (wgt is 0 on the plateau; rows / columns outside the image
-    // are masked: their accumulators hold finite garbage of the padded GEMM)
+    // are masked: their accumulators hold finite garbage of the padded GEMM).  The 64 weights of a lane are REQUESTED
+    // BEFORE the column GEMM whose accumulators they multiply (load_w) and consumed after it (dot_w): loaded row by row
+    // inside the reduction each of the 16 rows paid a full memory round trip -- 2 x 16 of them per sample, more than the
+    // four GEMMs together (SQ counters: the waves of this kernel were parked 71 % of their cycles).  During the column
+    // GEMM the row operands' planes are dead, so the 64 registers are there.
     int li_o = li, h_o = h;
     asm volatile("" : "+v"(li_o), "+v"(h_o));
     const float* wp = wgt + (size_t)b * NPIX;
-    auto dot_w = [&](const f32x16 (&ac)[4]) {
+    float wv[16][4];
+    auto load_w = [&]() {
       const int yb = 32 * w + 4 * h_o;
       const int x3 = 96 + li_o < HS ? 96 + li_o : HS - 1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int yy = yb + (r & 3) + 8 * (r >> 2);
+        const unsigned ro = (unsigned)((yy < HS ? yy : HS - 1) * HS);      // uniform base + 32-bit lane offset
+        wv[r][0] = wp[ro + (unsigned)li_o];
+        wv[r][1] = wp[ro + 32u + (unsigned)li_o];
+        wv[r][2] = wp[ro + 64u + (unsigned)li_o];
+        wv[r][3] = wp[ro + (unsigned)x3];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto dot_w = [&](const f32x16 (&ac)[4]) {
+      const int yb = 32 * w + 4 * h_o;
       const float ok3 = 96 + li_o < HS ? 1.f : 0.f;
       float part = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int yy = yb + (r & 3) + 8 * (r >> 2);
-        const float* wr = wp + (yy < HS ? yy : HS - 1) * HS;
         const float rowok = yy < HS ? 1.f : 0.f;
-        const float w0 = wr[li_o], w1 = wr[32 + li_o], w2 = wr[64 + li_o], w3 = wr[x3];
-        part = fmaf(w0 * rowok, ac[0][r], part);
-        part = fmaf(w1 * rowok, ac[1][r], part);
-        part = fmaf(w2 * rowok, ac[2][r], part);
-        part = fmaf(w3 * (rowok * ok3), ac[3][r], part);
-        // pin the partial sum here: LLVM otherwise SINKS the whole multiply-add chain of the first reduction to the end of
-        // the sample iteration (its only use), keeping 64 loaded weights (through scratch) and a second accumulator set alive
-        asm volatile("" : "+v"(part) : : "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        part = fmaf(wv[r][0] * rowok, ac[0][r], part);
+        part = fmaf(wv[r][1] * rowok, ac[1][r], part);
+        part = fmaf(wv[r][2] * rowok, ac[2][r], part);
+        part = fmaf(wv[r][3] * (rowok * ok3), ac[3][r], part);
       }
       return part;
     };
@@ -654,13 +687,16 @@ __global__ __launch_bounds__(256, TPSF_BWD_OCC) void tpsf_bwd_dhb_kernel(const f
     }
     if (w < 3) store_rt<false>(acc, sRg / (sD * G_SCALE), RT, w, h, li);
     else store_rt<true>(acc, sRg / (sD * G_SCALE), RT, w, h, li);
+    // the depth rows again for the second product (L2): requested here, a whole column GEMM ahead of their use (neither
+    // they nor their planes are kept across the first product)
+    load_depth(b);
+    load_w();
     __syncthreads();                                                      // (3) R^T = Rg
     zero_acc(acc);
     gemm_toeplitz_rt(acc, Th, RT, laneT, w, h, li);                       // H Rg, scale sH * sRg
     double db = (double)dot_w(acc) / ((double)sH * (double)sRg);
     __syncthreads();                                                      // (4) every wave is done with Rg
     {
-      load_depth(b);             // the rows again (L2): neither they nor their planes are kept across the first product
       f16x8 a_hi[7], a_lo[7];
       depth_planes(a_hi, a_lo);
       zero_acc(acc);
@@ -668,11 +704,12 @@ __global__ __launch_bounds__(256, TPSF_BWD_OCC) void tpsf_bwd_dhb_kernel(const f
     }
     if (w < 3) store_rt<false>(acc, sRh / (sD * sH), RT, w, h, li);
     else store_rt<true>(acc, sRh / (sD * sH), RT, w, h, li);
+    if (b + (int)gridDim.x < B) load_depth(b + gridDim.x);               // the planes are dead: the next sample's rows
+    load_w();
     __syncthreads();                                                      // (5) R^T = Rh
     zero_acc(acc);
     gemm_toeplitz_rt(acc, Tg, RT, laneT, w, h, li);                       // G Rh, scale 2^13 * sRh
     db += (double)dot_w(acc) / ((double)G_SCALE * (double)sRh);
-    if (b + (int)gridDim.x < B) load_depth(b + gridDim.x);               // planes and accumulators are dead: next rows
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) db += __shfl_xor(db, o);
     if (lane == 0) redd[w] = db;
