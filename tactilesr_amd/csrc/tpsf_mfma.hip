@@ -416,8 +416,11 @@ __global__ __launch_bounds__(256, TPSF_FWD_OCC) void tpsf_fwd_mfma_kernel(const 
 //         -(d/dc)(G D G) = H D G + G D H,   c = Kp / b^2,
 //     four Toeplitz GEMMs on the matrix cores (Rg = D G -> LDS, H Rg; Rh = D H -> LDS, G Rh), each product reduced against
 //     wgt straight from its accumulator (the sum is linear in dhb, so the two terms never have to be added
-//     element-wise: ONE accumulator set is live at a time), depth planes kept in registers across both row GEMMs.
-//     58 KB of LDS and < 256 VGPRs: two workgroups per CU.
+//     element-wise: ONE accumulator set is live at a time).  Round 4: ONE workgroup per CU (512-register budget): the 64
+//     weights a lane multiplies its accumulators with, and the depth rows of the next row GEMM, are requested a whole
+//     column GEMM ahead of their use and held in registers unspilled -- loaded row by row inside the reduction each of
+//     the 2 x 16 weight rows per sample paid a full memory round trip (waves parked 71 % of their cycles): 0.76 -> 0.51 ms
+//     per 8192 samples (the kernel had measured the same at one and at two workgroups per CU before).
 __global__ __launch_bounds__(256) void tpsf_bwd_pool_kernel(const float* __restrict__ depth, const float* __restrict__ ab,
                                                             const float* __restrict__ HR, const float* __restrict__ dLRd,
                                                             float* __restrict__ dab, float* __restrict__ wgt, int B) {
