@@ -23,6 +23,8 @@ import shutil
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
+only = set(sys.argv[3].split()) if len(sys.argv) > 3 else None      # e.g. "tpsf": re-summarise that group only (its raw
+#                                   data was re-collected on newer sources; the other groups keep their recorded hashes)
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 os.makedirs(dst, exist_ok=True)
 
@@ -39,6 +41,8 @@ def files(run, suffix):
 
 
 for run in sorted(os.listdir(src)):
+    if only is not None and run.split("_")[0] not in only:
+        continue
     if run.endswith("_stats") and os.path.isdir(os.path.join(src, run)):
         for f in files(run, "_kernel_stats.csv"):
             shutil.copy(f, os.path.join(dst, f"{tag}_{run[:-6]}_kernel_stats.csv"))
@@ -73,6 +77,8 @@ def per_launch(v):
 
 
 for mode in ("eval", "train", "tpsf", "bf16", "trainbf16"):
+    if only is not None and mode not in only:
+        continue
     out = {}
     for k, d in collect([f"{mode}_fetch", f"{mode}_write"]).items():
         e = {}
@@ -99,7 +105,7 @@ for mode in ("eval", "train", "bf16"):
             e["lds_bank_conflict_share_of_lds_cycles"] = (e.get("SQ_LDS_BANK_CONFLICT", 0) / e["SQ_LDS_IDX_ACTIVE"]
                                                          if e.get("SQ_LDS_IDX_ACTIVE") else None)
         sq[f"{mode}: {k}"] = e
-if sq:
+if sq and only is None:
     json.dump(sq, open(os.path.join(dst, f"{tag}_sq_summary.json"), "w"), indent=1, sort_keys=True)
 print("wrote", sorted(f for f in os.listdir(dst) if f.startswith(tag)))
 
@@ -116,6 +122,6 @@ for mode in ("eval", "train"):
     for k, v in per.items():
         clk[f"{mode}: {k}"] = {"effective_clock_GHz": round(sum(x for x, _ in v) / len(v), 3),
                                "avg_launch_ms": round(sum(d for _, d in v) / len(v) / 1e6, 3), "launches": len(v)}
-if clk:
+if clk and only is None:
     json.dump(clk, open(os.path.join(dst, f"{tag}_clock_summary.json"), "w"), indent=1, sort_keys=True)
     print("wrote", f"{tag}_clock_summary.json")
