@@ -56,15 +56,22 @@ def source_hashes() -> dict:
 
 
 def kernel_source_state(kernel_name: str, hashes: dict = None) -> dict:
-    """The subset of `source_hashes()` a kernel's code depends on: the .hip file that defines it + the csrc headers (the
-    public include/tactilesr_hip.h holds declarations and two host-facing structs; a new entry point there does not
-    change a kernel)."""
+    """The subset of `source_hashes()` a kernel's code depends on: the .hip file that defines it + the transitive closure
+    of the csrc headers that file includes (the public include/tactilesr_hip.h holds declarations and two host-facing
+    structs; a new entry point there does not change a kernel)."""
+    import re
     h = source_hashes() if hashes is None else hashes
     base = kernel_name.split("<")[0].split("(")[0].replace("void ", "").strip()
-    dep = {f: v for f, v in h.items() if f.endswith(".h") and f != "tactilesr_hip.h"}
+    dep, todo = {}, []
     for f in sorted(os.listdir(CSRC)):
         if f.endswith(".hip") and base and base in open(os.path.join(CSRC, f)).read():
-            dep[f] = h.get(f)
+            todo.append(f)
+    while todo:
+        f = todo.pop()
+        if f in dep or f == "tactilesr_hip.h" or not os.path.exists(os.path.join(CSRC, f)):
+            continue
+        dep[f] = h.get(f)
+        todo += re.findall(r'#include\s+"([^"]+)"', open(os.path.join(CSRC, f)).read())
     return dep
 
 

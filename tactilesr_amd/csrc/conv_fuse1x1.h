@@ -222,14 +222,39 @@ __device__ __forceinline__ void conv_fuse1x1_b16_epilogue(const ConvArgs& a, f32
       else rvv[n2][t] = (fz_bf16x4){(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
     }
   }
+  // Everything the epilogue reads from global memory is requested HERE, in one round trip: the BatchNorm vectors of all four
+  // 32-channel blocks, the output stage's shift, and the W2 fragments of the first half (the second half's are requested
+  // as soon as the first half's accumulators are parked and their registers free).  Loaded where they were used -- a
+  // scale / shift pair per block, a W2 fragment pair per K step right in front of its MFMAs -- each was a full L2 round
+  // trip in a workgroup that has no MFMA work to cover it: s_memtime stamps put this epilogue at 26-28 k cycles, 40 % of the
+  // 3x3 launch's workgroup time (fp16x3 form, which prefetches: 18 k).
+  float bsc[4], bsh[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    bsc[nb] = a.scale ? a.scale[nb * 32 + li] : 1.f;
+    bsh[nb] = a.shift ? a.shift[nb * 32 + li] : 0.f;
+  }
+  f32x4 osh[2];
+#pragma unroll
+  for (int n2 = 0; n2 < 2; ++n2)
+    osh[n2] = a.shift2 ? *(const f32x4*)(a.shift2 + n2 * 32 + 4 * k4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  fz_bf16x8 fbw[4][2];
+  auto load_w2 = [&](int hb) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int n2 = 0; n2 < 2; ++n2) fbw[c][n2] = *(const fz_bf16x8*)(wb + (size_t)(4 * hb + c) * (2 * 64 * 8) + n2 * 32 * 8);
+  };
+  load_w2(0);
+  __builtin_amdgcn_sched_barrier(0);
+  // The parked tile is WAVE-PRIVATE (ew = this wave's 12 KB: written and read by this wave only, and LDS operations of a wave
+  // complete in order), and the main loop ended on a barrier: no workgroup barrier is needed in here.
 #pragma unroll
   for (int hb = 0; hb < 2; ++hb) {
-    if (hb) __syncthreads();          // every wave is done reading the first 64 channels
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int nb = 2 * hb + q;
-      const int n = nb * 32 + li;
-      const float sc = a.scale ? a.scale[n] : 1.f, sh = a.shift ? a.shift[n] : 0.f;
+      const float sc = bsc[nb], sh = bsh[nb];
       const int nq = nb * 32 + 4 * k4;
       char* eb = ew + ((nq >> 4) - 4 * hb) * E::IMGB + (j + 4 * h) * E::PIXB + (nq & 15) * 2;
 #pragma unroll
@@ -254,19 +279,26 @@ __device__ __forceinline__ void conv_fuse1x1_b16_epilogue(const ConvArgs& a, f32
           *(fz_bf16x4*)(eb + (4 * mb + g) * E::ROWB) = p0;
         }
     }
-    __syncthreads();
+    // (the wave's own ds_writes above are ordered before its ds_reads below: same wave, same LDS queue; the wave barrier
+    //  only keeps the compiler from moving one across the other)
+    __builtin_amdgcn_wave_barrier();
+    fz_bf16x8 fa[4][2];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      fz_bf16x8 fa[2], fb[2];
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) fa[mb] = *(const fz_bf16x8*)(ea + c * E::IMGB + (4 * mb) * E::ROWB);
+      for (int mb = 0; mb < 2; ++mb) fa[c][mb] = *(const fz_bf16x8*)(ea + c * E::IMGB + (4 * mb) * E::ROWB);
 #pragma unroll
-      for (int n2 = 0; n2 < 2; ++n2) fb[n2] = *(const fz_bf16x8*)(wb + (size_t)(4 * hb + c) * (2 * 64 * 8) + n2 * 32 * 8);
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2)
-          acc2[mb][n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mb], fb[n2], acc2[mb][n2], 0, 0, 0);
+          acc2[mb][n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][mb], fbw[c][n2], acc2[mb][n2], 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
+    if (hb == 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_w2(1);          // the first half's accumulators are dead: their registers take the second half's fragments
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // + bias + residual (bf16), ReLU, bf16 store
@@ -274,8 +306,7 @@ __device__ __forceinline__ void conv_fuse1x1_b16_epilogue(const ConvArgs& a, f32
   for (int n2 = 0; n2 < 2; ++n2) {
     const int nq2 = n2 * 32 + 4 * k4;
     const int oq = a.out_coff + nq2;
-    f32x4 sh4 = {0.f, 0.f, 0.f, 0.f};
-    if (a.shift2) sh4 = *(const f32x4*)(a.shift2 + nq2);
+    const f32x4 sh4 = osh[n2];
     __bf16* ob4 = (__bf16*)a.out + (((size_t)bsafe * out_blocks + (oq >> 4)) * HW) * 16 + (oq & 15);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
