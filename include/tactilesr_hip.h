@@ -144,6 +144,28 @@ int tsr_conv2d_fwd_b16_fuse1x1(const void* in, int in_ctot, int in_coff, int cin
 int tsr_conv2d_fwd_b16_pair(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed,
                             const float* scale, const float* shift, void* out, int out_ctot, int out_coff,
                             int relu, int B, int H, int W, void* stream);
+/* The bf16-storage INFERENCE convolutions proper (csrc/conv_b16k.hip; 3x3 / 5x5, C_out 64 / 128, C_in a multiple of 32):
+ * v_mfma_f32_16x16x32_bf16 with channels as rows -- the accumulators are in CB16 order (8-B bf16 stores, no transpose)
+ * and, for the fused form, already the operand layout of the 1x1 product -- LDS-DMA halo rows into a circular row buffer
+ * and an LDS-DMA weight ring.  Same arguments and semantics as the three entries above; the weight layouts differ:
+ * w_packed from tsr_pack_conv_weight_b16k ([C_in/32][tap][4][C_out][8] bf16; tsr_conv_weight_b16k_elems elements),
+ * w2_packed from tsr_pack_w2_b16k (the 64x128 fp32 half of `confusion`, model/tactileSR_model.py:203-206, in the K order
+ * of the fused epilogue). */
+long long tsr_conv_weight_b16k_elems(int cout, int cin, int ks);
+int tsr_pack_conv_weight_b16k(const float* w_oihw, void* w_packed, int cout, int cin, int ks, void* stream);
+int tsr_pack_w2_b16k(const float* w2_64x128, void* w_packed, void* stream);
+int tsr_conv2d_fwd_b16k(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed, int cout, int ks,
+                        const float* scale, const float* shift, const void* res, int res_ctot, int res_coff,
+                        void* out, int out_ctot, int out_coff, int relu, int B, int H, int W, void* stream);
+int tsr_conv2d_fwd_b16k_fuse1x1(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed, int ks,
+                                const float* scale, const float* shift, int relu,
+                                const void* w2_packed, const float* shift2,
+                                const void* res, int res_ctot, int res_coff,
+                                void* out, int out_ctot, int out_coff, int relu2,
+                                int B, int H, int W, void* stream);
+int tsr_conv2d_fwd_b16k_pair(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed,
+                             const float* scale, const float* shift, void* out, int out_ctot, int out_coff,
+                             int relu, int B, int H, int W, void* stream);
 int tsr_stem_fwd_b16(const float* lr, int lr_ctot, int lr_coff, int axis_cnt, int hin, int win, int sf,
                      const float* w_oihw, const float* scale, const float* shift,
                      void* out_bf16, int out_ctot, int out_coff, int relu, int B, void* stream);

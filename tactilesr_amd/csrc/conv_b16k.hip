@@ -1,0 +1,566 @@
+// Inference convolutions of the bf16 ACTIVATION-STORAGE path (BASELINE's "bf16" configurations: bf16 CB16 tensors in HBM,
+// plain bf16 MFMA operands, fp32 accumulation) on v_mfma_f32_16x16x32_bf16, CHANNELS AS ROWS:
+//
+//     D[co][pixel] += W[co][ci] . X[ci][pixel]          A operand = weights (M = C_out), B operand = halo pixels (N)
+//
+//   * Why this orientation.  The accumulator of a 16x16 tile then holds, per lane, FOUR CONSECUTIVE CHANNELS of ONE
+//     pixel (lane = (pixel n = lane & 15, channel quad g = lane >> 4)) -- which is (a) the CB16 storage order, so the
+//     output stage is one 8-B bf16 store per tile with no transpose, and (b), for two channel tiles side by side, exactly
+//     the B-operand register layout of the NEXT matrix product over those channels: the MSRB's fused 1x1 `confusion`
+//     half (model/tactileSR_model.py:196-206) runs on the converted accumulators directly -- no LDS round trip, no
+//     barrier, no 4x4 transposes (the 32x32x16 pixel-row kernel parked the tile in LDS: its epilogue was 26-28 k cycles,
+//     40 % of the 3x3 launch's workgroup time).  The 1x1 weight is packed in the matching K order (tsr_pack_w2_b16k).
+//   * Why this instruction.  Under an MFMA-dense loop the chip holds a higher clock on the 16x16x32 shape than on
+//     32x32x16 at equal cycles per FLOP (MI355X_MICROARCH.md, DVFS give-back item 7).
+//   * K = 32 = the 32 input channels of TWO CB16 blocks at ONE tap (the tensors are bf16: a halo pixel of a 32-channel
+//     block is 64 B): no tap pairing, no odd-tap cross step.
+//
+// Workgroup = 256 threads = 4 images x one 8x8 patch x all C_out; wave = image; per wave C_out/16 x 4 accumulator tiles.
+// LDS: halo slab [image][row][pixel][32 ch] (row stride == 2 (mod 4) 16-B slots: conflict-free ds_read_b128 B fragments)
+// + a 3-slot ring of one-tap weight slabs [k group 4][C_out][8] fed by LDS-DMA.  Slab s is read (A fragments, one step
+// ahead, refilled in place as the rows of the step retire) during step s-1 only, so slab s+3 is requested at the START of
+// step s into the slot slab s just left and has two whole steps to land.  Per step and wave: 32 MFMAs, 12 ds_read_b128.
+// Forms: plain / FUSED (stage 2 of an MSRB + its 1x1 half) / PAIR (stage 1: conv_3_1 || conv_5_1 on one halo; the 3x3
+// half's MFMAs and fragment reads are skipped on the 16 outer taps).
+#include "tsr_common.h"
+#include "conv_args.h"
+#include "tactilesr_hip.h"
+#include <type_traits>
+
+typedef __bf16 kb16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 kb16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned ku32x4 __attribute__((ext_vector_type(4)));
+typedef int ki32x4 __attribute__((ext_vector_type(4)));
+
+// LDS-DMA (buffer_load_dwordx4 ... lds: 16 B per lane, global -> LDS at m0 + 16 * lane, no VGPR hop) as inline assembly: the
+// builtin form needs an exec-masked BRANCH around a request that only part of the wave takes part in, and a basic-block
+// boundary inside a step costs hipcc its register allocation (it starts spilling accumulators).  `rs` = raw buffer
+// descriptor (base, 0 stride, num_records, flags), `vo` = per-lane byte offset, `so` = scalar byte offset, `m0v` = LDS byte
+// address of lane 0's 16 B.  The hardware counts these like any vector-memory load (vmcnt, in issue order).
+__device__ __forceinline__ void b16k_dma(ki32x4 rs, int vo, int so, unsigned m0v) {
+  unsigned keep;       // (M0 is compiler-reserved: saved and restored inside the statement)
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(m0v), "v"(vo), "s"(rs), "s"(so));
+}
+// two requests of the lanes in `mask` only (the same source bytes to two LDS rows)
+__device__ __forceinline__ void b16k_dma2_masked(ki32x4 rs, int vo, int so, unsigned m0a, unsigned m0b, unsigned long long mask) {
+  unsigned long long sv;
+  unsigned keep;
+  asm volatile("s_mov_b32 %1, m0\n\ts_mov_b64 %0, exec\n\ts_mov_b64 exec, %7\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "buffer_load_dwordx4 %4, %5, %6 offen lds\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "buffer_load_dwordx4 %4, %5, %6 offen lds\n\ts_mov_b64 exec, %0\n\ts_mov_b32 m0, %1"
+               : "=&s"(sv), "=&s"(keep) : "s"(m0a), "s"(m0b), "v"(vo), "s"(rs), "s"(so), "s"(mask));
+}
+__device__ __forceinline__ unsigned b16k_lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+constexpr int b16k_row_slots(int px) {
+  int rs = px * 4;
+  while ((rs & 3) != 2) ++rs;
+  return rs;
+}
+
+template <int KS, int COUT> struct B16KGeom {
+  static constexpr int HH = 8 + KS - 1;
+  static constexpr int T = KS * KS;
+  static constexpr int PIXB = 64;
+  static constexpr int ROWB = b16k_row_slots(HH) * 16;
+  static constexpr int NROW = 16;                    // physical halo rows per image: a circular buffer (see below)
+  static constexpr int IMGB = (NROW + 1) * ROWB;     // + row 16, a copy of row 0 (a row pair may start at row 15)
+  static constexpr int HALO_B = 4 * IMGB + ROWB;     // + one row nobody reads (where the copy goes when the row is not row 0)
+  static constexpr int WTAP_B = 64 * COUT;           // 32 channels x C_out bf16
+  static constexpr int RING = 3;
+  static constexpr int LDS_B = HALO_B + RING * WTAP_B;
+};
+
+enum { B16K_PLAIN = 0, B16K_FUSED = 1, B16K_PAIR = 2 };
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (the scheduling hints need constant operands)
+template <int I, int N, class F> __device__ __forceinline__ void b16k_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    b16k_static_for<I + 1, N>(f);
+  }
+}
+// pair form: first C_out tile with work at tap t (the 3x3 conv, tiles 0..3, has no weight outside the inner 3x3 taps)
+template <int KS, int MODE, int MT> constexpr int b16k_tap_rows(int t) {
+  const int kh = t / KS, kw = t - kh * KS;
+  return (MODE != B16K_PAIR || (kh >= 1 && kh <= 3 && kw >= 1 && kw <= 3)) ? 0 : MT / 2;
+}
+
+// Halo-row requests of step t of a block (two slots; -1 = none): row r of the CURRENT block = r, of the NEXT block = 16 + r.
+// Constraints (checked by hand against the circular-buffer rule in the kernel): a slot is requested only after the step
+// whose tap last read its old row (old row q < KS-1 dies with kernel row q, the others with the block), at least two
+// steps before the first tap that reads the new row (row r is first needed at kernel row max(0, r - 7)); next-block rows
+// 0..7 no later than step T-2.
+template <int KS> struct B16KJobs;
+template <> struct B16KJobs<5> {       // HH = 12: next rows 0..3 -> never-used slots, 4..7 -> this block's rows 0..3, 8..11 -> its rows 4..7
+  static constexpr int job(int t, int i) {
+    if (i) return -1;
+    if (t < 4) return 8 + t;                    // this block's rows 8..11 (first needed at taps 5, 10, 15, 20)
+    if (t >= 6 && t < 10) return 16 + (t - 6);
+    if (t == 11) return 16 + 4;                 // slot = row 0, dead after tap 4
+    if (t == 13) return 16 + 5;                 // row 1, dead after tap 9
+    if (t == 16) return 16 + 6;                 // row 2, dead after tap 14
+    if (t == 21) return 16 + 7;                 // row 3, dead after tap 19
+    return -1;
+  }
+};
+template <> struct B16KJobs<3> {       // HH = 10: next rows 0..5 -> never-used slots, 6, 7 -> this block's rows 0, 1, 8, 9 -> its rows 2, 3
+  static constexpr int job(int t, int i) {
+    if (t == 0) return i ? -1 : 8;              // this block's rows 8, 9 (first needed at taps 3, 6)
+    if (t == 1) return i ? -1 : 9;
+    if (t >= 2 && t <= 4) return 16 + 2 * (t - 2) + i;
+    if (t == 5) return i ? -1 : 16 + 6;         // slot = row 0, dead after tap 2
+    if (t == 6) return i ? -1 : 16 + 7;         // row 1, dead after tap 5
+    return -1;
+  }
+};
+
+template <int KS, int COUT, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
+  static_assert(MODE == B16K_PLAIN || (COUT == 128 && (MODE == B16K_FUSED || KS == 5)), "fused / pair: 128 channels");
+  typedef B16KGeom<KS, COUT> G;
+  constexpr int P = KS / 2, HH = G::HH, T = G::T, MT = COUT / 16, NT = 4;
+  constexpr int PIXB = G::PIXB, ROWB = G::ROWB, IMGB = G::IMGB, HALO_B = G::HALO_B, WTAP_B = G::WTAP_B;
+  constexpr int WV = WTAP_B / 4096;                          // LDS-DMA instructions per wave and slab (1 KB each)
+  __shared__ __attribute__((aligned(16))) char lds[G::LDS_B];
+  char* halo = lds;
+  char* wbuf = lds + HALO_B;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, g = lane >> 4;
+
+  int bid;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tpi = a.tiles_x * a.tiles_y;
+  const int ig = bid / tpi;
+  const int trem = bid - ig * tpi;
+  const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+  const int y0 = ty * 8, x0 = tx * 8, b0 = ig * 4;
+  const int HW = a.H * a.W;
+  const int in_blocks = a.in_ctot >> 4;
+
+  // ---- halo staging: LDS-DMA, one ROW of one image per wave instruction (wave w stages image w), no registers.
+  // The slab of a 32-channel block is HH rows; the LDS holds NROW = 16 physical rows per image as a CIRCULAR buffer: row r of
+  // block c lives in physical row (c * HH + r) & 15.  Tap (kh, kw) reads rows kh .. kh+7, so with kh ascending the rows of a
+  // block die one kernel row at a time, and the next block's rows are needed one kernel row at a time: its rows 0 .. NROW-HH-1
+  // go into slots the current block never used, the following ones into the current block's rows 0, 1, .. as they die, and
+  // its last rows (first needed at kernel row 1, 2, ..) are requested during its own first steps into the slots that were
+  // live until the previous block's last tap.  A row requested at step s is awaited before the barrier that ends step s+1
+  // and read from step s+2 on: no block boundary, no staging registers, no conversion -- a step is a step.
+  const int hpx = lane >> 2, hqd = lane & 3;
+  const int hgx = x0 - P + hpx;
+  const bool col_ok = hpx < HH && hgx >= 0 && hgx < a.W && b0 + wm < a.B;
+  const unsigned img_stride = (unsigned)in_blocks * HW * 32;                      // bytes per image
+  const int lane_base = (int)(wm * img_stride) + hgx * 32 + (hqd >> 1) * HW * 32 + (hqd & 1) * 16;
+  const unsigned long long in_grp = (unsigned long long)((const char*)a.in + ((size_t)b0 * in_blocks + (a.in_coff >> 4)) * HW * 32);
+  const unsigned long long w_base = (unsigned long long)a.wp;
+  // An offset beyond the descriptor's range makes a buffer load return zeros: the zero padding (a lane whose column lies
+  // outside the image carries such an offset), and -- through a descriptor of range ZERO (a scalar select on its
+  // num_records word) -- a row outside the image / a request that has nothing to fetch.  Such requests are issued all the
+  // same: every step then issues a compile-time number of operations, which is what its counted vmcnt wait relies on.
+  // The row part of the address goes through the SCALAR offset, the lane part (column, channel quarter, image) is one
+  // loop-invariant register.  (`opaque`: hipcc would otherwise precompute the per-row / per-tap address registers of a
+  // whole block -- 30 VGPRs the accumulator tile does not leave.)
+  const int vo_lane = col_ok ? lane_base : (int)0x80000000;
+  auto opaque = [](int v) __attribute__((always_inline)) { asm volatile("" : "+s"(v)); return v; };
+  const unsigned halo_a = b16k_lds_addr(halo), wbuf_a = b16k_lds_addr(wbuf);
+  auto dma_row = [&](int cblk, int r, bool real) __attribute__((always_inline)) {
+    const int gy = opaque(y0 - P + r);
+    const bool row_ok = real && gy >= 0 && gy < a.H;
+    const int prow = (cblk * HH + r) & 15;
+    const unsigned dst = halo_a + wm * IMGB + prow * ROWB;
+    // physical row 0 has a copy behind row 15: lanes m >= 8 of a fragment read the row AFTER the (uniform) first row
+    const unsigned dst2 = prow == 0 ? dst + 16 * ROWB : halo_a + 4 * IMGB;
+    const ki32x4 rs = {(int)in_grp, (int)(in_grp >> 32) & 0xffff, row_ok ? 0x7fffffff : 0, 0x00020000};
+    b16k_dma2_masked(rs, vo_lane, row_ok ? cblk * HW * 64 + gy * a.W * 32 : 0, dst, dst2, (1ull << (4 * HH)) - 1);
+  };
+  const int wvo = tid * 16;
+
+  const int laneA = (g * COUT + m) * 16;                                          // + mt * 256 (+ slot)
+  const int laneB = wm * IMGB + (m >> 3) * ROWB + (m & 7) * PIXB + g * 16;         // + first physical row * ROWB + kw * PIXB
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nblk = a.cin >> 5;
+  const int S = nblk * T;
+
+#define DMA_W(sidx, slot_)                                                                \
+  {                                                                                      \
+    const bool real_ = (sidx) < S;                                                       \
+    const ki32x4 rs_ = {(int)w_base, (int)(w_base >> 32) & 0xffff, real_ ? 0x7fffffff : 0, 0x00020000}; \
+    const int so_ = real_ ? (sidx) * WTAP_B : 0;                                         \
+    const unsigned dst_ = wbuf_a + (slot_) * WTAP_B + wm * 1024;                         \
+    _Pragma("unroll") for (int v = 0; v < WV; ++v) b16k_dma(rs_, wvo, so_ + v * 4096, dst_ + v * 4096); \
+  }
+  // vmcnt wait that leaves the n_ youngest vector-memory operations in flight (they count in issue order)
+#define VM_WAIT(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14))
+  // end of a step: everything requested before this step has landed (the n_ operations of this step stay in flight), this
+  // wave's LDS reads are done (the slot of the slab they read is re-requested right after the barrier), then a RAW
+  // s_barrier -- __syncthreads()'s fence would drain the LDS-DMA queue (vmcnt(0)) at every step
+  // (the empty asm statements are compiler-only fences: no LDS access may be moved across the wait / barrier pair)
+#define STEP_END(n_)                                                                     \
+  {                                                                                      \
+    asm volatile("" ::: "memory");                                                       \
+    __builtin_amdgcn_s_waitcnt(0x0070 | ((n_) & 15) | (((n_) >> 4) << 14));              \
+    __builtin_amdgcn_s_barrier();                                                        \
+    asm volatile("" ::: "memory");                                                       \
+  }
+#define LOAD_A(mt_, slot_) A[mt_] = *(const kb16x8*)(wbuf + (slot_) * WTAP_B + laneA + (mt_) * 256)
+  // B fragment of row pair nt_ at tap (kh_, kw_) of the block whose row 0 is physical row rb_
+#define LOAD_B(nt_, rb_, kh_, kw_)                                                        \
+  Bf[nt_] = *(const kb16x8*)(halo + laneB + (((rb_) + 2 * (nt_) + (kh_)) & 15) * ROWB + (kw_) * PIXB)
+#define MFMA(mt_, nt_) acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt_], Bf[nt_], acc[mt_][nt_], 0, 0, 0)
+#define SGB(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0)
+
+  // ---- prologue: rows 0..7 of block 0, W(0), W(1) landed; W(2) in flight
+#pragma unroll
+  for (int r = 0; r < 8; ++r) dma_row(0, r, true);
+  DMA_W(0, 0);
+  DMA_W(1, 1);
+  DMA_W(2, 2);
+  STEP_END(WV);
+
+  kb16x8 A[MT], Bf[NT];
+#pragma unroll
+  for (int mt = b16k_tap_rows<KS, MODE, MT>(0); mt < MT; ++mt) LOAD_A(mt, 0);
+  LOAD_B(0, 0, 0, 0);
+  LOAD_B(1, 0, 0, 0);
+  // (step 0 re-requests slot 0 -- slab 3 -- right away: every wave must have READ slab 0 first)
+  STEP_END(WV);
+
+  int s = 0, slot = 0;
+  for (int c = 0; c < nblk; ++c) {
+    const bool more = c + 1 < nblk;
+    const int rb0 = (c * HH) & 15;
+    b16k_static_for<0, T>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int kh = t / KS, kw = t - kh * KS;
+      constexpr int tn = t + 1 < T ? t + 1 : 0;
+      constexpr int nkh = tn / KS, nkw = tn - nkh * KS;
+      constexpr int m0 = b16k_tap_rows<KS, MODE, MT>(t), m1 = b16k_tap_rows<KS, MODE, MT>(tn);
+      constexpr int j0 = B16KJobs<KS>::job(t, 0), j1 = B16KJobs<KS>::job(t, 1);
+      constexpr int NJ = (j0 >= 0) + (j1 >= 0);
+      const int slot1 = slot == 2 ? 0 : slot + 1;
+      const int rb = opaque(rb0), rbn = (rb + HH) & 15;
+      LOAD_B(2, rb, kh, kw);
+      LOAD_B(3, rb, kh, kw);
+#pragma unroll
+      for (int mt = m0; mt < MT; ++mt) { MFMA(mt, 0); MFMA(mt, 1); }
+      SGB(0x100, 2);
+      SGB(0x008, 2 * (MT - m0));
+      __builtin_amdgcn_sched_barrier(0);
+      // this step's requests, issued behind the first half's MFMAs (right after the barrier they would delay them)
+      DMA_W(s + 3, slot);                                      // slab s was read during step s-1: its slot is free
+      if constexpr (j0 >= 0) dma_row(c + (j0 >> 4), j0 & 15, (j0 >> 4) == 0 || more);
+      if constexpr (j1 >= 0) dma_row(c + (j1 >> 4), j1 & 15, (j1 >> 4) == 0 || more);
+      LOAD_B(0, (t + 1 < T ? rb : rbn), nkh, nkw);
+      LOAD_B(1, (t + 1 < T ? rb : rbn), nkh, nkw);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (mt >= m0) { MFMA(mt, 2); MFMA(mt, 3); }
+        if (mt >= m1) LOAD_A(mt, slot1);
+      }
+      // order: B2 B3 | first half | requests | B0' B1' | second half with the A rows refilled as they retire
+      SGB(0x100, 2);
+      b16k_static_for<0, MT>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int mt = decltype(mc)::value;
+        if constexpr (mt >= m0) SGB(0x008, 2);
+        if constexpr (mt >= m1) SGB(0x100, 1);
+      });
+      // everything requested BEFORE this step has landed (this step's own requests stay in flight): slab s+2, the halo
+      // rows of step s-1
+      STEP_END(WV + 2 * NJ);
+      ++s;
+      slot = slot1;
+    });
+  }
+  // (the trailing requests fetch nothing but still write LDS: none may be in flight when the workgroup's LDS is released)
+  VM_WAIT(0);
+#undef DMA_W
+#undef VM_WAIT
+#undef STEP_END
+#undef LOAD_A
+#undef LOAD_B
+#undef MFMA
+#undef SGB
+
+  // ---- epilogue: lane = (pixel m of row pair nt, channel quad g).  Every global read is requested in program order BEFORE the
+  // first store of its phase: behind a store to `out` the compiler may not hoist a load (the pointers could alias), and a
+  // load waited for where it is used is a full round trip in a workgroup that has no MFMA work left to cover it.
+  const int b = b0 + wm;
+  const bool img_ok = b < a.B;
+  const int bsafe = img_ok ? b : 0;
+  const int out_blocks = a.out_ctot >> 4, res_blocks = a.res_ctot >> 4;
+  bool ok[NT];
+  unsigned po[NT];                      // element offset of the pixel inside a 16-channel plane
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int gy = y0 + 2 * nt + (m >> 3), gx = x0 + (m & 7);
+    ok[nt] = img_ok && gy < a.H && gx < a.W;
+    po[nt] = ok[nt] ? (unsigned)(gy * a.W + gx) * 16u : 0u;
+  }
+  const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
+  const kb16x4 zero4h = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+  const float lo = a.relu ? 0.f : -__builtin_inff();          // v < lo ? lo : v  -- ReLU or identity, NaN-propagating
+  constexpr int OT = MODE == B16K_FUSED ? 4 : MT;            // C_out tiles of the tensor this launch writes
+  const __bf16* rbase = a.res ? (const __bf16*)a.res + (((size_t)bsafe * res_blocks + (a.res_coff >> 4)) * HW) * 16 + 4 * g : nullptr;
+  __bf16* obase = (__bf16*)a.out + (((size_t)bsafe * out_blocks + (a.out_coff >> 4)) * HW) * 16 + 4 * g;
+  const size_t plane = (size_t)HW * 16;                      // elements per (image, 16-channel block)
+  const __bf16* w2 = (const __bf16*)a.w2 + ((size_t)g * 64 + m) * 8;              // fused form: [kk][g][64][8]
+  kb16x8 wa[2][4];
+  f32x4 sh2[4];
+  if constexpr (MODE == B16K_FUSED) {        // the first two K steps' W2 fragments and the bias travel under the BatchNorm fold
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int m2 = 0; m2 < 4; ++m2) wa[kk][m2] = *(const kb16x8*)(w2 + (size_t)kk * (4 * 64 * 8) + m2 * 16 * 8);
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2) sh2[m2] = a.shift2 ? *(const f32x4*)(a.shift2 + m2 * 16 + 4 * g) : zero4;
+  }
+  // BatchNorm fold of all C_out tiles, in place.  Fused form with ReLU: the fold yields v / 2 and ReLU is v/2 + |v/2| (one
+  // instruction, NaN-propagating, exact: a power-of-two factor)
+  {
+    const float hs = (MODE == B16K_FUSED && a.relu) ? 0.5f : 1.f;
+    f32x4 sc[MT], sh[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      sc[mt] = a.scale ? *(const f32x4*)(a.scale + mt * 16 + 4 * g) : one4;
+      sh[mt] = a.shift ? *(const f32x4*)(a.shift + mt * 16 + 4 * g) : zero4;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      sc[mt] *= hs;
+      sh[mt] *= hs;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[mt][nt][i] = fmaf(acc[mt][nt][i], sc[mt][i], sh[mt][i]);
+    }
+  }
+
+  if constexpr (MODE == B16K_FUSED) {
+    // 1. ReLU, rounded to bf16: bq[kk][nt] IS the B fragment of K step kk of the second product (K slot (g, j): channel
+    //    32 kk + 4 g + j for j < 4, 32 kk + 16 + 4 g + j - 4 for j >= 4)
+    kb16x8 bq[4][NT];
+    if (a.relu) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bq[kk][nt][4 * u + i] = (__bf16)tsr_relu_x2(acc[2 * kk + u][nt][i]);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bq[kk][nt][4 * u + i] = (__bf16)acc[2 * kk + u][nt][i];
+    }
+    // 2. out2[64 co][64 px] = W2 . bq ; the W2 fragments come straight from L2 (16 B per lane, the same for every wave);
+    //    the output stage's residual tile is requested under the product
+    kb16x4 rv[4][NT];
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) rv[m2][nt] = rbase ? *(const kb16x4*)(rbase + m2 * plane + po[nt]) : zero4h;
+    f32x4 acc2[4][NT];
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc2[m2][nt] = sh2[m2];        // the product accumulates onto the bias
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+      for (int m2 = 0; m2 < 4; ++m2)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc2[m2][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[kk & 1][m2], bq[kk][nt], acc2[m2][nt], 0, 0, 0);
+      if (kk + 2 < 4) {
+#pragma unroll
+        for (int m2 = 0; m2 < 4; ++m2) wa[kk & 1][m2] = *(const kb16x8*)(w2 + (size_t)(kk + 2) * (4 * 64 * 8) + m2 * 16 * 8);
+      }
+    }
+    // 3. + bias + residual (bf16), ReLU, bf16 store: 4 consecutive channels of a pixel per lane
+    const float lo2 = a.relu2 ? 0.f : -__builtin_inff();
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        kb16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = acc2[m2][nt][i] + (float)rv[m2][nt][i];
+          o[i] = (__bf16)(v < lo2 ? lo2 : v);
+        }
+        if (ok[nt]) *(kb16x4*)(obase + m2 * plane + po[nt]) = o;
+      }
+  } else {
+    // residual tiles two C_out tiles ahead of the stores
+    kb16x4 rv[2][2][NT];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) rv[0][u][nt] = rbase ? *(const kb16x4*)(rbase + u * plane + po[nt]) : zero4h;
+#pragma unroll
+    for (int mp = 0; mp < OT / 2; ++mp) {
+      if (mp + 1 < OT / 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            rv[(mp + 1) & 1][u][nt] = rbase ? *(const kb16x4*)(rbase + (2 * mp + 2 + u) * plane + po[nt]) : zero4h;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          kb16x4 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float v = acc[2 * mp + u][nt][i] + (float)rv[mp & 1][u][nt][i];
+            o[i] = (__bf16)(v < lo ? lo : v);
+          }
+          if (ok[nt]) *(kb16x4*)(obase + (2 * mp + u) * plane + po[nt]) = o;
+        }
+    }
+  }
+}
+
+// ---- weight packs ------------------------------------------------------------------------------------------------------
+// OIHW fp32 -> [C_in/32][tap][k group 4][C_out][8] bf16: the A fragment of lane (m, g) for C_out tile mt is the 16 B at
+// ((g * C_out + mt * 16 + m) * 8) of a tap slab; slabs follow one another in step order (LDS-DMA copies them verbatim).
+__global__ void pack_b16k_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int cout, int cin, int T) {
+  const size_t total = (size_t)cout * cin * T;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i & 7;
+    size_t r = i >> 3;
+    const int co = r % cout; r /= cout;
+    const int g = r & 3; r >>= 2;
+    const int tap = r % T;
+    const int cb = r / T;
+    const int ci = cb * 32 + g * 8 + j;
+    wp[i] = (__bf16)w[((size_t)co * cin + ci) * T + tap];
+  }
+}
+
+// [64][128] fp32 (one half of an MSRB's `confusion` weight) -> [kk 4][g 4][64][8] bf16 in the K order in which the fused
+// epilogue's accumulators ARE the B operand: slot (g, j) of K step kk = channel 32 kk + 4 g + j (j < 4) or
+// 32 kk + 16 + 4 g + (j - 4) (j >= 4)
+__global__ void pack_w2_b16k_kernel(const float* __restrict__ w2, __bf16* __restrict__ wp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 64 * 128) return;
+  const int j = i & 7, co = (i >> 3) & 63, g = (i >> 9) & 3, kk = i >> 11;
+  const int ch = 32 * kk + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
+  wp[i] = (__bf16)w2[co * 128 + ch];
+}
+
+extern "C" long long tsr_conv_weight_b16k_elems(int cout, int cin, int ks) { return (long long)cout * cin * ks * ks; }
+
+static bool b16k_shape_ok(int cout, int cin, int ks) {
+  return (cout == 64 || cout == 128) && cin > 0 && (cin & 31) == 0 && (ks == 3 || ks == 5);
+}
+
+extern "C" int tsr_pack_conv_weight_b16k(const float* w_oihw, void* w_packed, int cout, int cin, int ks, void* stream) {
+  if (!w_oihw || !w_packed || !b16k_shape_ok(cout, cin, ks)) return TSR_ERR_ARG;
+  const size_t total = (size_t)cout * cin * ks * ks;
+  const int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(pack_b16k_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                     (__bf16*)w_packed, cout, cin, ks * ks);
+  return tsr_check_launch();
+}
+
+extern "C" int tsr_pack_w2_b16k(const float* w2_64x128, void* w_packed, void* stream) {
+  if (!w2_64x128 || !w_packed) return TSR_ERR_ARG;
+  hipLaunchKernelGGL(pack_w2_b16k_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, w2_64x128, (__bf16*)w_packed);
+  return tsr_check_launch();
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------------------
+static int b16k_fill(ConvArgs& a, const void* in, int in_ctot, int in_coff, int cin, const void* w_packed, int cout,
+                     const float* scale, const float* shift, const void* res, int res_ctot, int res_coff, void* out,
+                     int out_ctot, int out_coff, int out_ch, int relu, int B, int H, int W) {
+  if (!in || !w_packed || !out || B <= 0 || H <= 0 || W <= 0) return TSR_ERR_ARG;
+  if ((in_ctot & 15) || (in_coff & 15) || (out_ctot & 15) || (out_coff & 15) || in_coff + cin > in_ctot ||
+      out_coff + out_ch > out_ctot)
+    return TSR_ERR_ARG;
+  if (res && ((res_ctot & 15) || (res_coff & 15) || res_coff + out_ch > res_ctot)) return TSR_ERR_ARG;
+  if ((long long)4 * in_ctot * H * W * 2 >= 0x7fffffffLL) return TSR_ERR_ARG;      // 32-bit halo offsets inside a 4-image group
+  a = ConvArgs{};
+  a.in = (const float*)in; a.in_ctot = in_ctot; a.in_coff = in_coff; a.cin = cin;
+  a.wp = (const float*)w_packed; a.scale = scale; a.shift = shift;
+  a.res = (const float*)res; a.res_ctot = res_ctot; a.res_coff = res_coff;
+  a.out = (float*)out; a.out_ctot = out_ctot; a.out_coff = out_coff; a.relu = relu;
+  a.B = B; a.H = H; a.W = W;
+  a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8;
+  (void)cout;
+  return TSR_OK;
+}
+
+extern "C" int tsr_conv2d_fwd_b16k(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed, int cout, int ks,
+                                   const float* scale, const float* shift, const void* res, int res_ctot, int res_coff,
+                                   void* out, int out_ctot, int out_coff, int relu, int B, int H, int W, void* stream) {
+  if (!b16k_shape_ok(cout, cin, ks)) return TSR_ERR_ARG;
+  ConvArgs a;
+  const int rc = b16k_fill(a, in, in_ctot, in_coff, cin, w_packed, cout, scale, shift, res, res_ctot, res_coff, out, out_ctot,
+                           out_coff, cout, relu, B, H, W);
+  if (rc != TSR_OK) return rc;
+  const dim3 grid(((B + 3) / 4) * a.tiles_x * a.tiles_y), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (cout == 64 && ks == 3) hipLaunchKernelGGL((conv_b16k_kernel<3, 64, B16K_PLAIN>), grid, blk, 0, st, a);
+  else if (cout == 64) hipLaunchKernelGGL((conv_b16k_kernel<5, 64, B16K_PLAIN>), grid, blk, 0, st, a);
+  else if (ks == 3) hipLaunchKernelGGL((conv_b16k_kernel<3, 128, B16K_PLAIN>), grid, blk, 0, st, a);
+  else hipLaunchKernelGGL((conv_b16k_kernel<5, 128, B16K_PLAIN>), grid, blk, 0, st, a);
+  return tsr_check_launch();
+}
+
+// Stage-2 convolution of an MSRB (128 -> 128, BatchNorm + ReLU) with its half of the 1x1 `confusion` fused: out / res
+// describe the 64-channel result; w2_packed from tsr_pack_w2_b16k.
+extern "C" int tsr_conv2d_fwd_b16k_fuse1x1(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed, int ks,
+                                           const float* scale, const float* shift, int relu, const void* w2_packed,
+                                           const float* shift2, const void* res, int res_ctot, int res_coff, void* out,
+                                           int out_ctot, int out_coff, int relu2, int B, int H, int W, void* stream) {
+  if (!b16k_shape_ok(128, cin, ks) || !w2_packed) return TSR_ERR_ARG;
+  ConvArgs a;
+  const int rc = b16k_fill(a, in, in_ctot, in_coff, cin, w_packed, 128, scale, shift, res, res_ctot, res_coff, out, out_ctot,
+                           out_coff, 64, relu, B, H, W);
+  if (rc != TSR_OK) return rc;
+  a.w2 = w2_packed; a.w2_inv_scale = 1.f; a.shift2 = shift2; a.relu2 = relu2;
+  const dim3 grid(((B + 3) / 4) * a.tiles_x * a.tiles_y), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (ks == 3) hipLaunchKernelGGL((conv_b16k_kernel<3, 128, B16K_FUSED>), grid, blk, 0, st, a);
+  else hipLaunchKernelGGL((conv_b16k_kernel<5, 128, B16K_FUSED>), grid, blk, 0, st, a);
+  return tsr_check_launch();
+}
+
+// Stage-1 pair of an MSRB: w_packed = tsr_pack_conv_weight_b16k(cat([zero-pad(w3 -> 5x5), w5]), 128, cin, 5); scale / shift
+// = the two convs' folded BatchNorm vectors concatenated; out = 128 channels in torch.cat order.
+extern "C" int tsr_conv2d_fwd_b16k_pair(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed,
+                                        const float* scale, const float* shift, void* out, int out_ctot, int out_coff,
+                                        int relu, int B, int H, int W, void* stream) {
+  if (!b16k_shape_ok(128, cin, 5)) return TSR_ERR_ARG;
+  ConvArgs a;
+  const int rc = b16k_fill(a, in, in_ctot, in_coff, cin, w_packed, 128, scale, shift, nullptr, 0, 0, out, out_ctot, out_coff,
+                           128, relu, B, H, W);
+  if (rc != TSR_OK) return rc;
+  const dim3 grid(((B + 3) / 4) * a.tiles_x * a.tiles_y), blk(256);
+  hipLaunchKernelGGL((conv_b16k_kernel<5, 128, B16K_PAIR>), grid, blk, 0, (hipStream_t)stream, a);
+  return tsr_check_launch();
+}

@@ -196,7 +196,7 @@ CONV_IMPLS = {"f32": 0, "bf16x6": 3, "bf16x3": 2, "bf16": 1, "fp16x3": -2}   # n
 
 class _PackedConv:
     """Device-side constants of one conv launch: packed weight, folded scale/shift."""
-    __slots__ = ("w", "scale", "shift", "cin", "cout", "ks", "nsplit", "w_inv_scale")
+    __slots__ = ("w", "scale", "shift", "cin", "cout", "ks", "nsplit", "w_inv_scale", "b16k")
 
     def __init__(self, conv: nn.Conv2d, bn: Optional[nn.BatchNorm2d], nsplit: int = 0, cin_perm=None):
         w = conv.weight.detach().float()
@@ -206,7 +206,15 @@ class _PackedConv:
         self.cout, self.cin, self.ks = w.shape[0], w.shape[1], w.shape[2]
         self.nsplit = nsplit
         self.w_inv_scale = 1.0
-        if nsplit == -2:
+        # bf16 activation storage (nsplit 1 is only ever that path's): the 3x3 / 5x5 convs run csrc/conv_b16k.hip
+        # (its 64-channel instantiations -- 16 MFMAs per barrier step -- measure slower than the 32x32x16 kernel's 3-tap steps:
+        #  3x3 64->64 0.83 vs 0.70 ms per launch at B = 4096; they stay on that kernel)
+        self.b16k = nsplit == 1 and self.ks > 1 and self.cin % 32 == 0 and self.cout == 128
+        if self.b16k:
+            n = _lib.load().tsr_conv_weight_b16k_elems(self.cout, self.cin, self.ks)
+            self.w = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+            call("tsr_pack_conv_weight_b16k", ptr(w), ptr(self.w), _I(self.cout), _I(self.cin), _I(self.ks), stream())
+        elif nsplit == -2:
             # fp16 planes: power-of-two weight scale so that max|w|*wscale lies in [2^13, 2^14)
             import math
             m = float(w.abs().max())
@@ -272,9 +280,9 @@ class _PackedPairB16:
         w5 = seq5[0].weight.detach().float()
         self.cin = w3.shape[1]
         w = torch.cat([torch.nn.functional.pad(w3, (1, 1, 1, 1)), w5], dim=0).contiguous()
-        n = _lib.load().tsr_conv_weight_bf16s_elems(128, self.cin, 5, 1)
+        n = _lib.load().tsr_conv_weight_b16k_elems(128, self.cin, 5)
         self.w = torch.empty(n, dtype=torch.bfloat16, device=w.device)
-        call("tsr_pack_conv_weight_bf16s", ptr(w), ptr(self.w), _I(128), _I(self.cin), _I(5), _I(1), stream())
+        call("tsr_pack_conv_weight_b16k", ptr(w), ptr(self.w), _I(128), _I(self.cin), _I(5), stream())
         s3, sh3 = _fold(seq3[0].bias, seq3[1], 64, w.device)
         s5, sh5 = _fold(seq5[0].bias, seq5[1], 64, w.device)
         self.scale = torch.cat([s3, s5]).contiguous()
@@ -290,9 +298,8 @@ class _PackedHalf:
         w = w.float().contiguous()
         if ns != -2:        # bf16-storage path: one bf16 plane, no scaling
             self.w_inv_scale = 1.0
-            n = _lib.load().tsr_conv_weight_bf16s_elems(64, 128, 1, 1)
-            self.w = torch.empty(n, dtype=torch.bfloat16, device=w.device)
-            call("tsr_pack_conv_weight_bf16s", ptr(w), ptr(self.w), _I(64), _I(128), _I(1), _I(1), stream())
+            self.w = torch.empty(64 * 128, dtype=torch.bfloat16, device=w.device)
+            call("tsr_pack_w2_b16k", ptr(w), ptr(self.w), stream())
             return
         m = float(w.abs().max())
         wscale = 2.0 ** (13 - math.floor(math.log2(m))) if m > 0 else 1.0
@@ -453,7 +460,7 @@ class TactileSR(nn.Module):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if pc.nsplit == 1 and src.dtype == torch.bfloat16:      # bf16 activation storage
-            call("tsr_conv2d_fwd_b16", ptr(src), _I(s_ctot), _I(s_coff), _I(pc.cin), ptr(pc.w), _I(pc.cout), _I(pc.ks),
+            call("tsr_conv2d_fwd_b16k" if pc.b16k else "tsr_conv2d_fwd_b16", ptr(src), _I(s_ctot), _I(s_coff), _I(pc.cin), ptr(pc.w), _I(pc.cout), _I(pc.ks),
                  ptr(pc.scale), ptr(pc.shift), ptr(res), _I(r_ctot), _I(r_coff), ptr(dst), _I(d_ctot), _I(d_coff),
                  _I(1 if relu else 0), _I(B), _I(H), _I(W), stream())
         elif pc.nsplit == -2:
@@ -480,7 +487,7 @@ class TactileSR(nn.Module):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if isinstance(pp, _PackedPairB16):
-            call("tsr_conv2d_fwd_b16_pair", ptr(src), _I(64), _I(0), _I(pp.cin), ptr(pp.w), ptr(pp.scale), ptr(pp.shift),
+            call("tsr_conv2d_fwd_b16k_pair", ptr(src), _I(64), _I(0), _I(pp.cin), ptr(pp.w), ptr(pp.scale), ptr(pp.shift),
                  ptr(dst), _I(128), _I(0), _I(1), _I(B), _I(H), _I(W), stream())
         else:
             call("tsr_conv2d_fwd_f16s_pair", ptr(src), _I(64), _I(0), _I(pp.cin), ptr(pp.w), _lib.c_float(pp.w_inv_scale),
@@ -498,7 +505,7 @@ class TactileSR(nn.Module):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if src.dtype == torch.bfloat16:
-            call("tsr_conv2d_fwd_b16_fuse1x1", ptr(src), _I(128), _I(0), _I(128), ptr(pc.w), _I(pc.ks), ptr(pc.scale),
+            call("tsr_conv2d_fwd_b16k_fuse1x1", ptr(src), _I(128), _I(0), _I(128), ptr(pc.w), _I(pc.ks), ptr(pc.scale),
                  ptr(pc.shift), _I(1), ptr(half.w), ptr(shift2), ptr(res), _I(r_ctot), _I(r_coff), ptr(dst), _I(d_ctot),
                  _I(d_coff), _I(1 if relu2 else 0), _I(B), _I(H), _I(W), stream())
         else:

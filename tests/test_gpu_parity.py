@@ -554,6 +554,98 @@ def test_conv2d_fwd_bf16_storage(T, ks, cin, cout, B, H, W):
     assert torch.isnan(_from_cb16_bf16(out, B, 16, H, W, cout + 32, 0)).all()      # outside the slice: untouched
 
 
+B16K_CASES = [(3, 64, 64, 5, 40, 40), (5, 64, 64, 3, 40, 40), (3, 128, 128, 6, 40, 40), (5, 128, 128, 5, 40, 40),
+              (3, 448, 64, 2, 40, 40), (3, 32, 64, 1, 13, 21), (5, 96, 128, 3, 17, 9), (3, 128, 128, 1, 100, 100)]
+
+
+@pytest.mark.parametrize("ks,cin,cout,B,H,W", B16K_CASES)
+@pytest.mark.parametrize("residual", [True, False])
+def test_conv2d_fwd_b16k(T, ks, cin, cout, B, H, W, residual):
+    """tsr_conv2d_fwd_b16k (csrc/conv_b16k.hip: 16x16x32 MFMA, channels as rows, LDS-DMA circular halo): bf16 tensors in HBM,
+    bf16 operands, fp32 accumulate.  Yardstick: fp64 convolution of the bf16-ROUNDED input and weights, rounded to bf16 once:
+    >= 99 % of the outputs identical, the rest within one bf16 ulp (or the fp32-accumulation floor next to the ReLU's zero).
+    Channel slices (ctot / coff), ragged tiles, batch tails, 1..14 channel blocks; nothing outside the slice is written."""
+    from tactilesr_amd._lib import call, ptr, stream, load, c_int as I
+    g = torch.Generator().manual_seed(ks * 100 + cin + B + 11)
+    x = (torch.randn(B, cin, H, W, generator=g) * 3).to(torch.bfloat16).float()
+    w = torch.randn(cout, cin, ks, ks, generator=g) * (2.0 / (cin * ks * ks)) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    res = torch.randn(B, cout, H, W, generator=g).to(torch.bfloat16).float()
+    ref = F.conv2d(x.double(), w.bfloat16().double(), padding=ks // 2) * scale.double().view(1, -1, 1, 1) \
+        + shift.double().view(1, -1, 1, 1)
+    if residual:
+        ref = ref + res.double()
+    ref = F.relu(ref).float().bfloat16().float()
+    xin, rbuf = _to_cb16_bf16(x.cuda(), cin + 16, 16), _to_cb16_bf16(res.cuda(), cout + 16, 0)
+    wd = w.cuda().contiguous()
+    wp = torch.empty(load().tsr_conv_weight_b16k_elems(cout, cin, ks), dtype=torch.bfloat16, device="cuda")
+    call("tsr_pack_conv_weight_b16k", ptr(wd), ptr(wp), I(cout), I(cin), I(ks), stream())
+    out = torch.full((B * (cout + 32) * H * W,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    sc, sh = scale.cuda(), shift.cuda()
+    call("tsr_conv2d_fwd_b16k", ptr(xin), I(cin + 16), I(16), I(cin), ptr(wp), I(cout), I(ks), ptr(sc), ptr(sh),
+         ptr(rbuf if residual else None), I(cout + 16), I(0), ptr(out), I(cout + 32), I(16), I(1), I(B), I(H), I(W), stream())
+    got = _from_cb16_bf16(out, B, cout, H, W, cout + 32, 16).cpu()
+    ulp = (ref.abs() * 2.0 ** -7).clamp_min(1e-30)
+    d = (got - ref).abs()
+    same = float((d == 0).float().mean())
+    floor = 3e-6 * float(ref.abs().max())
+    bad = d > torch.maximum(1.01 * ulp, torch.full_like(ulp, floor))
+    print(f"[b16k] k{ks} {cin}->{cout} B={B} {H}x{W} res={residual}: identical {same:.5f}, beyond one ulp: {int(bad.sum())}")
+    assert same >= 0.99 and not bad.any()
+    assert torch.isnan(_from_cb16_bf16(out, B, 16, H, W, cout + 32, 0)).all()      # outside the slice: untouched
+    assert torch.isnan(_from_cb16_bf16(out, B, 16, H, W, cout + 32, cout + 16)).all()
+
+
+@pytest.mark.parametrize("ks,B,H,W,relu2,with_res,with_bias", [(3, 5, 40, 40, False, True, True), (5, 6, 40, 40, True, True, False),
+                                                               (3, 2, 13, 21, True, False, True), (5, 1, 100, 100, True, True, True)])
+def test_conv2d_fwd_b16k_fuse1x1(T, ks, B, H, W, relu2, with_res, with_bias):
+    """tsr_conv2d_fwd_b16k_fuse1x1: stage-2 conv (128 -> 128, folded BN, ReLU) whose bf16-rounded result feeds, as it sits in the
+    accumulator registers, the 64x128 half of the MSRB's 1x1 `confusion` (+ bias + residual, optional ReLU).  Yardstick: the
+    same two steps in fp64 on the bf16-rounded operands with the intermediate rounded to bf16 once.  A rounding-boundary
+    flip of an intermediate element (fp32 vs fp64 accumulation) moves an output by a fraction of its ulp: >= 98 % identical,
+    everything within two ulps or 2e-3 of the tensor maximum."""
+    from tactilesr_amd._lib import call, ptr, stream, load, c_int as I
+    cin = 128
+    g = torch.Generator().manual_seed(ks * 10 + B + H)
+    x = (torch.randn(B, cin, H, W, generator=g).clamp_(min=0) * 2).bfloat16()
+    w = torch.randn(128, cin, ks, ks, generator=g) * (2.0 / (cin * ks * ks)) ** 0.5
+    w2 = torch.randn(64, 128, generator=g) * (1.0 / 128) ** 0.5
+    scale, shift = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.3
+    shift2 = torch.randn(64, generator=g) * 0.2
+    res = torch.randn(B, 64, H, W, generator=g).bfloat16()
+    t = F.relu(F.conv2d(x.double(), w.bfloat16().double(), padding=ks // 2) * scale.double().view(1, -1, 1, 1)
+               + shift.double().view(1, -1, 1, 1)).float().bfloat16().double()
+    ref = torch.einsum("oc,bchw->bohw", w2.bfloat16().double(), t)
+    if with_bias:
+        ref = ref + shift2.double().view(1, -1, 1, 1)
+    if with_res:
+        ref = ref + res.double()
+    if relu2:
+        ref = F.relu(ref)
+    ref = ref.float().bfloat16().float()
+    xin = _to_cb16_bf16(x.float().cuda())
+    rbuf = _to_cb16_bf16(res.float().cuda(), 80, 16)
+    wp = torch.empty(load().tsr_conv_weight_b16k_elems(128, cin, ks), dtype=torch.bfloat16, device="cuda")
+    wd, w2d = w.cuda().contiguous(), w2.cuda().contiguous()
+    call("tsr_pack_conv_weight_b16k", ptr(wd), ptr(wp), I(128), I(cin), I(ks), stream())
+    w2p = torch.empty(64 * 128, dtype=torch.bfloat16, device="cuda")
+    call("tsr_pack_w2_b16k", ptr(w2d), ptr(w2p), stream())
+    out = torch.full((B * 96 * H * W,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    sc, sh, sh2 = scale.cuda(), shift.cuda(), shift2.cuda()
+    call("tsr_conv2d_fwd_b16k_fuse1x1", ptr(xin), I(cin), I(0), I(cin), ptr(wp), I(ks), ptr(sc), ptr(sh), I(1), ptr(w2p),
+         ptr(sh2 if with_bias else None), ptr(rbuf if with_res else None), I(80), I(16), ptr(out), I(96), I(16),
+         I(1 if relu2 else 0), I(B), I(H), I(W), stream())
+    got = _from_cb16_bf16(out, B, 64, H, W, 96, 16).cpu()
+    ulp = (ref.abs() * 2.0 ** -7).clamp_min(1e-30)
+    d = (got - ref).abs()
+    same = float((d == 0).float().mean())
+    mx = float(ref.abs().max())
+    bad = d > torch.maximum(2.01 * ulp, torch.full_like(ulp, 2e-3 * mx))
+    print(f"[b16k fused] k{ks} B={B} {H}x{W}: identical {same:.5f}, worst {float(d.max()) / mx:.2e} of max, beyond bar: {int(bad.sum())}")
+    assert same >= 0.98 and not bad.any()
+    assert torch.isnan(_from_cb16_bf16(out, B, 16, H, W, 96, 0)).all() and torch.isnan(_from_cb16_bf16(out, B, 16, H, W, 96, 80)).all()
+
+
 @pytest.mark.parametrize("tag", ["t1", "t7", "t1_l2"])
 def test_model_eval_forward_bf16_storage_vs_reference_golden(T, golden, tag):
     """conv_impl = 'bf16': every activation between the kernels is a bf16 tensor.  Stated tolerance of BASELINE's bf16
@@ -759,11 +851,12 @@ def test_conv2d_stage1_pair_kernel(T, cin, B, H, W):
 
 @pytest.mark.parametrize("cin,B,H,W", [(64, 5, 40, 40), (64, 2, 13, 21), (32, 1, 100, 100)])
 def test_conv2d_stage1_pair_kernel_bf16_storage(T, cin, B, H, W):
-    """tsr_conv2d_fwd_b16_pair: conv3x3 || conv5x5 (+ folded BN + ReLU) of one bf16 input as ONE launch (the 3x3 half's
+    """tsr_conv2d_fwd_b16k_pair: conv3x3 || conv5x5 (+ folded BN + ReLU) of one bf16 input as ONE launch (the 3x3 half's
     outer-tap MFMAs are skipped), output = torch.cat order as a bf16 tensor.  Yardstick: fp64 convolutions of the
     bf16-ROUNDED input and weights (exact products, wide accumulation) rounded to bf16 once -- the device differs only by its
     fp32 accumulation order: >= 99 % of the elements identical, the rest within one bf16 ulp; and the result equals the
-    two-launch form (tsr_conv2d_fwd_b16 twice) up to the same one-ulp rounding-boundary flips."""
+    two-launch form (tsr_conv2d_fwd_b16k twice, the 64-channel 3x3 / 5x5 instantiations) up to the same one-ulp
+    rounding-boundary flips."""
     from tactilesr_amd._lib import call, ptr, stream, load, c_int as I
     g = torch.Generator().manual_seed(cin + 7 * B + H)
     x = (torch.randn(B, cin, H, W, generator=g).clamp_(min=0) * 3).bfloat16()
@@ -778,17 +871,17 @@ def test_conv2d_stage1_pair_kernel_bf16_storage(T, cin, B, H, W):
         return T.to_cb16(t.float().cuda()).to(torch.bfloat16)
 
     def pack(w, cout, ks):
-        n = load().tsr_conv_weight_bf16s_elems(cout, cin, ks, 1)
+        n = load().tsr_conv_weight_b16k_elems(cout, cin, ks)
         wp = torch.empty(n, dtype=torch.bfloat16, device="cuda")
         wd = w.cuda().contiguous()
-        call("tsr_pack_conv_weight_bf16s", ptr(wd), ptr(wp), I(cout), I(cin), I(ks), I(1), stream())
+        call("tsr_pack_conv_weight_b16k", ptr(wd), ptr(wp), I(cout), I(cin), I(ks), stream())
         torch.cuda.synchronize()
         return wp
     xin = cb16_bf16(x)
     wpair = pack(torch.cat([F.pad(w3, (1, 1, 1, 1)), w5], 0), 128, 5)
     sc, sh = scale.cuda(), shift.cuda()
     out = torch.empty(B * 128 * H * W, dtype=torch.bfloat16, device="cuda")
-    call("tsr_conv2d_fwd_b16_pair", ptr(xin), I(cin), I(0), I(cin), ptr(wpair), ptr(sc), ptr(sh), ptr(out), I(128), I(0), I(1),
+    call("tsr_conv2d_fwd_b16k_pair", ptr(xin), I(cin), I(0), I(cin), ptr(wpair), ptr(sc), ptr(sh), ptr(out), I(128), I(0), I(1),
          I(B), I(H), I(W), stream())
     got = T.from_cb16(out, B, 128, H, W).cpu()
     ulp = (ref.float().abs() * 2.0 ** -7).clamp_min(1e-30)
@@ -804,7 +897,7 @@ def test_conv2d_stage1_pair_kernel_bf16_storage(T, cin, B, H, W):
     out2 = torch.empty_like(out)
     w3p, w5p = pack(w3, 64, 3), pack(w5, 64, 5)
     for wp_, ks, off in ((w3p, 3, 0), (w5p, 5, 64)):
-        call("tsr_conv2d_fwd_b16", ptr(xin), I(cin), I(0), I(cin), ptr(wp_), I(64), I(ks), ptr(sc[off:off + 64]),
+        call("tsr_conv2d_fwd_b16k", ptr(xin), I(cin), I(0), I(cin), ptr(wp_), I(64), I(ks), ptr(sc[off:off + 64]),
              ptr(sh[off:off + 64]), ptr(None), I(0), I(0), ptr(out2), I(128), I(off), I(1), I(B), I(H), I(W), stream())
     got2 = T.from_cb16(out2, B, 128, H, W).cpu()
     d2 = (got - got2).abs()

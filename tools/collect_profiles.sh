@@ -38,6 +38,7 @@ run bf16_stats   --kernel-trace --stats --output-format csv -d $OUT/bf16_stats  
 run bf16_fetch   --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/bf16_fetch -- $BF16
 run bf16_write   --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/bf16_write -- $BF16
 run bf16_sq      --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/bf16_sq -- $BF16
+run bf16_clk     --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/bf16_clk -- $BF16
 run trainbf16_stats --kernel-trace --stats --output-format csv -d $OUT/trainbf16_stats -- $TRAINBF16
 run trainbf16_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/trainbf16_fetch -- $TRAINBF16
 run trainbf16_write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/trainbf16_write -- $TRAINBF16

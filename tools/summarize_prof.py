@@ -110,7 +110,7 @@ if sq and only is None:
 print("wrote", sorted(f for f in os.listdir(dst) if f.startswith(tag)))
 
 clk = {}
-for mode in ("eval", "train"):
+for mode in ("eval", "train", "bf16"):
     per = collections.defaultdict(list)
     for f in files(f"{mode}_clk", "_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
