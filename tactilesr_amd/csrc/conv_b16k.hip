@@ -76,6 +76,13 @@ template <int KS, int COUT> struct B16KGeom {
 
 enum { B16K_PLAIN = 0, B16K_FUSED = 1, B16K_PAIR = 2 };
 
+#ifdef TSR_STAMP
+__device__ unsigned long long* g_b16k_stamps;
+#define STAMP(i_) if (threadIdx.x == 0 && a.slab) ((unsigned long long*)a.slab)[(size_t)blockIdx.x * 8 + (i_)] = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(i_)
+#endif
+
 // compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (the scheduling hints need constant operands)
 template <int I, int N, class F> __device__ __forceinline__ void b16k_static_for(F&& f) {
   if constexpr (I < N) {
@@ -87,6 +94,174 @@ template <int I, int N, class F> __device__ __forceinline__ void b16k_static_for
 template <int KS, int MODE, int MT> constexpr int b16k_tap_rows(int t) {
   const int kh = t / KS, kw = t - kh * KS;
   return (MODE != B16K_PAIR || (kh >= 1 && kh <= 3 && kw >= 1 && kw <= 3)) ? 0 : MT / 2;
+}
+
+typedef float kf32x8 __attribute__((ext_vector_type(8)));
+
+// Epilogue.  Lane = (pixel m of the 16-pixel row pair nt, channel quad g): acc[mt][nt] holds channels 16 mt + 4 g .. + 3 of that
+// pixel, i.e. 8 contiguous bytes of the bf16 CB16 tensor.
+//   * ReLU is t + |t| on HALVED operands (one instruction, NaN-propagating like torch's; v_max would drop a NaN and a
+//     compare + select is two): the BatchNorm vectors are halved once per channel (exact), in the fused form the 1x1 weight
+//     is packed halved (tsr_pack_w2_b16k) and bias / residual enter through an fma with 1/2; without ReLU the same h is
+//     doubled (h + h).
+//   * Fused form: the rounded stage-1 tile IS the B operand of the second product -- K slot (g, j) of K step kk = channel
+//     32 kk + 4 g + j (j < 4) or 32 kk + 16 + 4 g + j - 4 -- so the 1x1 runs straight from the accumulator registers.
+//   * Every global read is requested before the first store (behind a store the compiler may not hoist a load: the
+//     pointers could alias) and addresses are a uniform base + a 32-bit lane offset.
+template <int MT, int MODE>
+__device__ __forceinline__ void b16k_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][4], int b, int y0, int x0, int m, int g, int HW) {
+  constexpr int NT = 4;
+  const bool img_ok = b < a.B;
+  const int bsafe = img_ok ? b : 0;
+  bool ok[NT];
+  unsigned po[NT];                      // byte offset of this lane's channel quad inside a 16-channel plane
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int gy = y0 + 2 * nt + (m >> 3), gx = x0 + (m & 7);
+    ok[nt] = img_ok && gy < a.H && gx < a.W;
+    po[nt] = (ok[nt] ? (unsigned)(gy * a.W + gx) * 32u : 0u) + 8u * g;
+  }
+  const unsigned plane = (unsigned)HW * 32u;                 // bytes per (image, 16-channel block)
+  const char* rb = a.res ? (const char*)a.res + ((size_t)bsafe * (a.res_ctot >> 4) + (a.res_coff >> 4)) * plane : nullptr;
+  char* ob = (char*)a.out + ((size_t)bsafe * (a.out_ctot >> 4) + (a.out_coff >> 4)) * plane;
+  const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
+  const kb16x4 zero4h = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+  auto relu_x2 = [](f32x4 t) __attribute__((always_inline)) {
+    return (f32x4){tsr_relu_x2(t[0]), tsr_relu_x2(t[1]), tsr_relu_x2(t[2]), tsr_relu_x2(t[3])};
+  };
+
+  // BatchNorm fold of all C_out tiles, in place (halved where a ReLU follows)
+  {
+    const float hs = a.relu ? 0.5f : 1.f;
+    f32x4 sc[MT], sh[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      sc[mt] = a.scale ? *(const f32x4*)(a.scale + mt * 16 + 4 * g) : one4;
+      sh[mt] = a.shift ? *(const f32x4*)(a.shift + mt * 16 + 4 * g) : zero4;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      sc[mt] *= hs;
+      sh[mt] *= hs;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc[mt][nt] * sc[mt] + sh[mt];
+    }
+  }
+
+  if constexpr (MODE == B16K_FUSED) {
+    // 1. stage-1 activation, rounded to bf16: the B fragments of the second product (the accumulators die here)
+    kb16x8 bq[4][NT];
+    if (a.relu) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          bq[kk][nt] = __builtin_convertvector(__builtin_shufflevector(relu_x2(acc[2 * kk][nt]), relu_x2(acc[2 * kk + 1][nt]),
+                                                                       0, 1, 2, 3, 4, 5, 6, 7), kb16x8);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          bq[kk][nt] = __builtin_convertvector(__builtin_shufflevector(acc[2 * kk][nt], acc[2 * kk + 1][nt], 0, 1, 2, 3, 4, 5, 6, 7), kb16x8);
+    }
+    // 2. everything else the epilogue reads -- the W2 fragments (16 B per lane straight from L2, the same for every wave),
+    //    the bias, the residual tile -- requested in ONE round trip (beside the accumulators they would not have fit)
+    __builtin_amdgcn_sched_barrier(0);
+    const __bf16* w2 = (const __bf16*)a.w2 + ((size_t)g * 64 + m) * 8;            // [kk][g][64][8]
+    kb16x8 wa[4][4];
+    f32x4 sh2[4];
+    kb16x4 rv[4][NT];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int m2 = 0; m2 < 4; ++m2) wa[kk][m2] = *(const kb16x8*)(w2 + (size_t)kk * (4 * 64 * 8) + m2 * 16 * 8);
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2) sh2[m2] = a.shift2 ? *(const f32x4*)(a.shift2 + m2 * 16 + 4 * g) * 0.5f : zero4;
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) rv[m2][nt] = zero4h;
+    if (rb) {
+#pragma unroll
+      for (int m2 = 0; m2 < 4; ++m2)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) rv[m2][nt] = *(const kb16x4*)(rb + (m2 * plane + po[nt]));
+    }
+    // 3. per pair of output tiles: acc2 = (W2 / 2) . bq; h = acc2 + (residual / 2 + shift2 / 2); out = h + |h| (ReLU) or h + h,
+    //    bf16, 8-B stores
+#define B16K_OUT2(EXPR_)                                                                  \
+  _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                     \
+    kb16x4 o[2];                                                                          \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                       \
+      kb16x4 r_ = rv[2 * mh + u][nt];                                                     \
+      asm volatile("" : "+v"(r_));       /* (hipcc would convert all 16 quads ahead of the product and spill them) */ \
+      const f32x4 h = acc2[u][nt] + (__builtin_convertvector(r_, f32x4) * 0.5f + sh2[2 * mh + u]); \
+      o[u] = __builtin_convertvector(EXPR_, kb16x4);                                      \
+    }                                                                                     \
+    if (ok[nt]) {                                                                         \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) *(kb16x4*)(ob + ((2 * mh + u) * plane + po[nt])) = o[u]; \
+    }                                                                                     \
+  }
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+      f32x4 acc2[2][NT];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc2[u][nt] = zero4;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc2[u][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[kk][2 * mh + u], bq[kk][nt], acc2[u][nt], 0, 0, 0);
+      if (a.relu2) { B16K_OUT2(relu_x2(h)) } else { B16K_OUT2(h + h) }
+    }
+#undef B16K_OUT2
+  } else {
+    // plain form: h = bn(acc) [+ residual] (halved under a ReLU), nt-outer: one exec mask per row pair
+    const float hs = a.relu ? 0.5f : 1.f;
+#define B16K_OUT1(H_, EXPR_)                                                              \
+  _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                     \
+    kb16x4 o[MT];                                                                         \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                   \
+      const f32x4 h = H_;                                                                 \
+      o[mt] = __builtin_convertvector(EXPR_, kb16x4);                                     \
+    }                                                                                     \
+    if (ok[nt]) {                                                                         \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) *(kb16x4*)(ob + (mt * plane + po[nt])) = o[mt]; \
+    }                                                                                     \
+  }
+    if (rb) {      // (a residual: the ResBlock's second conv -- all quads of a row pair requested together, one pair ahead)
+      kb16x4 rv[2][MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) rv[0][mt] = *(const kb16x4*)(rb + (mt * plane + po[0]));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (nt + 1 < NT) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) rv[(nt + 1) & 1][mt] = *(const kb16x4*)(rb + (mt * plane + po[nt + 1]));
+        }
+        kb16x4 o[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const f32x4 h = __builtin_convertvector(rv[nt & 1][mt], f32x4) * hs + acc[mt][nt];
+          o[mt] = __builtin_convertvector(a.relu ? relu_x2(h) : h, kb16x4);
+        }
+        if (ok[nt]) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) *(kb16x4*)(ob + (mt * plane + po[nt])) = o[mt];
+        }
+      }
+    } else if (a.relu) {
+      B16K_OUT1(acc[mt][nt], relu_x2(h))
+    } else {
+      B16K_OUT1(acc[mt][nt], h)
+    }
+#undef B16K_OUT1
+  }
 }
 
 // Halo-row requests of step t of a block (two slots; -1 = none): row r of the CURRENT block = r, of the NEXT block = 16 + r.
@@ -133,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
   const int lane = tid & 63;
   const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, g = lane >> 4;
+  STAMP(0);
 
   int bid;
   {
@@ -240,6 +416,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
   LOAD_B(1, 0, 0, 0);
   // (step 0 re-requests slot 0 -- slab 3 -- right away: every wave must have READ slab 0 first)
   STEP_END(WV);
+  STAMP(1);
 
   int s = 0, slot = 0;
   for (int c = 0; c < nblk; ++c) {
@@ -289,6 +466,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
   }
   // (the trailing requests fetch nothing but still write LDS: none may be in flight when the workgroup's LDS is released)
   VM_WAIT(0);
+  STAMP(2);
 #undef DMA_W
 #undef VM_WAIT
 #undef STEP_END
@@ -297,151 +475,11 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
 #undef MFMA
 #undef SGB
 
-  // ---- epilogue: lane = (pixel m of row pair nt, channel quad g).  Every global read is requested in program order BEFORE the
-  // first store of its phase: behind a store to `out` the compiler may not hoist a load (the pointers could alias), and a
-  // load waited for where it is used is a full round trip in a workgroup that has no MFMA work left to cover it.
-  const int b = b0 + wm;
-  const bool img_ok = b < a.B;
-  const int bsafe = img_ok ? b : 0;
-  const int out_blocks = a.out_ctot >> 4, res_blocks = a.res_ctot >> 4;
-  bool ok[NT];
-  unsigned po[NT];                      // element offset of the pixel inside a 16-channel plane
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int gy = y0 + 2 * nt + (m >> 3), gx = x0 + (m & 7);
-    ok[nt] = img_ok && gy < a.H && gx < a.W;
-    po[nt] = ok[nt] ? (unsigned)(gy * a.W + gx) * 16u : 0u;
-  }
-  const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
-  const kb16x4 zero4h = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-  const float lo = a.relu ? 0.f : -__builtin_inff();          // v < lo ? lo : v  -- ReLU or identity, NaN-propagating
-  constexpr int OT = MODE == B16K_FUSED ? 4 : MT;            // C_out tiles of the tensor this launch writes
-  const __bf16* rbase = a.res ? (const __bf16*)a.res + (((size_t)bsafe * res_blocks + (a.res_coff >> 4)) * HW) * 16 + 4 * g : nullptr;
-  __bf16* obase = (__bf16*)a.out + (((size_t)bsafe * out_blocks + (a.out_coff >> 4)) * HW) * 16 + 4 * g;
-  const size_t plane = (size_t)HW * 16;                      // elements per (image, 16-channel block)
-  const __bf16* w2 = (const __bf16*)a.w2 + ((size_t)g * 64 + m) * 8;              // fused form: [kk][g][64][8]
-  kb16x8 wa[2][4];
-  f32x4 sh2[4];
-  if constexpr (MODE == B16K_FUSED) {        // the first two K steps' W2 fragments and the bias travel under the BatchNorm fold
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int m2 = 0; m2 < 4; ++m2) wa[kk][m2] = *(const kb16x8*)(w2 + (size_t)kk * (4 * 64 * 8) + m2 * 16 * 8);
-#pragma unroll
-    for (int m2 = 0; m2 < 4; ++m2) sh2[m2] = a.shift2 ? *(const f32x4*)(a.shift2 + m2 * 16 + 4 * g) : zero4;
-  }
-  // BatchNorm fold of all C_out tiles, in place.  Fused form with ReLU: the fold yields v / 2 and ReLU is v/2 + |v/2| (one
-  // instruction, NaN-propagating, exact: a power-of-two factor)
-  {
-    const float hs = (MODE == B16K_FUSED && a.relu) ? 0.5f : 1.f;
-    f32x4 sc[MT], sh[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      sc[mt] = a.scale ? *(const f32x4*)(a.scale + mt * 16 + 4 * g) : one4;
-      sh[mt] = a.shift ? *(const f32x4*)(a.shift + mt * 16 + 4 * g) : zero4;
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      sc[mt] *= hs;
-      sh[mt] *= hs;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[mt][nt][i] = fmaf(acc[mt][nt][i], sc[mt][i], sh[mt][i]);
-    }
-  }
-
-  if constexpr (MODE == B16K_FUSED) {
-    // 1. ReLU, rounded to bf16: bq[kk][nt] IS the B fragment of K step kk of the second product (K slot (g, j): channel
-    //    32 kk + 4 g + j for j < 4, 32 kk + 16 + 4 g + j - 4 for j >= 4)
-    kb16x8 bq[4][NT];
-    if (a.relu) {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bq[kk][nt][4 * u + i] = (__bf16)tsr_relu_x2(acc[2 * kk + u][nt][i]);
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bq[kk][nt][4 * u + i] = (__bf16)acc[2 * kk + u][nt][i];
-    }
-    // 2. out2[64 co][64 px] = W2 . bq ; the W2 fragments come straight from L2 (16 B per lane, the same for every wave);
-    //    the output stage's residual tile is requested under the product
-    kb16x4 rv[4][NT];
-#pragma unroll
-    for (int m2 = 0; m2 < 4; ++m2)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) rv[m2][nt] = rbase ? *(const kb16x4*)(rbase + m2 * plane + po[nt]) : zero4h;
-    f32x4 acc2[4][NT];
-#pragma unroll
-    for (int m2 = 0; m2 < 4; ++m2)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc2[m2][nt] = sh2[m2];        // the product accumulates onto the bias
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-      for (int m2 = 0; m2 < 4; ++m2)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc2[m2][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[kk & 1][m2], bq[kk][nt], acc2[m2][nt], 0, 0, 0);
-      if (kk + 2 < 4) {
-#pragma unroll
-        for (int m2 = 0; m2 < 4; ++m2) wa[kk & 1][m2] = *(const kb16x8*)(w2 + (size_t)(kk + 2) * (4 * 64 * 8) + m2 * 16 * 8);
-      }
-    }
-    // 3. + bias + residual (bf16), ReLU, bf16 store: 4 consecutive channels of a pixel per lane
-    const float lo2 = a.relu2 ? 0.f : -__builtin_inff();
-#pragma unroll
-    for (int m2 = 0; m2 < 4; ++m2)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        kb16x4 o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float v = acc2[m2][nt][i] + (float)rv[m2][nt][i];
-          o[i] = (__bf16)(v < lo2 ? lo2 : v);
-        }
-        if (ok[nt]) *(kb16x4*)(obase + m2 * plane + po[nt]) = o;
-      }
-  } else {
-    // residual tiles two C_out tiles ahead of the stores
-    kb16x4 rv[2][2][NT];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) rv[0][u][nt] = rbase ? *(const kb16x4*)(rbase + u * plane + po[nt]) : zero4h;
-#pragma unroll
-    for (int mp = 0; mp < OT / 2; ++mp) {
-      if (mp + 1 < OT / 2) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            rv[(mp + 1) & 1][u][nt] = rbase ? *(const kb16x4*)(rbase + (2 * mp + 2 + u) * plane + po[nt]) : zero4h;
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          kb16x4 o;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float v = acc[2 * mp + u][nt][i] + (float)rv[mp & 1][u][nt][i];
-            o[i] = (__bf16)(v < lo ? lo : v);
-          }
-          if (ok[nt]) *(kb16x4*)(obase + (2 * mp + u) * plane + po[nt]) = o;
-        }
-    }
-  }
+  b16k_epilogue<MT, MODE>(a, acc, b0 + wm, y0, x0, m, g, HW);
+#ifdef TSR_STAMP
+  __builtin_amdgcn_s_waitcnt(0);
+  STAMP(3);
+#endif
 }
 
 // ---- weight packs ------------------------------------------------------------------------------------------------------
@@ -461,7 +499,7 @@ __global__ void pack_b16k_kernel(const float* __restrict__ w, __bf16* __restrict
   }
 }
 
-// [64][128] fp32 (one half of an MSRB's `confusion` weight) -> [kk 4][g 4][64][8] bf16 in the K order in which the fused
+// [64][128] fp32 (one half of an MSRB's `confusion` weight) -> HALVED, [kk 4][g 4][64][8] bf16 in the K order in which the fused
 // epilogue's accumulators ARE the B operand: slot (g, j) of K step kk = channel 32 kk + 4 g + j (j < 4) or
 // 32 kk + 16 + 4 g + (j - 4) (j >= 4)
 __global__ void pack_w2_b16k_kernel(const float* __restrict__ w2, __bf16* __restrict__ wp) {
@@ -469,11 +507,15 @@ __global__ void pack_w2_b16k_kernel(const float* __restrict__ w2, __bf16* __rest
   if (i >= 64 * 128) return;
   const int j = i & 7, co = (i >> 3) & 63, g = (i >> 9) & 3, kk = i >> 11;
   const int ch = 32 * kk + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4));
-  wp[i] = (__bf16)w2[co * 128 + ch];
+  wp[i] = (__bf16)(0.5f * w2[co * 128 + ch]);       // halved (exact): the fused epilogue's ReLU is h + |h| on halves
 }
 
 extern "C" long long tsr_conv_weight_b16k_elems(int cout, int cin, int ks) { return (long long)cout * cin * ks * ks; }
 
+#ifdef TSR_STAMP
+static void* g_stamp_buf = nullptr;
+extern "C" int tsr_debug_set_stamps(void* dev_buf) { g_stamp_buf = dev_buf; return 0; }
+#endif
 static bool b16k_shape_ok(int cout, int cin, int ks) {
   return (cout == 64 || cout == 128) && cin > 0 && (cin & 31) == 0 && (ks == 3 || ks == 5);
 }
@@ -511,6 +553,9 @@ static int b16k_fill(ConvArgs& a, const void* in, int in_ctot, int in_coff, int 
   a.B = B; a.H = H; a.W = W;
   a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8;
   (void)cout;
+#ifdef TSR_STAMP
+  a.slab = (float*)g_stamp_buf;
+#endif
   return TSR_OK;
 }
 
