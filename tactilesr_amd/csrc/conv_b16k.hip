@@ -42,14 +42,16 @@ __device__ __forceinline__ void b16k_dma(ki32x4 rs, int vo, int so, unsigned m0v
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "s"(m0v), "v"(vo), "s"(rs), "s"(so));
 }
-// two requests of the lanes in `mask` only (the same source bytes to two LDS rows)
-__device__ __forceinline__ void b16k_dma2_masked(ki32x4 rs, int vo, int so, unsigned m0a, unsigned m0b, unsigned long long mask) {
+// one request of the lanes in `mask` only; `m0b` != 0: a second one with the same source bytes to that LDS row (the branch
+// lives inside the statement: no basic-block boundary for the compiler)
+__device__ __forceinline__ void b16k_dma_row(ki32x4 rs, int vo, int so, unsigned m0a, unsigned m0b, unsigned long long mask) {
   unsigned long long sv;
   unsigned keep;
   asm volatile("s_mov_b32 %1, m0\n\ts_mov_b64 %0, exec\n\ts_mov_b64 exec, %7\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-               "buffer_load_dwordx4 %4, %5, %6 offen lds\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-               "buffer_load_dwordx4 %4, %5, %6 offen lds\n\ts_mov_b64 exec, %0\n\ts_mov_b32 m0, %1"
-               : "=&s"(sv), "=&s"(keep) : "s"(m0a), "s"(m0b), "v"(vo), "s"(rs), "s"(so), "s"(mask));
+               "buffer_load_dwordx4 %4, %5, %6 offen lds\n\ts_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 .Lb16k_skip%=\n\t"
+               "s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds\n"
+               ".Lb16k_skip%=:\n\ts_mov_b64 exec, %0\n\ts_mov_b32 m0, %1"
+               : "=&s"(sv), "=&s"(keep) : "s"(m0a), "s"(m0b), "v"(vo), "s"(rs), "s"(so), "s"(mask) : "scc");
 }
 __device__ __forceinline__ unsigned b16k_lds_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
@@ -68,7 +70,7 @@ template <int KS, int COUT> struct B16KGeom {
   static constexpr int ROWB = b16k_row_slots(HH) * 16;
   static constexpr int NROW = 16;                    // physical halo rows per image: a circular buffer (see below)
   static constexpr int IMGB = (NROW + 1) * ROWB;     // + row 16, a copy of row 0 (a row pair may start at row 15)
-  static constexpr int HALO_B = 4 * IMGB + ROWB;     // + one row nobody reads (where the copy goes when the row is not row 0)
+  static constexpr int HALO_B = 4 * IMGB;
   static constexpr int WTAP_B = 64 * COUT;           // 32 channels x C_out bf16
   static constexpr int RING = 3;
   static constexpr int LDS_B = HALO_B + RING * WTAP_B;
@@ -109,7 +111,8 @@ typedef float kf32x8 __attribute__((ext_vector_type(8)));
 //   * Every global read is requested before the first store (behind a store the compiler may not hoist a load: the
 //     pointers could alias) and addresses are a uniform base + a 32-bit lane offset.
 template <int MT, int MODE>
-__device__ __forceinline__ void b16k_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][4], int b, int y0, int x0, int m, int g, int HW) {
+__device__ __forceinline__ void b16k_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][4], int b, int y0, int x0, int m, int g, int HW,
+                                              const char* w2h0, const char* w2h1) {
   constexpr int NT = 4;
   const bool img_ok = b < a.B;
   const int bsafe = img_ok ? b : 0;
@@ -149,7 +152,26 @@ __device__ __forceinline__ void b16k_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
   }
 
   if constexpr (MODE == B16K_FUSED) {
-    // 1. stage-1 activation, rounded to bf16: the B fragments of the second product (the accumulators die here)
+    // 1. the residual tile and the bias are requested HERE -- the BatchNorm vectors' registers are free again -- and travel
+    //    under the conversion
+    __builtin_amdgcn_sched_barrier(0);
+    kb16x8 wa[4][4];
+    f32x4 sh2[4];
+    kb16x4 rv[4][NT];
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) rv[m2][nt] = zero4h;
+    if (rb) {
+#pragma unroll
+      for (int m2 = 0; m2 < 4; ++m2)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) rv[m2][nt] = *(const kb16x4*)(rb + (m2 * plane + po[nt]));
+    }
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2) sh2[m2] = a.shift2 ? *(const f32x4*)(a.shift2 + m2 * 16 + 4 * g) * 0.5f : zero4;
+    __builtin_amdgcn_sched_barrier(0);
+    // 2. stage-1 activation, rounded to bf16: the B fragments of the second product (the accumulators die here)
     kb16x8 bq[4][NT];
     if (a.relu) {
 #pragma unroll
@@ -165,29 +187,12 @@ __device__ __forceinline__ void b16k_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
         for (int nt = 0; nt < NT; ++nt)
           bq[kk][nt] = __builtin_convertvector(__builtin_shufflevector(acc[2 * kk][nt], acc[2 * kk + 1][nt], 0, 1, 2, 3, 4, 5, 6, 7), kb16x8);
     }
-    // 2. everything else the epilogue reads -- the W2 fragments (16 B per lane straight from L2, the same for every wave),
-    //    the bias, the residual tile -- requested in ONE round trip (beside the accumulators they would not have fit)
-    __builtin_amdgcn_sched_barrier(0);
-    const __bf16* w2 = (const __bf16*)a.w2 + ((size_t)g * 64 + m) * 8;            // [kk][g][64][8]
-    kb16x8 wa[4][4];
-    f32x4 sh2[4];
-    kb16x4 rv[4][NT];
+    // the W2 fragments: LDS, [kk & 1][g][64][8] inside the half kk >> 1 (landed and published by the main loop's last barriers)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int m2 = 0; m2 < 4; ++m2) wa[kk][m2] = *(const kb16x8*)(w2 + (size_t)kk * (4 * 64 * 8) + m2 * 16 * 8);
-#pragma unroll
-    for (int m2 = 0; m2 < 4; ++m2) sh2[m2] = a.shift2 ? *(const f32x4*)(a.shift2 + m2 * 16 + 4 * g) * 0.5f : zero4;
-#pragma unroll
-    for (int m2 = 0; m2 < 4; ++m2)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) rv[m2][nt] = zero4h;
-    if (rb) {
-#pragma unroll
       for (int m2 = 0; m2 < 4; ++m2)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) rv[m2][nt] = *(const kb16x4*)(rb + (m2 * plane + po[nt]));
-    }
+        wa[kk][m2] = *(const kb16x8*)((kk < 2 ? w2h0 : w2h1) + (((kk & 1) * 4 + g) * 64 + m2 * 16 + m) * 16);
     // 3. per pair of output tiles: acc2 = (W2 / 2) . bq; h = acc2 + (residual / 2 + shift2 / 2); out = h + |h| (ReLU) or h + h,
     //    bf16, 8-B stores
 #define B16K_OUT2(EXPR_)                                                                  \
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
   const unsigned img_stride = (unsigned)in_blocks * HW * 32;                      // bytes per image
   const int lane_base = (int)(wm * img_stride) + hgx * 32 + (hqd >> 1) * HW * 32 + (hqd & 1) * 16;
   const unsigned long long in_grp = (unsigned long long)((const char*)a.in + ((size_t)b0 * in_blocks + (a.in_coff >> 4)) * HW * 32);
-  const unsigned long long w_base = (unsigned long long)a.wp;
+  const unsigned long long w_base = (unsigned long long)a.wp, w2_base = (unsigned long long)a.w2;
   // An offset beyond the descriptor's range makes a buffer load return zeros: the zero padding (a lane whose column lies
   // outside the image carries such an offset), and -- through a descriptor of range ZERO (a scalar select on its
   // num_records word) -- a row outside the image / a request that has nothing to fetch.  Such requests are issued all the
@@ -355,9 +360,11 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
     const int prow = (cblk * HH + r) & 15;
     const unsigned dst = halo_a + wm * IMGB + prow * ROWB;
     // physical row 0 has a copy behind row 15: lanes m >= 8 of a fragment read the row AFTER the (uniform) first row
-    const unsigned dst2 = prow == 0 ? dst + 16 * ROWB : halo_a + 4 * IMGB;
-    const ki32x4 rs = {(int)in_grp, (int)(in_grp >> 32) & 0xffff, row_ok ? 0x7fffffff : 0, 0x00020000};
-    b16k_dma2_masked(rs, vo_lane, row_ok ? cblk * HW * 64 + gy * a.W * 32 : 0, dst, dst2, (1ull << (4 * HH)) - 1);
+    const unsigned dst2 = (dst + 16 * ROWB) & -(unsigned)(prow == 0);  // (an LDS address of a halo row is never 0: row 16)
+    // (masks, not selects: hipcc turns a select between an expression and 0 into a BRANCH, and a basic-block boundary inside a
+    //  step ends its MFMA / LDS-read interleave)
+    const ki32x4 rs = {(int)in_grp, (int)(in_grp >> 32) & 0xffff, 0x7fffffff & -(int)row_ok, 0x00020000};
+    b16k_dma_row(rs, vo_lane, cblk * HW * 64 + gy * a.W * 32, dst, dst2, (1ull << (4 * HH)) - 1);
   };
   const int wvo = tid * 16;
 
@@ -373,13 +380,26 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
   const int nblk = a.cin >> 5;
   const int S = nblk * T;
 
+  // (fused form: the two requests past the end of the conv's stream -- their slots are dead -- fetch the two 8-KB halves of the
+  //  packed 1x1 weight instead of nothing: the epilogue reads its W2 fragments from LDS)
 #define DMA_W(sidx, slot_)                                                                \
   {                                                                                      \
-    const bool real_ = (sidx) < S;                                                       \
-    const ki32x4 rs_ = {(int)w_base, (int)(w_base >> 32) & 0xffff, real_ ? 0x7fffffff : 0, 0x00020000}; \
-    const int so_ = real_ ? (sidx) * WTAP_B : 0;                                         \
+    const int real_ = -(int)((sidx) < S);                 /* all ones / zero: masks, not selects (see dma_row) */ \
+    const int w2_ = MODE == B16K_FUSED ? ~real_ & -(int)((sidx) < S + 2) : 0;            \
+    const int blo_ = (int)w2_base ^ (((int)w_base ^ (int)w2_base) & real_);              \
+    const int bhi_ = (int)(w2_base >> 32) ^ (((int)(w_base >> 32) ^ (int)(w2_base >> 32)) & real_); \
+    const ki32x4 rs_ = {blo_, bhi_ & 0xffff, 0x7fffffff & (real_ | w2_), 0x00020000};    \
+    const int so_ = (((sidx) - S) * 8192) ^ (((((sidx) - S) * 8192) ^ ((sidx) * WTAP_B)) & real_); \
     const unsigned dst_ = wbuf_a + (slot_) * WTAP_B + wm * 1024;                         \
     _Pragma("unroll") for (int v = 0; v < WV; ++v) b16k_dma(rs_, wvo, so_ + v * 4096, dst_ + v * 4096); \
+  }
+  // pair form, a slab of an OUTER tap: only the 5x5 conv's channels (co >= 64: the second KB of every 2-KB k group) are ever
+  // read -- one request per wave (k group = wave) instead of two
+#define DMA_W_HI(sidx, slot_)                                                             \
+  {                                                                                      \
+    const int real_ = -(int)((sidx) < S);                                                \
+    const ki32x4 rs_ = {(int)w_base, (int)(w_base >> 32) & 0xffff, 0x7fffffff & real_, 0x00020000}; \
+    b16k_dma(rs_, wvo, (sidx) * WTAP_B + wm * 1024 + 1024, wbuf_a + (slot_) * WTAP_B + wm * 2048 + 1024); \
   }
   // vmcnt wait that leaves the n_ youngest vector-memory operations in flight (they count in issue order)
 #define VM_WAIT(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14))
@@ -440,7 +460,11 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
       SGB(0x008, 2 * (MT - m0));
       __builtin_amdgcn_sched_barrier(0);
       // this step's requests, issued behind the first half's MFMAs (right after the barrier they would delay them)
-      DMA_W(s + 3, slot);                                      // slab s was read during step s-1: its slot is free
+      // slab s was read during step s-1: its slot is free
+      constexpr int t3 = (t + 3) % T;
+      constexpr bool hi3 = b16k_tap_rows<KS, MODE, MT>(t3) != 0;
+      constexpr int WVS = hi3 ? 1 : WV;
+      if constexpr (hi3) { DMA_W_HI(s + 3, slot); } else { DMA_W(s + 3, slot); }
       if constexpr (j0 >= 0) dma_row(c + (j0 >> 4), j0 & 15, (j0 >> 4) == 0 || more);
       if constexpr (j1 >= 0) dma_row(c + (j1 >> 4), j1 & 15, (j1 >> 4) == 0 || more);
       LOAD_B(0, (t + 1 < T ? rb : rbn), nkh, nkw);
@@ -459,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
       });
       // everything requested BEFORE this step has landed (this step's own requests stay in flight): slab s+2, the halo
       // rows of step s-1
-      STEP_END(WV + 2 * NJ);
+      STEP_END(WVS + NJ);
       ++s;
       slot = slot1;
     });
@@ -468,6 +492,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
   VM_WAIT(0);
   STAMP(2);
 #undef DMA_W
+#undef DMA_W_HI
 #undef VM_WAIT
 #undef STEP_END
 #undef LOAD_A
@@ -475,7 +500,8 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
 #undef MFMA
 #undef SGB
 
-  b16k_epilogue<MT, MODE>(a, acc, b0 + wm, y0, x0, m, g, HW);
+  // (fused form: the 1x1 weight's halves sit in the ring slots of the two requests past the stream's end, slabs S and S+1)
+  b16k_epilogue<MT, MODE>(a, acc, b0 + wm, y0, x0, m, g, HW, wbuf + slot * WTAP_B, wbuf + (slot == 2 ? 0 : slot + 1) * WTAP_B);
 #ifdef TSR_STAMP
   __builtin_amdgcn_s_waitcnt(0);
   STAMP(3);
