@@ -327,9 +327,8 @@ def run_infer(args, world, rank, dev):
         k32 = args.impl == "fp16x3"                                             # conv_mfma_k32.hip (16x16x32 MFMA)
         kname = ("conv_mfma_f32_kernel<5, 128" if args.impl == "f32" else
                  ("conv_k32_kernel<5, 128, false, 2, %s" % ("true, false, 256" if fused else "false, false, 512")) if k32 else
-                 # (bf16 storage: <KS, COUT, NS, EXT, F16, WN, DBH, IO16, FUSE2, PAIR> -- spelled out, the stage-1 pair
-                 #  instantiation shares the shorter prefix)
-                 ("conv_mfma_split16_kernel<5, 128, 1, false, false, 1, false, true, %s, false" % ("true" if fused else "false"))
+                 # (bf16 storage: csrc/conv_b16k.hip <KS, COUT, MODE>, MODE 1 = the fused form, 0 = plain)
+                 ("conv_b16k_kernel<5, 128, %d" % (1 if fused else 0))
                  if args.impl == "bf16" else
                  "conv_mfma_split16_kernel<5, 128, %d, false, %s" % ({"fp16x3": 2, "bf16x6": 3, "bf16x3": 2}[args.impl],
                                                                      "true" if args.impl == "fp16x3" else "false"))

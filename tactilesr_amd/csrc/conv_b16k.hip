@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
 #define STEP_END(n_)                                                                     \
   {                                                                                      \
     asm volatile("" ::: "memory");                                                       \
-    __builtin_amdgcn_s_waitcnt(0x0070 | ((n_) & 15) | (((n_) >> 4) << 14));              \
+    __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14));              \
     __builtin_amdgcn_s_barrier();                                                        \
     asm volatile("" ::: "memory");                                                       \
   }
@@ -426,16 +426,13 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
   for (int r = 0; r < 8; ++r) dma_row(0, r, true);
   DMA_W(0, 0);
   DMA_W(1, 1);
-  DMA_W(2, 2);
-  STEP_END(WV);
+  STEP_END(0);
 
   kb16x8 A[MT], Bf[NT];
 #pragma unroll
   for (int mt = b16k_tap_rows<KS, MODE, MT>(0); mt < MT; ++mt) LOAD_A(mt, 0);
   LOAD_B(0, 0, 0, 0);
   LOAD_B(1, 0, 0, 0);
-  // (step 0 re-requests slot 0 -- slab 3 -- right away: every wave must have READ slab 0 first)
-  STEP_END(WV);
   STAMP(1);
 
   int s = 0, slot = 0;
@@ -452,6 +449,12 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
       constexpr int NJ = (j0 >= 0) + (j1 >= 0);
       const int slot1 = slot == 2 ? 0 : slot + 1;
       const int rb = opaque(rb0), rbn = (rb + HH) & 15;
+      // slab s+2 -> the slot of slab s-1: its fragments were read during step s-2 and consumed by step s-1's MFMAs, and every
+      // wave has passed the barrier that ended step s-1
+      constexpr int t2 = (t + 2) % T;
+      constexpr bool hi2 = b16k_tap_rows<KS, MODE, MT>(t2) != 0;
+      const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
+      if constexpr (hi2) { DMA_W_HI(s + 2, slot2); } else { DMA_W(s + 2, slot2); }
       LOAD_B(2, rb, kh, kw);
       LOAD_B(3, rb, kh, kw);
 #pragma unroll
@@ -460,11 +463,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
       SGB(0x008, 2 * (MT - m0));
       __builtin_amdgcn_sched_barrier(0);
       // this step's requests, issued behind the first half's MFMAs (right after the barrier they would delay them)
-      // slab s was read during step s-1: its slot is free
-      constexpr int t3 = (t + 3) % T;
-      constexpr bool hi3 = b16k_tap_rows<KS, MODE, MT>(t3) != 0;
-      constexpr int WVS = hi3 ? 1 : WV;
-      if constexpr (hi3) { DMA_W_HI(s + 3, slot); } else { DMA_W(s + 3, slot); }
+
       if constexpr (j0 >= 0) dma_row(c + (j0 >> 4), j0 & 15, (j0 >> 4) == 0 || more);
       if constexpr (j1 >= 0) dma_row(c + (j1 >> 4), j1 & 15, (j1 >> 4) == 0 || more);
       LOAD_B(0, (t + 1 < T ? rb : rbn), nkh, nkw);
@@ -483,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
       });
       // everything requested BEFORE this step has landed (this step's own requests stay in flight): slab s+2, the halo
       // rows of step s-1
-      STEP_END(WVS + NJ);
+      STEP_END(NJ);
       ++s;
       slot = slot1;
     });
