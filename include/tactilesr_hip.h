@@ -128,29 +128,20 @@ int tsr_conv2d_fwd_f16s_fuse1x1(const float* in, int in_ctot, int in_coff, int c
 int tsr_conv2d_fwd_b16(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed, int cout, int ks,
                        const float* scale, const float* shift, const void* res, int res_ctot, int res_coff,
                        void* out, int out_ctot, int out_coff, int relu, int B, int H, int W, void* stream);
-/* ... and its stage-2 form with half of the 1x1 `confusion` fused (see tsr_conv2d_fwd_f16s_fuse1x1; w2_packed =
- * tsr_pack_conv_weight_bf16s(nsplit = 1) of the 64x128x1x1 half; res / out are 64-channel bf16 tensors). */
-int tsr_conv2d_fwd_b16_fuse1x1(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed, int ks,
-                               const float* scale, const float* shift, int relu,
-                               const void* w2_packed, const float* shift2,
-                               const void* res, int res_ctot, int res_coff,
-                               void* out, int out_ctot, int out_coff, int relu2,
-                               int B, int H, int W, void* stream);
-/* ... and the stage-1 pair of an MSRB on bf16 tensors: conv_3_1 || conv_5_1 (each conv + BN + ReLU,
- * model/tactileSR_model.py:167-175) and the first torch.cat (:200) as ONE launch on one staged halo.  w_packed =
- * tsr_pack_conv_weight_bf16s(W, cout = 128, cin, ks = 5, nsplit = 1) of W = cat([3x3 weight zero-padded to 5x5, 5x5
- * weight]) along C_out; scale / shift = the two convs' folded BatchNorm vectors concatenated (128); out = 128 channels in
- * torch.cat order.  The 3x3 half's MFMAs on the 16 outer taps are not issued. */
-int tsr_conv2d_fwd_b16_pair(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed,
-                            const float* scale, const float* shift, void* out, int out_ctot, int out_coff,
-                            int relu, int B, int H, int W, void* stream);
 /* The bf16-storage INFERENCE convolutions proper (csrc/conv_b16k.hip; 3x3 / 5x5, C_out 64 / 128, C_in a multiple of 32):
  * v_mfma_f32_16x16x32_bf16 with channels as rows -- the accumulators are in CB16 order (8-B bf16 stores, no transpose)
  * and, for the fused form, already the operand layout of the 1x1 product -- LDS-DMA halo rows into a circular row buffer
- * and an LDS-DMA weight ring.  Same arguments and semantics as the three entries above; the weight layouts differ:
+ * and an LDS-DMA weight ring.  tsr_conv2d_fwd_b16k: same arguments and semantics as tsr_conv2d_fwd_b16.
+ * tsr_conv2d_fwd_b16k_fuse1x1: a stage-2 convolution of an MSRB (128 -> 128, folded BatchNorm, ReLU) with its half of the
+ * 1x1 `confusion` applied to the tile as it sits in the accumulator registers (see tsr_conv2d_fwd_f16s_fuse1x1; res / out
+ * are 64-channel bf16 tensors).  tsr_conv2d_fwd_b16k_pair: the stage-1 pair of an MSRB, conv_3_1 || conv_5_1 (each conv +
+ * BN + ReLU, model/tactileSR_model.py:167-175) and the first torch.cat (:200) as ONE launch on one staged halo: w_packed =
+ * the pack of W = cat([3x3 weight zero-padded to 5x5, 5x5 weight]) along C_out (cout = 128, ks = 5), scale / shift = the two
+ * convs' folded BatchNorm vectors concatenated (128), out = 128 channels in torch.cat order; the 3x3 half's MFMAs, fragment
+ * reads and weight bytes on the 16 outer taps are skipped.  The weight layouts:
  * w_packed from tsr_pack_conv_weight_b16k ([C_in/32][tap][4][C_out][8] bf16; tsr_conv_weight_b16k_elems elements),
- * w2_packed from tsr_pack_w2_b16k (the 64x128 fp32 half of `confusion`, model/tactileSR_model.py:203-206, in the K order
- * of the fused epilogue). */
+ * w2_packed from tsr_pack_w2_b16k (the 64x128 fp32 half of `confusion`, model/tactileSR_model.py:203-206, HALVED, in the K
+ * order of the fused epilogue). */
 long long tsr_conv_weight_b16k_elems(int cout, int cin, int ks);
 int tsr_pack_conv_weight_b16k(const float* w_oihw, void* w_packed, int cout, int cin, int ks, void* stream);
 int tsr_pack_w2_b16k(const float* w2_64x128, void* w_packed, void* stream);

@@ -39,8 +39,6 @@ SIGNATURES = {
     "tsr_conv2d_fwd_f16s_pair": [_P, _I, _I, _I, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "tsr_head_fwd": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _P],
     "tsr_conv2d_fwd_b16": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],
-    "tsr_conv2d_fwd_b16_fuse1x1": [_P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],
-    "tsr_conv2d_fwd_b16_pair": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "tsr_conv_weight_b16k_elems": [_I, _I, _I],
     "tsr_pack_conv_weight_b16k": [_P, _P, _I, _I, _I, _P],
     "tsr_pack_w2_b16k": [_P, _P, _P],

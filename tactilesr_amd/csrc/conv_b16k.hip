@@ -53,6 +53,16 @@ __device__ __forceinline__ void b16k_dma_row(ki32x4 rs, int vo, int so, unsigned
                ".Lb16k_skip%=:\n\ts_mov_b64 exec, %0\n\ts_mov_b32 m0, %1"
                : "=&s"(sv), "=&s"(keep) : "s"(m0a), "s"(m0b), "v"(vo), "s"(rs), "s"(so), "s"(mask) : "scc");
 }
+// one request of the lanes in `mask` only (mask 0: the wave takes no part)
+__device__ __forceinline__ void b16k_dma_masked(ki32x4 rs, int vo, int so, unsigned m0a, bool on) {
+  unsigned long long sv;
+  unsigned keep;
+  const unsigned m32 = (unsigned)__builtin_amdgcn_readfirstlane(-(int)on);      // (wave-uniform by construction)
+  const unsigned long long mask = ((unsigned long long)m32 << 32) | m32;
+  asm volatile("s_mov_b32 %1, m0\n\ts_mov_b64 %0, exec\n\ts_mov_b64 exec, %6\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "buffer_load_dwordx4 %3, %4, %5 offen lds\n\ts_mov_b64 exec, %0\n\ts_mov_b32 m0, %1"
+               : "=&s"(sv), "=&s"(keep) : "s"(m0a), "v"(vo), "s"(rs), "s"(so), "s"(mask));
+}
 __device__ __forceinline__ unsigned b16k_lds_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
@@ -63,14 +73,14 @@ constexpr int b16k_row_slots(int px) {
   return rs;
 }
 
-template <int KS, int COUT> struct B16KGeom {
+template <int KS, int COUT, int NW> struct B16KGeom {
   static constexpr int HH = 8 + KS - 1;
   static constexpr int T = KS * KS;
   static constexpr int PIXB = 64;
   static constexpr int ROWB = b16k_row_slots(HH) * 16;
   static constexpr int NROW = 16;                    // physical halo rows per image: a circular buffer (see below)
   static constexpr int IMGB = (NROW + 1) * ROWB;     // + row 16, a copy of row 0 (a row pair may start at row 15)
-  static constexpr int HALO_B = 4 * IMGB;
+  static constexpr int HALO_B = NW * IMGB;           // one image per wave
   static constexpr int WTAP_B = 64 * COUT;           // 32 channels x C_out bf16
   static constexpr int RING = 3;
   static constexpr int LDS_B = HALO_B + RING * WTAP_B;
@@ -78,12 +88,6 @@ template <int KS, int COUT> struct B16KGeom {
 
 enum { B16K_PLAIN = 0, B16K_FUSED = 1, B16K_PAIR = 2 };
 
-#ifdef TSR_STAMP
-__device__ unsigned long long* g_b16k_stamps;
-#define STAMP(i_) if (threadIdx.x == 0 && a.slab) ((unsigned long long*)a.slab)[(size_t)blockIdx.x * 8 + (i_)] = __builtin_amdgcn_s_memtime()
-#else
-#define STAMP(i_)
-#endif
 
 // compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (the scheduling hints need constant operands)
 template <int I, int N, class F> __device__ __forceinline__ void b16k_static_for(F&& f) {
@@ -298,13 +302,16 @@ template <> struct B16KJobs<3> {       // HH = 10: next rows 0..5 -> never-used 
   }
 };
 
-template <int KS, int COUT, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
+// NW = waves = images per workgroup (4: two workgroups per CU; 8: one 512-thread workgroup per CU whose weight slab serves 512
+// pixels -- see B16K_LAUNCH).
+template <int KS, int COUT, int MODE, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_b16k_kernel(const ConvArgs a) {
   static_assert(MODE == B16K_PLAIN || (COUT == 128 && (MODE == B16K_FUSED || KS == 5)), "fused / pair: 128 channels");
-  typedef B16KGeom<KS, COUT> G;
+  typedef B16KGeom<KS, COUT, NW> G;
   constexpr int P = KS / 2, HH = G::HH, T = G::T, MT = COUT / 16, NT = 4;
   constexpr int PIXB = G::PIXB, ROWB = G::ROWB, IMGB = G::IMGB, HALO_B = G::HALO_B, WTAP_B = G::WTAP_B;
-  constexpr int WV = WTAP_B / 4096;                          // LDS-DMA instructions per wave and slab (1 KB each)
+  constexpr int WCH = WTAP_B / 1024;                         // 1-KB LDS-DMA requests per slab: wave w issues w, w + NW, ...
+  constexpr int WV = (WCH + NW - 1) / NW;
   __shared__ __attribute__((aligned(16))) char lds[G::LDS_B];
   char* halo = lds;
   char* wbuf = lds + HALO_B;
@@ -313,7 +320,6 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
   const int lane = tid & 63;
   const int wm = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, g = lane >> 4;
-  STAMP(0);
 
   int bid;
   {
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
   const int ig = bid / tpi;
   const int trem = bid - ig * tpi;
   const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
-  const int y0 = ty * 8, x0 = tx * 8, b0 = ig * 4;
+  const int y0 = ty * 8, x0 = tx * 8, b0 = ig * NW;
   const int HW = a.H * a.W;
   const int in_blocks = a.in_ctot >> 4;
 
@@ -367,6 +373,7 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
     b16k_dma_row(rs, vo_lane, cblk * HW * 64 + gy * a.W * 32, dst, dst2, (1ull << (4 * HH)) - 1);
   };
   const int wvo = tid * 16;
+  const int lane16 = lane * 16;
 
   const int laneA = (g * COUT + m) * 16;                                          // + mt * 256 (+ slot)
   const int laneB = wm * IMGB + (m >> 3) * ROWB + (m & 7) * PIXB + g * 16;         // + first physical row * ROWB + kw * PIXB
@@ -391,7 +398,10 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
     const ki32x4 rs_ = {blo_, bhi_ & 0xffff, 0x7fffffff & (real_ | w2_), 0x00020000};    \
     const int so_ = (((sidx) - S) * 8192) ^ (((((sidx) - S) * 8192) ^ ((sidx) * WTAP_B)) & real_); \
     const unsigned dst_ = wbuf_a + (slot_) * WTAP_B + wm * 1024;                         \
-    _Pragma("unroll") for (int v = 0; v < WV; ++v) b16k_dma(rs_, wvo, so_ + v * 4096, dst_ + v * 4096); \
+    _Pragma("unroll") for (int v = 0; v < WV; ++v) {                                     \
+      if ((v + 1) * NW <= WCH) b16k_dma(rs_, wvo, so_ + v * NW * 1024, dst_ + v * NW * 1024); \
+      else b16k_dma_masked(rs_, wvo, so_ + v * NW * 1024, dst_ + v * NW * 1024, wm + v * NW < WCH); \
+    }                                                                                    \
   }
   // pair form, a slab of an OUTER tap: only the 5x5 conv's channels (co >= 64: the second KB of every 2-KB k group) are ever
   // read -- one request per wave (k group = wave) instead of two
@@ -399,7 +409,9 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
   {                                                                                      \
     const int real_ = -(int)((sidx) < S);                                                \
     const ki32x4 rs_ = {(int)w_base, (int)(w_base >> 32) & 0xffff, 0x7fffffff & real_, 0x00020000}; \
-    b16k_dma(rs_, wvo, (sidx) * WTAP_B + wm * 1024 + 1024, wbuf_a + (slot_) * WTAP_B + wm * 2048 + 1024); \
+    const int g_ = wm & 3;                                  /* k group of this wave's request (waves 4..7: none) */ \
+    b16k_dma_masked(rs_, lane16, (sidx) * WTAP_B + g_ * 2048 + 1024, wbuf_a + (slot_) * WTAP_B + g_ * 2048 + 1024, \
+                    wm < 4);                                                             \
   }
   // vmcnt wait that leaves the n_ youngest vector-memory operations in flight (they count in issue order)
 #define VM_WAIT(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14))
@@ -433,7 +445,6 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
   for (int mt = b16k_tap_rows<KS, MODE, MT>(0); mt < MT; ++mt) LOAD_A(mt, 0);
   LOAD_B(0, 0, 0, 0);
   LOAD_B(1, 0, 0, 0);
-  STAMP(1);
 
   int s = 0, slot = 0;
   for (int c = 0; c < nblk; ++c) {
@@ -489,7 +500,6 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
   }
   // (the trailing requests fetch nothing but still write LDS: none may be in flight when the workgroup's LDS is released)
   VM_WAIT(0);
-  STAMP(2);
 #undef DMA_W
 #undef DMA_W_HI
 #undef VM_WAIT
@@ -501,10 +511,6 @@ __global__ __launch_bounds__(256, 2) void conv_b16k_kernel(const ConvArgs a) {
 
   // (fused form: the 1x1 weight's halves sit in the ring slots of the two requests past the stream's end, slabs S and S+1)
   b16k_epilogue<MT, MODE>(a, acc, b0 + wm, y0, x0, m, g, HW, wbuf + slot * WTAP_B, wbuf + (slot == 2 ? 0 : slot + 1) * WTAP_B);
-#ifdef TSR_STAMP
-  __builtin_amdgcn_s_waitcnt(0);
-  STAMP(3);
-#endif
 }
 
 // ---- weight packs ------------------------------------------------------------------------------------------------------
@@ -537,10 +543,17 @@ __global__ void pack_w2_b16k_kernel(const float* __restrict__ w2, __bf16* __rest
 
 extern "C" long long tsr_conv_weight_b16k_elems(int cout, int cin, int ks) { return (long long)cout * cin * ks * ks; }
 
-#ifdef TSR_STAMP
-static void* g_stamp_buf = nullptr;
-extern "C" int tsr_debug_set_stamps(void* dev_buf) { g_stamp_buf = dev_buf; return 0; }
+// NW = 4 is what ships.  NW = 8 (one 512-thread workgroup per CU: half the L2 -> LDS weight traffic, the epilogue no longer under
+// another workgroup's loop) passes the same tests and measures the SAME launch times at B = 4096 (5x5 fused 3.63 vs 3.61 ms,
+// 3x3 fused 1.77 vs 1.74, pair 1.63 vs 1.62, same box) -- as did halving the barriers: at ~1.5 PFLOP/s on real activations the
+// 5x5 launch sits where the chip holds ~1.9 GHz under bf16 MFMA load (MI355X_MICROARCH.md, DVFS give-back: 1.25 PFLOP/s for a
+// bare GEMM loop on random data), and a saved stall comes back as a lower clock.  -DTSR_B16K_NW=8 builds that form.
+#ifndef TSR_B16K_NW
+#define TSR_B16K_NW 4
 #endif
+#define B16K_LAUNCH(KS_, COUT_, MODE_)                                                                         \
+  hipLaunchKernelGGL((conv_b16k_kernel<KS_, COUT_, MODE_, TSR_B16K_NW>),                                       \
+                     dim3(((a.B + TSR_B16K_NW - 1) / TSR_B16K_NW) * a.tiles_x * a.tiles_y), dim3(TSR_B16K_NW * 64), 0, st, a);
 static bool b16k_shape_ok(int cout, int cin, int ks) {
   return (cout == 64 || cout == 128) && cin > 0 && (cin & 31) == 0 && (ks == 3 || ks == 5);
 }
@@ -578,9 +591,6 @@ static int b16k_fill(ConvArgs& a, const void* in, int in_ctot, int in_coff, int 
   a.B = B; a.H = H; a.W = W;
   a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8;
   (void)cout;
-#ifdef TSR_STAMP
-  a.slab = (float*)g_stamp_buf;
-#endif
   return TSR_OK;
 }
 
@@ -592,12 +602,11 @@ extern "C" int tsr_conv2d_fwd_b16k(const void* in, int in_ctot, int in_coff, int
   const int rc = b16k_fill(a, in, in_ctot, in_coff, cin, w_packed, cout, scale, shift, res, res_ctot, res_coff, out, out_ctot,
                            out_coff, cout, relu, B, H, W);
   if (rc != TSR_OK) return rc;
-  const dim3 grid(((B + 3) / 4) * a.tiles_x * a.tiles_y), blk(256);
   hipStream_t st = (hipStream_t)stream;
-  if (cout == 64 && ks == 3) hipLaunchKernelGGL((conv_b16k_kernel<3, 64, B16K_PLAIN>), grid, blk, 0, st, a);
-  else if (cout == 64) hipLaunchKernelGGL((conv_b16k_kernel<5, 64, B16K_PLAIN>), grid, blk, 0, st, a);
-  else if (ks == 3) hipLaunchKernelGGL((conv_b16k_kernel<3, 128, B16K_PLAIN>), grid, blk, 0, st, a);
-  else hipLaunchKernelGGL((conv_b16k_kernel<5, 128, B16K_PLAIN>), grid, blk, 0, st, a);
+  if (cout == 64 && ks == 3) B16K_LAUNCH(3, 64, B16K_PLAIN)
+  else if (cout == 64) B16K_LAUNCH(5, 64, B16K_PLAIN)
+  else if (ks == 3) B16K_LAUNCH(3, 128, B16K_PLAIN)
+  else B16K_LAUNCH(5, 128, B16K_PLAIN)
   return tsr_check_launch();
 }
 
@@ -613,10 +622,9 @@ extern "C" int tsr_conv2d_fwd_b16k_fuse1x1(const void* in, int in_ctot, int in_c
                            out_coff, 64, relu, B, H, W);
   if (rc != TSR_OK) return rc;
   a.w2 = w2_packed; a.w2_inv_scale = 1.f; a.shift2 = shift2; a.relu2 = relu2;
-  const dim3 grid(((B + 3) / 4) * a.tiles_x * a.tiles_y), blk(256);
   hipStream_t st = (hipStream_t)stream;
-  if (ks == 3) hipLaunchKernelGGL((conv_b16k_kernel<3, 128, B16K_FUSED>), grid, blk, 0, st, a);
-  else hipLaunchKernelGGL((conv_b16k_kernel<5, 128, B16K_FUSED>), grid, blk, 0, st, a);
+  if (ks == 3) B16K_LAUNCH(3, 128, B16K_FUSED)
+  else B16K_LAUNCH(5, 128, B16K_FUSED)
   return tsr_check_launch();
 }
 
@@ -630,7 +638,7 @@ extern "C" int tsr_conv2d_fwd_b16k_pair(const void* in, int in_ctot, int in_coff
   const int rc = b16k_fill(a, in, in_ctot, in_coff, cin, w_packed, 128, scale, shift, nullptr, 0, 0, out, out_ctot, out_coff,
                            128, relu, B, H, W);
   if (rc != TSR_OK) return rc;
-  const dim3 grid(((B + 3) / 4) * a.tiles_x * a.tiles_y), blk(256);
-  hipLaunchKernelGGL((conv_b16k_kernel<5, 128, B16K_PAIR>), grid, blk, 0, (hipStream_t)stream, a);
+  hipStream_t st = (hipStream_t)stream;
+  B16K_LAUNCH(5, 128, B16K_PAIR)
   return tsr_check_launch();
 }

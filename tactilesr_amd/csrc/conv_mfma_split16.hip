@@ -91,11 +91,10 @@ constexpr int row_slots(int hh, int pixs, int rmod) {
 template <int KS, int COUT, int NS, bool EXT, bool F16, int WN, bool DBH = false, bool IO16 = false, bool FUSE2 = false,
           bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArgs a) {
-  static_assert(!PAIR || (KS == 5 && COUT == 128 && NS == 1 && IO16 && WN == 1 && !EXT && !FUSE2 && !DBH),
-                "pair form: bf16 storage, 5x5 geometry, 4 images x 128 channels");
+  static_assert(!PAIR, "the bf16-storage stage-1 pair runs csrc/conv_b16k.hip");
   static_assert(!IO16 || (NS == 1 && !F16), "bf16 activation storage: plain bf16 operands");
-  static_assert(!FUSE2 || (!EXT && COUT == 128 && ((NS == 2 && F16 && WN == 2 && !IO16) || (NS == 1 && IO16 && WN == 1))),
-                "fused 1x1: 128 channels, inference; fp16x3 (2 images / workgroup) or bf16 storage (4 images)");
+  static_assert(!FUSE2 || (!EXT && COUT == 128 && NS == 2 && F16 && WN == 2 && !IO16),
+                "fused 1x1: 128 channels, inference, fp16x3 (2 images / workgroup); bf16 storage: csrc/conv_b16k.hip");
   typedef typename Plane<F16>::T PT;
   typedef typename Plane<F16>::V8 PV8;
   typedef typename Plane<F16>::V4 PV4;
@@ -124,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
   static_assert(!DBH || (NSTEP >= 3 && (T & 1)), "double-buffered halo needs >= 3 steps per block and an odd tap count");
   constexpr int NHB = DBH ? 2 : 1;
   constexpr int MAIN_LDS = NHB * HALO_B + 3 * WSLAB_B;
-  constexpr int FUSE_LDS = !FUSE2 ? 0 : (IO16 ? Fuse1x1GeomB16::BYTES : Fuse1x1Geom::BYTES + 64);
+  constexpr int FUSE_LDS = !FUSE2 ? 0 : Fuse1x1Geom::BYTES + 64;
   __shared__ __attribute__((aligned(16))) char lds[MAIN_LDS > FUSE_LDS ? MAIN_LDS : FUSE_LDS];
   char* halo = lds;
   char* wbuf = lds + NHB * HALO_B;  // 3-slot ring: slab s lives in slot s % 3
@@ -458,8 +457,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_split16_kernel(const ConvArg
 #undef DMA_WAIT_N
 #undef LOAD_FRAGS
 
-  if constexpr (FUSE2 && IO16) conv_fuse1x1_b16_epilogue(a, acc, lds, b0, y0, x0, wm, h, li, HW);
-  else if constexpr (FUSE2) conv_fuse1x1_epilogue(a, acc, lds, b0, y0, x0, wm, wn, h, li, HW, accmul);
+  if constexpr (FUSE2) conv_fuse1x1_epilogue(a, acc, lds, b0, y0, x0, wm, wn, h, li, HW, accmul);
   else conv_epilogue<COUT, EXT, WN, IO16>(a, acc, bid, b0, y0, x0, wm, wn, h, li, HW, accmul);
 }
 
@@ -921,56 +919,6 @@ extern "C" int tsr_conv2d_fwd_b16(const void* in, int in_ctot, int in_coff, int 
     if (ks == 5) return launch_b16<5, 128>(a, st);
   }
   return TSR_ERR_ARG;
-}
-
-// The fused stage-2 form for the bf16-storage path (one plane, one product; 4 images per workgroup)
-extern "C" int tsr_conv2d_fwd_b16_fuse1x1(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed, int ks,
-                                          const float* scale, const float* shift, int relu,
-                                          const void* w2_packed, const float* shift2,
-                                          const void* res, int res_ctot, int res_coff,
-                                          void* out, int out_ctot, int out_coff, int relu2,
-                                          int B, int H, int W, void* stream) {
-  if (!in || !w_packed || !w2_packed || !out || B <= 0 || H <= 0 || W <= 0 || (ks != 3 && ks != 5)) return TSR_ERR_ARG;
-  if ((cin & 15) || (in_ctot & 15) || (in_coff & 15) || (out_ctot & 15) || (out_coff & 15) || cin <= 0 ||
-      in_coff + cin > in_ctot || out_coff + 64 > out_ctot)
-    return TSR_ERR_ARG;
-  if (res && ((res_ctot & 15) || (res_coff & 15) || res_coff + 64 > res_ctot)) return TSR_ERR_ARG;
-  ConvArgs a = {};
-  a.in = (const float*)in; a.in_ctot = in_ctot; a.in_coff = in_coff; a.cin = cin;
-  a.wp = (const float*)w_packed; a.scale = scale; a.shift = shift; a.relu = relu;
-  a.res = (const float*)res; a.res_ctot = res_ctot; a.res_coff = res_coff;
-  a.out = (float*)out; a.out_ctot = out_ctot; a.out_coff = out_coff;
-  a.B = B; a.H = H; a.W = W;
-  a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8;
-  a.w2 = w2_packed; a.w2_inv_scale = 1.f; a.shift2 = shift2; a.relu2 = relu2;
-  const int grid4 = ((B + 3) / 4) * a.tiles_x * a.tiles_y;
-  hipStream_t st = (hipStream_t)stream;
-  if (ks == 5)
-    hipLaunchKernelGGL((conv_mfma_split16_kernel<5, 128, 1, false, false, 1, false, true, true>), dim3(grid4), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((conv_mfma_split16_kernel<3, 128, 1, false, false, 1, false, true, true>), dim3(grid4), dim3(256), 0, st, a);
-  return tsr_check_launch();
-}
-
-// Stage-1 pair of an MSRB on bf16 tensors: w_packed = tsr_pack_conv_weight_bf16s(cat([zero-pad(w3 -> 5x5), w5]), cout 128,
-// ks 5, nsplit 1); scale / shift = the two convs' folded BatchNorm vectors concatenated; out = 128 channels in cat order.
-extern "C" int tsr_conv2d_fwd_b16_pair(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed,
-                                       const float* scale, const float* shift, void* out, int out_ctot, int out_coff,
-                                       int relu, int B, int H, int W, void* stream) {
-  if (!in || !w_packed || !out || B <= 0 || H <= 0 || W <= 0) return TSR_ERR_ARG;
-  if ((cin & 15) || (in_ctot & 15) || (in_coff & 15) || (out_ctot & 15) || (out_coff & 15) || cin <= 0 ||
-      in_coff + cin > in_ctot || out_coff + 128 > out_ctot)
-    return TSR_ERR_ARG;
-  ConvArgs a = {};
-  a.in = (const float*)in; a.in_ctot = in_ctot; a.in_coff = in_coff; a.cin = cin;
-  a.wp = (const float*)w_packed; a.scale = scale; a.shift = shift;
-  a.out = (float*)out; a.out_ctot = out_ctot; a.out_coff = out_coff; a.relu = relu;
-  a.B = B; a.H = H; a.W = W;
-  a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8;
-  const int grid4 = ((B + 3) / 4) * a.tiles_x * a.tiles_y;
-  hipLaunchKernelGGL((conv_mfma_split16_kernel<5, 128, 1, false, false, 1, false, true, false, true>), dim3(grid4), dim3(256), 0,
-                     (hipStream_t)stream, a);
-  return tsr_check_launch();
 }
 
 // fp16 two-plane variant ("fp16x3": x*sx = h1+h2, w*sw = g1+g2, products h1g1 + h1g2 + h2g1, fp32 accumulate).

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Diagnostic (variant build -DTSR_STAMP only): per-workgroup s_memtime stamps of conv_b16k_kernel -- kernel start, end of
-prologue, end of main loop, end of epilogue -- for the fused 3x3 / 5x5 and the pair launch at B = 4096:
+"""Single-launch timings of conv_b16k_kernel (fused 3x3 / 5x5, pair, plain 3x3 128) at B = 4096, random data.  Against a
+library that exports tsr_debug_set_stamps -- the diagnostic -DTSR_STAMP build, which lives in the history of
+csrc/conv_b16k.hip at commit 9707380 (per-workgroup s_memtime stamps at kernel start, end of prologue, end of main loop,
+end of epilogue; it is not in the shipping source) -- it also prints the per-workgroup median of the three phases:
 
-    python tools/build_variant.py stamp -DTSR_STAMP
-    TSR_ALLOW_VARIANT=1 TSR_LIB_OVERRIDE=tactilesr_amd/lib/exp/stamp/libtactilesr_hip.so python tools/b16k_stamps.py
+    git worktree add /tmp/wt 9707380 && (cd /tmp/wt && python tools/build_variant.py stamp -DTSR_STAMP)
+    TSR_ALLOW_VARIANT=1 TSR_LIB_OVERRIDE=/tmp/wt/tactilesr_amd/lib/exp/stamp/libtactilesr_hip.so python tools/b16k_stamps.py
 """
 import ctypes
 import os
