@@ -94,6 +94,8 @@ for mode in ("eval", "train", "tpsf", "bf16", "trainbf16"):
 
 sq = {}
 for mode in ("eval", "train", "bf16"):
+    if only is not None and mode not in only:
+        continue
     for k, d in collect([f"{mode}_sq"]).items():
         e = {c: per_launch(v)[0] for c, v in d.items()}
         wc = e.get("SQ_WAVE_CYCLES")
@@ -105,12 +107,15 @@ for mode in ("eval", "train", "bf16"):
             e["lds_bank_conflict_share_of_lds_cycles"] = (e.get("SQ_LDS_BANK_CONFLICT", 0) / e["SQ_LDS_IDX_ACTIVE"]
                                                          if e.get("SQ_LDS_IDX_ACTIVE") else None)
         sq[f"{mode}: {k}"] = e
-if sq and only is None:
-    json.dump(sq, open(os.path.join(dst, f"{tag}_sq_summary.json"), "w"), indent=1, sort_keys=True)
+if sq:      # a group re-collected on newer sources gets files of its own (rNN_<group>_sq_summary.json)
+    name = f"{tag}_sq_summary.json" if only is None else f"{tag}_{'_'.join(sorted(only))}_sq_summary.json"
+    json.dump(sq, open(os.path.join(dst, name), "w"), indent=1, sort_keys=True)
 print("wrote", sorted(f for f in os.listdir(dst) if f.startswith(tag)))
 
 clk = {}
 for mode in ("eval", "train", "bf16"):
+    if only is not None and mode not in only:
+        continue
     per = collections.defaultdict(list)
     for f in files(f"{mode}_clk", "_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
@@ -122,6 +127,7 @@ for mode in ("eval", "train", "bf16"):
     for k, v in per.items():
         clk[f"{mode}: {k}"] = {"effective_clock_GHz": round(sum(x for x, _ in v) / len(v), 3),
                                "avg_launch_ms": round(sum(d for _, d in v) / len(v) / 1e6, 3), "launches": len(v)}
-if clk and only is None:
-    json.dump(clk, open(os.path.join(dst, f"{tag}_clock_summary.json"), "w"), indent=1, sort_keys=True)
-    print("wrote", f"{tag}_clock_summary.json")
+if clk:
+    name = f"{tag}_clock_summary.json" if only is None else f"{tag}_{'_'.join(sorted(only))}_clock_summary.json"
+    json.dump(clk, open(os.path.join(dst, name), "w"), indent=1, sort_keys=True)
+    print("wrote", name)
