@@ -217,6 +217,8 @@ def run_legs(args, dev):
         no_cpu_baseline=True)
     leg("tpsf_b8192", run_tpsf, mode="tpsf", steps=20, warmup=3)
     leg("seqs_eval_b512", run_infer, seqs=True, steps=3, warmup=1)
+    leg("seqs_eval_bf16_b512", run_infer, seqs=True, impl="bf16", impl_given=True, steps=3, warmup=1,    # configs[4] is a bf16 configuration
+        no_cpu_baseline=True)
     leg("seqs_train_b256", run_train, mode="train", seqs=True, steps=3, warmup=1)
     try:
         legs["eval_b8_latency"] = small_batch_latency(dev)
