@@ -136,7 +136,8 @@ int tsr_conv2d_fwd_b16(const void* in, int in_ctot, int in_coff, int cin, const 
  * 1x1 `confusion` applied to the tile as it sits in the accumulator registers (see tsr_conv2d_fwd_f16s_fuse1x1; res / out
  * are 64-channel bf16 tensors).  tsr_conv2d_fwd_b16k_pair: the stage-1 pair of an MSRB, conv_3_1 || conv_5_1 (each conv +
  * BN + ReLU, model/tactileSR_model.py:167-175) and the first torch.cat (:200) as ONE launch on one staged halo: w_packed =
- * the pack of W = cat([3x3 weight zero-padded to 5x5, 5x5 weight]) along C_out (cout = 128, ks = 5), scale / shift = the two
+ * tsr_pack_conv_weight_b16k_pair(W = cat([3x3 weight zero-padded to 5x5, 5x5 weight]) along C_out, [128][cin][5][5];
+ * tsr_conv_weight_b16k_pair_elems(cin) elements: one slab per barrier step, two outer taps per step), scale / shift = the two
  * convs' folded BatchNorm vectors concatenated (128), out = 128 channels in torch.cat order; the 3x3 half's MFMAs, fragment
  * reads and weight bytes on the 16 outer taps are skipped.  The weight layouts:
  * w_packed from tsr_pack_conv_weight_b16k ([C_in/32][tap][4][C_out][8] bf16; tsr_conv_weight_b16k_elems elements),
@@ -145,6 +146,8 @@ int tsr_conv2d_fwd_b16(const void* in, int in_ctot, int in_coff, int cin, const 
 long long tsr_conv_weight_b16k_elems(int cout, int cin, int ks);
 int tsr_pack_conv_weight_b16k(const float* w_oihw, void* w_packed, int cout, int cin, int ks, void* stream);
 int tsr_pack_w2_b16k(const float* w2_64x128, void* w_packed, void* stream);
+long long tsr_conv_weight_b16k_pair_elems(int cin);
+int tsr_pack_conv_weight_b16k_pair(const float* w128_oihw5, void* w_packed, int cin, void* stream);
 int tsr_conv2d_fwd_b16k(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed, int cout, int ks,
                         const float* scale, const float* shift, const void* res, int res_ctot, int res_coff,
                         void* out, int out_ctot, int out_coff, int relu, int B, int H, int W, void* stream);

@@ -304,6 +304,28 @@ template <> struct B16KJobs<3> {       // HH = 10: next rows 0..5 -> never-used 
 
 // NW = waves = images per workgroup (4: two workgroups per CU; 8: one 512-thread workgroup per CU whose weight slab serves 512
 // pixels -- see B16K_LAUNCH).
+// Barrier steps of a channel block.  Plain / fused: one tap per step.  Pair form: the 16 outer taps carry half the MFMAs (the 3x3
+// conv has no weight there), so two CONSECUTIVE outer taps share a step -- 8 double steps + the 9 inner taps = 17 steps of 32
+// MFMAs per wave instead of 25 -- and a weight slab: [k group][64 channels of the 5x5 conv at the second tap | at the first
+// tap][8] (tsr_pack_conv_weight_b16k_pair), which the A-fragment reads address exactly like a full slab.
+template <int KS, int MODE> struct B16KSteps {
+  static constexpr int T = KS * KS;
+  struct Tab { int n = 0; int first[T] = {}; int ntap[T] = {}; int step_of[T] = {}; };
+  static constexpr bool outer(int t) { return MODE == B16K_PAIR && b16k_tap_rows<KS, MODE, 8>(t) != 0; }
+  static constexpr Tab make() {
+    Tab tb;
+    int t = 0;
+    while (t < T) {
+      const int n = (outer(t) && t + 1 < T && outer(t + 1)) ? 2 : 1;
+      tb.first[tb.n] = t; tb.ntap[tb.n] = n;
+      for (int i = 0; i < n; ++i) tb.step_of[t + i] = tb.n;
+      ++tb.n; t += n;
+    }
+    return tb;
+  }
+  static constexpr Tab tab = make();
+};
+
 template <int KS, int COUT, int MODE, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_b16k_kernel(const ConvArgs a) {
   static_assert(MODE == B16K_PLAIN || (COUT == 128 && (MODE == B16K_FUSED || KS == 5)), "fused / pair: 128 channels");
@@ -373,7 +395,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_b16k_kernel(con
     b16k_dma_row(rs, vo_lane, cblk * HW * 64 + gy * a.W * 32, dst, dst2, (1ull << (4 * HH)) - 1);
   };
   const int wvo = tid * 16;
-  const int lane16 = lane * 16;
 
   const int laneA = (g * COUT + m) * 16;                                          // + mt * 256 (+ slot)
   const int laneB = wm * IMGB + (m >> 3) * ROWB + (m & 7) * PIXB + g * 16;         // + first physical row * ROWB + kw * PIXB
@@ -384,8 +405,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_b16k_kernel(con
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  typedef B16KSteps<KS, MODE> ST;
+  constexpr int NSTEP = ST::tab.n;                           // barrier steps (= weight slabs) per channel block
   const int nblk = a.cin >> 5;
-  const int S = nblk * T;
+  const int S = nblk * NSTEP;
 
   // (fused form: the two requests past the end of the conv's stream -- their slots are dead -- fetch the two 8-KB halves of the
   //  packed 1x1 weight instead of nothing: the epilogue reads its W2 fragments from LDS)
@@ -402,16 +425,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_b16k_kernel(con
       if ((v + 1) * NW <= WCH) b16k_dma(rs_, wvo, so_ + v * NW * 1024, dst_ + v * NW * 1024); \
       else b16k_dma_masked(rs_, wvo, so_ + v * NW * 1024, dst_ + v * NW * 1024, wm + v * NW < WCH); \
     }                                                                                    \
-  }
-  // pair form, a slab of an OUTER tap: only the 5x5 conv's channels (co >= 64: the second KB of every 2-KB k group) are ever
-  // read -- one request per wave (k group = wave) instead of two
-#define DMA_W_HI(sidx, slot_)                                                             \
-  {                                                                                      \
-    const int real_ = -(int)((sidx) < S);                                                \
-    const ki32x4 rs_ = {(int)w_base, (int)(w_base >> 32) & 0xffff, 0x7fffffff & real_, 0x00020000}; \
-    const int g_ = wm & 3;                                  /* k group of this wave's request (waves 4..7: none) */ \
-    b16k_dma_masked(rs_, lane16, (sidx) * WTAP_B + g_ * 2048 + 1024, wbuf_a + (slot_) * WTAP_B + g_ * 2048 + 1024, \
-                    wm < 4);                                                             \
   }
   // vmcnt wait that leaves the n_ youngest vector-memory operations in flight (they count in issue order)
 #define VM_WAIT(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14))
@@ -430,7 +443,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_b16k_kernel(con
   // B fragment of row pair nt_ at tap (kh_, kw_) of the block whose row 0 is physical row rb_
 #define LOAD_B(nt_, rb_, kh_, kw_)                                                        \
   Bf[nt_] = *(const kb16x8*)(halo + laneB + (((rb_) + 2 * (nt_) + (kh_)) & 15) * ROWB + (kw_) * PIXB)
-#define MFMA(mt_, nt_) acc[mt_][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt_], Bf[nt_], acc[mt_][nt_], 0, 0, 0)
+#define MFMA(am_, mt_, nt_) acc[am_][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt_], Bf[nt_], acc[am_][nt_], 0, 0, 0)
 #define SGB(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0)
 
   // ---- prologue: rows 0..7 of block 0, W(0), W(1) landed; W(2) in flight
@@ -442,7 +455,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_b16k_kernel(con
 
   kb16x8 A[MT], Bf[NT];
 #pragma unroll
-  for (int mt = b16k_tap_rows<KS, MODE, MT>(0); mt < MT; ++mt) LOAD_A(mt, 0);
+  for (int mt = 0; mt < MT; ++mt) LOAD_A(mt, 0);
   LOAD_B(0, 0, 0, 0);
   LOAD_B(1, 0, 0, 0);
 
@@ -450,48 +463,59 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_b16k_kernel(con
   for (int c = 0; c < nblk; ++c) {
     const bool more = c + 1 < nblk;
     const int rb0 = (c * HH) & 15;
-    b16k_static_for<0, T>([&](auto tc) __attribute__((always_inline)) {
-      constexpr int t = decltype(tc)::value;
-      constexpr int kh = t / KS, kw = t - kh * KS;
-      constexpr int tn = t + 1 < T ? t + 1 : 0;
-      constexpr int nkh = tn / KS, nkw = tn - nkh * KS;
-      constexpr int m0 = b16k_tap_rows<KS, MODE, MT>(t), m1 = b16k_tap_rows<KS, MODE, MT>(tn);
-      constexpr int j0 = B16KJobs<KS>::job(t, 0), j1 = B16KJobs<KS>::job(t, 1);
-      constexpr int NJ = (j0 >= 0) + (j1 >= 0);
+    b16k_static_for<0, NSTEP>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int st = decltype(sc)::value;
+      constexpr int t0 = ST::tab.first[st], NTAP = ST::tab.ntap[st];
       const int slot1 = slot == 2 ? 0 : slot + 1;
+      const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
       const int rb = opaque(rb0), rbn = (rb + HH) & 15;
       // slab s+2 -> the slot of slab s-1: its fragments were read during step s-2 and consumed by step s-1's MFMAs, and every
       // wave has passed the barrier that ended step s-1
-      constexpr int t2 = (t + 2) % T;
-      constexpr bool hi2 = b16k_tap_rows<KS, MODE, MT>(t2) != 0;
-      const int slot2 = slot1 == 2 ? 0 : slot1 + 1;
-      if constexpr (hi2) { DMA_W_HI(s + 2, slot2); } else { DMA_W(s + 2, slot2); }
-      LOAD_B(2, rb, kh, kw);
-      LOAD_B(3, rb, kh, kw);
+      DMA_W(s + 2, slot2);
+      // one tap: C_out tiles [ML, MH) of the A fragments accumulate into rows AO + mt (pair form, second tap of a double step:
+      // the 5x5 conv's channels sit in A rows 0..3)
+      auto tap = [&](auto tc, auto mlc, auto mhc, auto aoc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value, ML = decltype(mlc)::value, MH = decltype(mhc)::value, AO = decltype(aoc)::value;
+        constexpr int kh = t / KS, kw = t - kh * KS;
+        constexpr int tn = t + 1 < T ? t + 1 : 0;
+        constexpr int nkh = tn / KS, nkw = tn - nkh * KS;
+        constexpr int j0 = B16KJobs<KS>::job(t, 0), j1 = B16KJobs<KS>::job(t, 1);
+        LOAD_B(2, rb, kh, kw);
+        LOAD_B(3, rb, kh, kw);
 #pragma unroll
-      for (int mt = m0; mt < MT; ++mt) { MFMA(mt, 0); MFMA(mt, 1); }
-      SGB(0x100, 2);
-      SGB(0x008, 2 * (MT - m0));
-      __builtin_amdgcn_sched_barrier(0);
-      // this step's requests, issued behind the first half's MFMAs (right after the barrier they would delay them)
-
-      if constexpr (j0 >= 0) dma_row(c + (j0 >> 4), j0 & 15, (j0 >> 4) == 0 || more);
-      if constexpr (j1 >= 0) dma_row(c + (j1 >> 4), j1 & 15, (j1 >> 4) == 0 || more);
-      LOAD_B(0, (t + 1 < T ? rb : rbn), nkh, nkw);
-      LOAD_B(1, (t + 1 < T ? rb : rbn), nkh, nkw);
+        for (int mt = ML; mt < MH; ++mt) { MFMA(AO + mt, mt, 0); MFMA(AO + mt, mt, 1); }
+        SGB(0x100, 2);
+        SGB(0x008, 2 * (MH - ML));
+        __builtin_amdgcn_sched_barrier(0);
+        // this tap's halo requests, issued behind the first half's MFMAs (right after the barrier they would delay them)
+        if constexpr (j0 >= 0) dma_row(c + (j0 >> 4), j0 & 15, (j0 >> 4) == 0 || more);
+        if constexpr (j1 >= 0) dma_row(c + (j1 >> 4), j1 & 15, (j1 >> 4) == 0 || more);
+        LOAD_B(0, (t + 1 < T ? rb : rbn), nkh, nkw);
+        LOAD_B(1, (t + 1 < T ? rb : rbn), nkh, nkw);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        if (mt >= m0) { MFMA(mt, 2); MFMA(mt, 3); }
-        if (mt >= m1) LOAD_A(mt, slot1);
+        for (int mt = ML; mt < MH; ++mt) {
+          MFMA(AO + mt, mt, 2);
+          MFMA(AO + mt, mt, 3);
+          LOAD_A(mt, slot1);              // the NEXT step's fragment of this row, refilled in place as the row retires
+        }
+        // order: B2 B3 | first half | requests | B0' B1' | second half with the A rows refilled as they retire
+        SGB(0x100, 2);
+#pragma unroll
+        for (int mt = ML; mt < MH; ++mt) { SGB(0x008, 2); SGB(0x100, 1); }
+      };
+      constexpr int NJ = (B16KJobs<KS>::job(t0, 0) >= 0) + (B16KJobs<KS>::job(t0, 1) >= 0) +
+                         (NTAP == 2 ? (B16KJobs<KS>::job(t0 + 1, 0) >= 0) + (B16KJobs<KS>::job(t0 + 1, 1) >= 0) : 0);
+      typedef std::integral_constant<int, 0> I0;
+      typedef std::integral_constant<int, MT / 2> IH;
+      typedef std::integral_constant<int, MT> IM;
+      if constexpr (NTAP == 2) {
+        tap(std::integral_constant<int, t0>(), IH(), IM(), I0());           // first outer tap: A rows 4..7 -> C_out tiles 4..7
+        __builtin_amdgcn_sched_barrier(0);
+        tap(std::integral_constant<int, t0 + 1>(), I0(), IH(), IH());       // second: A rows 0..3 -> C_out tiles 4..7
+      } else {
+        tap(std::integral_constant<int, t0>(), I0(), IM(), I0());
       }
-      // order: B2 B3 | first half | requests | B0' B1' | second half with the A rows refilled as they retire
-      SGB(0x100, 2);
-      b16k_static_for<0, MT>([&](auto mc) __attribute__((always_inline)) {
-        constexpr int mt = decltype(mc)::value;
-        if constexpr (mt >= m0) SGB(0x008, 2);
-        if constexpr (mt >= m1) SGB(0x100, 1);
-      });
-      // everything requested BEFORE this step has landed (this step's own requests stay in flight): slab s+2, the halo
+      // everything requested BEFORE this step has landed (this step's own halo requests stay in flight): slab s+2, the halo
       // rows of step s-1
       STEP_END(NJ);
       ++s;
@@ -501,7 +525,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_b16k_kernel(con
   // (the trailing requests fetch nothing but still write LDS: none may be in flight when the workgroup's LDS is released)
   VM_WAIT(0);
 #undef DMA_W
-#undef DMA_W_HI
 #undef VM_WAIT
 #undef STEP_END
 #undef LOAD_A
@@ -541,7 +564,30 @@ __global__ void pack_w2_b16k_kernel(const float* __restrict__ w2, __bf16* __rest
   wp[i] = (__bf16)(0.5f * w2[co * 128 + ch]);       // halved (exact): the fused epilogue's ReLU is h + |h| on halves
 }
 
+// Stage-1 pair: W = cat([3x3 weight zero-padded to 5x5, 5x5 weight]) along C_out, [128][C_in][5][5] fp32 -> one 8-KB slab per
+// barrier step (B16KSteps): an inner tap's slab holds all 128 channels; a double step of two outer taps (u, u+1) holds the 5x5
+// conv's 64 channels twice -- rows 0..63 at tap u+1, rows 64..127 at tap u -- so that the kernel's A-fragment reads need no
+// second address map
+__global__ void pack_b16k_pair_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int cin) {
+  typedef B16KSteps<5, B16K_PAIR> ST;
+  constexpr int NSTEP = ST::tab.n;
+  const size_t total = (size_t)(cin >> 5) * NSTEP * 4096;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i & 7, row = (i >> 3) & 127, g = (i >> 10) & 3;
+    const int st = (i >> 12) % NSTEP, cb = (i >> 12) / NSTEP;
+    const int ci = cb * 32 + g * 8 + j;
+    const int t0 = ST::tab.first[st];
+    int co = row, tap = t0;
+    if (ST::tab.ntap[st] == 2) {
+      co = 64 + (row & 63);
+      tap = row < 64 ? t0 + 1 : t0;
+    }
+    wp[i] = (__bf16)w[((size_t)co * cin + ci) * 25 + tap];
+  }
+}
+
 extern "C" long long tsr_conv_weight_b16k_elems(int cout, int cin, int ks) { return (long long)cout * cin * ks * ks; }
+extern "C" long long tsr_conv_weight_b16k_pair_elems(int cin) { return (long long)(cin >> 5) * B16KSteps<5, B16K_PAIR>::tab.n * 4096; }
 
 // NW = 4 is what ships.  NW = 8 (one 512-thread workgroup per CU: half the L2 -> LDS weight traffic, the epilogue no longer under
 // another workgroup's loop) passes the same tests and measures the SAME launch times at B = 4096 (5x5 fused 3.63 vs 3.61 ms,
@@ -564,6 +610,15 @@ extern "C" int tsr_pack_conv_weight_b16k(const float* w_oihw, void* w_packed, in
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(pack_b16k_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
                      (__bf16*)w_packed, cout, cin, ks * ks);
+  return tsr_check_launch();
+}
+
+extern "C" int tsr_pack_conv_weight_b16k_pair(const float* w128_oihw5, void* w_packed, int cin, void* stream) {
+  if (!w128_oihw5 || !w_packed || !b16k_shape_ok(128, cin, 5)) return TSR_ERR_ARG;
+  const size_t total = (size_t)tsr_conv_weight_b16k_pair_elems(cin);
+  const int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(pack_b16k_pair_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, (hipStream_t)stream, w128_oihw5,
+                     (__bf16*)w_packed, cin);
   return tsr_check_launch();
 }
 
@@ -628,7 +683,7 @@ extern "C" int tsr_conv2d_fwd_b16k_fuse1x1(const void* in, int in_ctot, int in_c
   return tsr_check_launch();
 }
 
-// Stage-1 pair of an MSRB: w_packed = tsr_pack_conv_weight_b16k(cat([zero-pad(w3 -> 5x5), w5]), 128, cin, 5); scale / shift
+// Stage-1 pair of an MSRB: w_packed = tsr_pack_conv_weight_b16k_pair(cat([zero-pad(w3 -> 5x5), w5]), cin); scale / shift
 // = the two convs' folded BatchNorm vectors concatenated; out = 128 channels in torch.cat order.
 extern "C" int tsr_conv2d_fwd_b16k_pair(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed,
                                         const float* scale, const float* shift, void* out, int out_ctot, int out_coff,

@@ -280,9 +280,9 @@ class _PackedPairB16:
         w5 = seq5[0].weight.detach().float()
         self.cin = w3.shape[1]
         w = torch.cat([torch.nn.functional.pad(w3, (1, 1, 1, 1)), w5], dim=0).contiguous()
-        n = _lib.load().tsr_conv_weight_b16k_elems(128, self.cin, 5)
+        n = _lib.load().tsr_conv_weight_b16k_pair_elems(self.cin)
         self.w = torch.empty(n, dtype=torch.bfloat16, device=w.device)
-        call("tsr_pack_conv_weight_b16k", ptr(w), ptr(self.w), _I(128), _I(self.cin), _I(5), stream())
+        call("tsr_pack_conv_weight_b16k_pair", ptr(w), ptr(self.w), _I(self.cin), stream())
         s3, sh3 = _fold(seq3[0].bias, seq3[1], 64, w.device)
         s5, sh5 = _fold(seq5[0].bias, seq5[1], 64, w.device)
         self.scale = torch.cat([s3, s5]).contiguous()

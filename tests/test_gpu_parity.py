@@ -897,7 +897,9 @@ def test_conv2d_stage1_pair_kernel_bf16_storage(T, cin, B, H, W):
         torch.cuda.synchronize()
         return wp
     xin = cb16_bf16(x)
-    wpair = pack(torch.cat([F.pad(w3, (1, 1, 1, 1)), w5], 0), 128, 5)
+    wpair = torch.empty(load().tsr_conv_weight_b16k_pair_elems(cin), dtype=torch.bfloat16, device="cuda")
+    wcat = torch.cat([F.pad(w3, (1, 1, 1, 1)), w5], 0).cuda().contiguous()
+    call("tsr_pack_conv_weight_b16k_pair", ptr(wcat), ptr(wpair), I(cin), stream())
     sc, sh = scale.cuda(), shift.cuda()
     out = torch.empty(B * 128 * H * W, dtype=torch.bfloat16, device="cuda")
     call("tsr_conv2d_fwd_b16k_pair", ptr(xin), I(cin), I(0), I(cin), ptr(wpair), ptr(sc), ptr(sh), ptr(out), I(128), I(0), I(1),
