@@ -555,7 +555,8 @@ def test_conv2d_fwd_bf16_storage(T, ks, cin, cout, B, H, W):
 
 
 B16K_CASES = [(3, 64, 64, 5, 40, 40), (5, 64, 64, 3, 40, 40), (3, 128, 128, 6, 40, 40), (5, 128, 128, 5, 40, 40),
-              (3, 448, 64, 2, 40, 40), (3, 32, 64, 1, 13, 21), (5, 96, 128, 3, 17, 9), (3, 128, 128, 1, 100, 100)]
+              (3, 448, 64, 2, 40, 40), (3, 32, 64, 1, 13, 21), (5, 96, 128, 3, 17, 9), (3, 128, 128, 1, 100, 100),
+              (5, 64, 128, 9, 3, 5), (3, 160, 128, 7, 8, 8), (5, 512, 128, 1, 9, 33)]      # images smaller than a tile / than the kernel, 16 blocks
 
 
 @pytest.mark.parametrize("ks,cin,cout,B,H,W", B16K_CASES)
