@@ -146,6 +146,12 @@ int tsr_conv2d_fwd_b16(const void* in, int in_ctot, int in_coff, int cin, const 
 long long tsr_conv_weight_b16k_elems(int cout, int cin, int ks);
 int tsr_pack_conv_weight_b16k(const float* w_oihw, void* w_packed, int cout, int cin, int ks, void* stream);
 int tsr_pack_w2_b16k(const float* w2_64x128, void* w_packed, void* stream);
+/* Training with bf16 activation storage: tsr_conv2d_ex (nsplit = -1) runs the epi_mode-2 (dgrad) launches for which
+ * tsr_conv2d_ex_dgrad_b16k(nprime, cout, ks) returns 1 on the same kernel; their weight is then packed by
+ * tsr_pack_conv_weight_dgrad_b16k (arguments as tsr_pack_conv_weight_dgrad_bf16s with nprime = 128;
+ * tsr_conv_weight_b16k_elems(128, cout, ks) elements). */
+int tsr_conv2d_ex_dgrad_b16k(int nprime, int cout, int ks);
+int tsr_pack_conv_weight_dgrad_b16k(const float* w_oihw, void* w_packed, int cout, int cin, int ks, int ci0, void* stream);
 long long tsr_conv_weight_b16k_pair_elems(int cin);
 int tsr_pack_conv_weight_b16k_pair(const float* w128_oihw5, void* w_packed, int cin, void* stream);
 int tsr_conv2d_fwd_b16k(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed, int cout, int ks,

@@ -86,7 +86,7 @@ template <int KS, int COUT, int NW> struct B16KGeom {
   static constexpr int LDS_B = HALO_B + RING * WTAP_B;
 };
 
-enum { B16K_PLAIN = 0, B16K_FUSED = 1, B16K_PAIR = 2 };
+enum { B16K_PLAIN = 0, B16K_FUSED = 1, B16K_PAIR = 2, B16K_DGRAD = 3 };
 
 
 // compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (the scheduling hints need constant operands)
@@ -273,6 +273,90 @@ __device__ __forceinline__ void b16k_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
   }
 }
 
+// sum over the 16 lanes of a DPP row (the 16 pixels that hold the same channel quad); every lane ends up with the total
+__device__ __forceinline__ float b16k_row_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // lane ^ 1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // lane ^ 2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));   // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));   // row_ror:8
+  return v;
+}
+
+// Training with bf16 activation storage, the DGRAD launches of the 128-channel 3x3 / 5x5 layers (tsr_conv2d_ex, epi_mode 2; the
+// input is the stored gradient dz: nothing to transform while staging, so the inference loop applies unchanged):
+//   x = acc * scale + res, zeroed where the stored activation's BatchNorm + ReLU was off (mask * mask_scale + mask_shift <= 0),
+//   out = bf16(x); BatchNorm-backward partials sum(x), sum(x * xhat), xhat = mask * bn_a + bn_b, per (workgroup, image, channel)
+//   into the slab (same entry numbering as the 32x32x16 kernel's 4-image form: entry = logical workgroup * 4 + image).
+template <int MT>
+__device__ __forceinline__ void b16k_epilogue_dgrad(const ConvArgs& a, f32x4 (&acc)[MT][4], int bid, int wm, int b, int y0, int x0,
+                                                    int m, int g, int HW) {
+  constexpr int NT = 4;
+  const bool img_ok = b < a.B;
+  const int bsafe = img_ok ? b : 0;
+  bool ok[NT];
+  unsigned po[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int gy = y0 + 2 * nt + (m >> 3), gx = x0 + (m & 7);
+    ok[nt] = img_ok && gy < a.H && gx < a.W;
+    po[nt] = (ok[nt] ? (unsigned)(gy * a.W + gx) * 32u : 0u) + 8u * g;
+  }
+  const unsigned plane = (unsigned)HW * 32u;
+  const char* rb = a.res ? (const char*)a.res + ((size_t)bsafe * (a.res_ctot >> 4) + (a.res_coff >> 4)) * plane : nullptr;
+  const char* mb = (const char*)a.mask + ((size_t)bsafe * (a.mask_ctot >> 4) + (a.mask_coff >> 4)) * plane;
+  char* ob = (char*)a.out + ((size_t)bsafe * (a.out_ctot >> 4) + (a.out_coff >> 4)) * plane;
+  const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
+  const kb16x4 zero4h = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+  float* sl = a.slab + (((size_t)bid * 4 + wm) * 128 + 4 * g) * 2;
+  // the stored activation and the partial gradient of a C_out tile are requested one tile ahead of its stores
+  kb16x4 mv[2][NT], rv[2][NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    mv[0][nt] = *(const kb16x4*)(mb + po[nt]);
+    rv[0][nt] = rb ? *(const kb16x4*)(rb + po[nt]) : zero4h;
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int nq = mt * 16 + 4 * g;
+    const f32x4 sc = a.scale ? *(const f32x4*)(a.scale + nq) : one4;
+    const f32x4 msc = a.mask_scale ? *(const f32x4*)(a.mask_scale + nq) : one4;
+    const f32x4 msh = a.mask_scale ? *(const f32x4*)(a.mask_shift + nq) : zero4;
+    const f32x4 ba = a.bn_a ? *(const f32x4*)(a.bn_a + nq) : zero4;
+    const f32x4 bb = a.bn_a ? *(const f32x4*)(a.bn_b + nq) : zero4;
+    if (mt + 1 < MT) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        mv[(mt + 1) & 1][nt] = *(const kb16x4*)(mb + ((mt + 1) * plane + po[nt]));
+        rv[(mt + 1) & 1][nt] = rb ? *(const kb16x4*)(rb + ((mt + 1) * plane + po[nt])) : zero4h;
+      }
+    }
+    f32x4 s1 = zero4, s2 = zero4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const f32x4 mk = __builtin_convertvector(mv[mt & 1][nt], f32x4), r = __builtin_convertvector(rv[mt & 1][nt], f32x4);
+      f32x4 x;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v = acc[mt][nt][c] * sc[c] + r[c];
+        if (!(fmaf(mk[c], msc[c], msh[c]) > 0.f)) v = 0.f;
+        if (!ok[nt]) v = 0.f;            // (a dropped slot reads the image's first pixel: it must not feed the sums)
+        x[c] = v;
+        s1[c] += v;
+        s2[c] = fmaf(v, fmaf(ok[nt] ? mk[c] : 0.f, ba[c], bb[c]), s2[c]);
+      }
+      if (ok[nt]) *(kb16x4*)(ob + (mt * plane + po[nt])) = __builtin_convertvector(x, kb16x4);
+    }
+    if (a.bn_a) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { s1[c] = b16k_row_sum(s1[c]); s2[c] = b16k_row_sum(s2[c]); }
+      if (m == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { sl[(mt * 16 + c) * 2] = s1[c]; sl[(mt * 16 + c) * 2 + 1] = s2[c]; }
+      }
+    }
+  }
+}
+
 // Halo-row requests of step t of a block (two slots; -1 = none): row r of the CURRENT block = r, of the NEXT block = 16 + r.
 // Constraints (checked by hand against the circular-buffer rule in the kernel): a slot is requested only after the step
 // whose tap last read its old row (old row q < KS-1 dies with kernel row q, the others with the block), at least two
@@ -328,7 +412,7 @@ template <int KS, int MODE> struct B16KSteps {
 
 template <int KS, int COUT, int MODE, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_b16k_kernel(const ConvArgs a) {
-  static_assert(MODE == B16K_PLAIN || (COUT == 128 && (MODE == B16K_FUSED || KS == 5)), "fused / pair: 128 channels");
+  static_assert(MODE == B16K_PLAIN || (COUT == 128 && (MODE == B16K_FUSED || MODE == B16K_DGRAD || KS == 5)), "fused / pair / dgrad: 128 channels");
   typedef B16KGeom<KS, COUT, NW> G;
   constexpr int P = KS / 2, HH = G::HH, T = G::T, MT = COUT / 16, NT = 4;
   constexpr int PIXB = G::PIXB, ROWB = G::ROWB, IMGB = G::IMGB, HALO_B = G::HALO_B, WTAP_B = G::WTAP_B;
@@ -532,6 +616,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_b16k_kernel(con
 #undef MFMA
 #undef SGB
 
+  if constexpr (MODE == B16K_DGRAD) {
+    b16k_epilogue_dgrad<MT>(a, acc, bid, wm, b0 + wm, y0, x0, m, g, HW);
+    return;
+  }
   // (fused form: the 1x1 weight's halves sit in the ring slots of the two requests past the stream's end, slabs S and S+1)
   b16k_epilogue<MT, MODE>(a, acc, b0 + wm, y0, x0, m, g, HW, wbuf + slot * WTAP_B, wbuf + (slot == 2 ? 0 : slot + 1) * WTAP_B);
 }
@@ -586,6 +674,19 @@ __global__ void pack_b16k_pair_kernel(const float* __restrict__ w, __bf16* __res
   }
 }
 
+// dgrad weight of a conv with OIHW weight w[cout_f][cin_f][ks][ks]: the packed conv is W'[n][k = co][kh][kw] =
+// W[co][ci0 + n][K-1-kh][K-1-kw] (n = 0..127: the input-channel slice whose gradient the launch produces, reduction over the
+// forward conv's C_out), in conv_b16k's slab layout [co/32][tap][k group][128][8]
+__global__ void pack_b16k_dgrad_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int cout_f, int cin_f, int T, int ci0) {
+  const size_t total = (size_t)128 * cout_f * T;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i & 7, n = (i >> 3) & 127, g = (i >> 10) & 3;
+    const int tap = (i >> 12) % T, kb = (i >> 12) / T;
+    const int co = kb * 32 + g * 8 + j;
+    wp[i] = (__bf16)w[((size_t)co * cin_f + ci0 + n) * T + (T - 1 - tap)];
+  }
+}
+
 extern "C" long long tsr_conv_weight_b16k_elems(int cout, int cin, int ks) { return (long long)cout * cin * ks * ks; }
 extern "C" long long tsr_conv_weight_b16k_pair_elems(int cin) { return (long long)(cin >> 5) * B16KSteps<5, B16K_PAIR>::tab.n * 4096; }
 
@@ -619,6 +720,29 @@ extern "C" int tsr_pack_conv_weight_b16k_pair(const float* w128_oihw5, void* w_p
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(pack_b16k_pair_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, (hipStream_t)stream, w128_oihw5,
                      (__bf16*)w_packed, cin);
+  return tsr_check_launch();
+}
+
+// 1 if tsr_conv2d_ex runs a bf16-storage dgrad launch (nsplit = -1, epi_mode = 2) of this shape on conv_b16k -- it then wants
+// tsr_pack_conv_weight_dgrad_b16k's pack: 128 input channels per launch, 3x3 / 5x5, the forward conv's C_out a multiple of 32
+extern "C" int tsr_conv2d_ex_dgrad_b16k(int nprime, int cout_f, int ks) {
+  return nprime == 128 && (ks == 3 || ks == 5) && cout_f > 0 && (cout_f & 31) == 0;
+}
+
+extern "C" int tsr_pack_conv_weight_dgrad_b16k(const float* w_oihw, void* w_packed, int cout, int cin, int ks, int ci0, void* stream) {
+  if (!w_oihw || !w_packed || !tsr_conv2d_ex_dgrad_b16k(128, cout, ks) || ci0 < 0 || ci0 + 128 > cin) return TSR_ERR_ARG;
+  const size_t total = (size_t)128 * cout * ks * ks;
+  const int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(pack_b16k_dgrad_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                     (__bf16*)w_packed, cout, cin, ks * ks, ci0);
+  return tsr_check_launch();
+}
+
+// called by tsr_conv2d_ex's bf16-storage dispatcher (conv_mfma_split16.hip) for the launches tsr_conv2d_ex_dgrad_b16k names
+int tsr_conv_b16k_dgrad(const ConvArgs& a, int ks, hipStream_t st) {
+  if (a.in_scale || !a.mask || (a.bn_a && !a.slab) || (long long)4 * a.in_ctot * a.H * a.W * 2 >= 0x7fffffffLL) return TSR_ERR_ARG;
+  if (ks == 3) B16K_LAUNCH(3, 128, B16K_DGRAD)
+  else B16K_LAUNCH(5, 128, B16K_DGRAD)
   return tsr_check_launch();
 }
 

@@ -784,7 +784,11 @@ static int launch_b16_ex(const ConvArgs& a, hipStream_t st) {
   return tsr_check_launch();
 }
 
+extern "C" int tsr_conv2d_ex_dgrad_b16k(int nprime, int cout_f, int ks);       // conv_b16k.hip
+int tsr_conv_b16k_dgrad(const ConvArgs& a, int ks, hipStream_t st);
 static int dispatch_b16_ex(const ConvArgs& a, int cout, int ks, hipStream_t st) {
+  // dgrad launches of the 128-channel 3x3 / 5x5 layers: conv_b16k (weights from tsr_pack_conv_weight_dgrad_b16k)
+  if (a.epi_mode == 2 && tsr_conv2d_ex_dgrad_b16k(cout, a.cin, ks)) return tsr_conv_b16k_dgrad(a, ks, st);
   if (cout == 64) {
     if (ks == 1) return launch_b16_ex<1, 64>(a, st);
     if (ks == 3) return launch_b16_ex<3, 64>(a, st);

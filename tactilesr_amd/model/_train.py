@@ -103,8 +103,13 @@ def _pack(w, cout, cin, ks, nsplit=0, w_amax=None):
     return wp
 
 
-def _pack_dgrad(w, cout, cin, ks, ci0, nprime, nsplit=0, w_amax=None):
+def _pack_dgrad(w, cout, cin, ks, ci0, nprime, nsplit=0, w_amax=None, masked=True):
     if nsplit == -1:
+        # (`masked`: the launch has the ReLU-mask epilogue, epi_mode 2 -- the only dgrad form tsr_conv2d_ex routes to conv_b16k)
+        if masked and _lib.load().tsr_conv2d_ex_dgrad_b16k(nprime, cout, ks):   # that kernel's slab layout
+            wp = torch.empty(_lib.load().tsr_conv_weight_b16k_elems(nprime, cout, ks), dtype=torch.bfloat16, device=w.device)
+            call("tsr_pack_conv_weight_dgrad_b16k", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), _I(ci0), stream())
+            return wp
         nsplit = 1
     if nsplit == -2:
         n = _lib.load().tsr_conv_weight_bf16s_elems(nprime, cout, ks, 2)
@@ -484,7 +489,7 @@ class TrainEngine:
         w = conv.weight.detach().contiguous()
         cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
         wa = c.wamax.get(id(conv))
-        wp = _pack_dgrad(w, cout, cin, ks, ci0, nprime, self.nsplit, wa)
+        wp = _pack_dgrad(w, cout, cin, ks, ci0, nprime, self.nsplit, wa, masked=mask is not None)
         with self._timed(("dgrad", ks, nprime, cout)):
             conv_ex(B=c.B, H=c.H, W=c.W, src=dz, w=wp, cout=nprime, ks=ks, out=out, out_ctot=out_ctot,
                     out_coff=out_coff, res=res, epi_mode=2 if mask is not None else 0, mask=mask, bn=bn,

@@ -129,6 +129,63 @@ def test_conv2d_dgrad_with_mask_and_bn_sums(T, ks, cin, cout, B, H, W, NP):
     assert relerr(torch.cat(dbet), gbt) < 1e-5
 
 
+@pytest.mark.parametrize("ks,cin,cout,B,H,W,res", [(5, 128, 128, 5, 16, 24, True), (3, 128, 128, 1, 40, 40, True),
+                                                    (3, 256, 64, 3, 13, 21, False), (5, 128, 96, 2, 40, 40, True)])
+def test_conv2d_dgrad_bf16_storage_b16k(T, ks, cin, cout, B, H, W, res):
+    """Training with bf16 activation storage: the dgrad launches of the 128-input-channel 3x3 / 5x5 layers run
+    csrc/conv_b16k.hip (tsr_conv2d_ex, nsplit = -1, epi_mode = 2; weights from tsr_pack_conv_weight_dgrad_b16k).  Yardstick:
+    the same arithmetic in fp64 on the bf16-ROUNDED operands (dz, weights, stored activation, partial gradient) -- out = bf16 of
+    (conv_transpose(dz, w) + res) where the stored activation's BatchNorm + ReLU was on: >= 99 % of the elements identical, the
+    rest within one bf16 ulp (+ the fp32-accumulation floor next to zero); BatchNorm-backward sums sum(x), sum(x * xhat)
+    over every slab entry within 1e-4 of the tensor's scale (they are taken from the fp32 values, not the rounded ones)."""
+    from tactilesr_amd.model._train import conv_ex, Act, _pack_dgrad
+    from tactilesr_amd._lib import load
+    g = torch.Generator().manual_seed(ks * 7 + cin + cout + B)
+    NP = 128
+    q = lambda t: t.bfloat16().float()
+    dy = q(torch.randn(B, cout, H, W, generator=g))
+    w = torch.randn(cout, cin, ks, ks, generator=g) * 0.05
+    z = q(torch.randn(B, cin, H, W, generator=g))
+    extra = q(torch.randn(B, cin, H, W, generator=g) * 0.1)
+    msc, msh = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    ba, bb = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.2
+    lib = load()
+    to16 = lambda t, ctot=None, coff=0: T.to_cb16(t.cuda(), ctot, coff).to(torch.bfloat16)
+    dyd, zd, exd = to16(dy), to16(z), to16(extra)
+    gbuf = torch.full((B * cin * H * W,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    entries = lib.tsr_conv2d_slab_entries_ex(B, H, W, NP, ks, -1)
+    wd = w.cuda().contiguous()
+    full = F.conv_transpose2d(dy.double(), q(w).double(), padding=ks // 2)
+    for o in range(0, cin, NP):
+        assert lib.tsr_conv2d_ex_dgrad_b16k(NP, cout, ks) == 1
+        slab = torch.full((entries * NP * 2,), float("nan"), device="cuda")
+        wp = _pack_dgrad(wd, cout, cin, ks, o, NP, -1)
+        sl = slice(o, o + NP)
+        mk = Act(zd, cin, o, NP, msc[sl].cuda().contiguous(), msh[sl].cuda().contiguous(), ba[sl].cuda().contiguous(),
+                 bb[sl].cuda().contiguous())
+        conv_ex(B=B, H=H, W=W, src=Act(dyd, cout, 0, cout), w=wp, cout=NP, ks=ks, out=gbuf, out_ctot=cin, out_coff=o,
+                res=Act(exd, cin, o, NP) if res else None, epi_mode=2, mask=mk, bn=True, slab=slab, nsplit=-1)
+        x = full[:, sl] + (extra[:, sl].double() if res else 0.0)
+        on = (z[:, sl].double() * msc[sl].double().view(1, -1, 1, 1) + msh[sl].double().view(1, -1, 1, 1)) > 0
+        x = torch.where(on, x, torch.zeros_like(x))
+        ref = x.float().bfloat16().float()
+        got = T.from_cb16(gbuf, B, cin, H, W)[:, sl].float().cpu()
+        ulp = (ref.abs() * 2.0 ** -7).clamp_min(1e-30)
+        d = (got - ref).abs()
+        same = float((d == 0).float().mean())
+        floor = 3e-6 * float(ref.abs().max())
+        bad = d > torch.maximum(1.01 * ulp, torch.full_like(ulp, floor))
+        xhat = z[:, sl].double() * ba[sl].double().view(1, -1, 1, 1) + bb[sl].double().view(1, -1, 1, 1)
+        s1, s2 = x.sum(dim=(0, 2, 3)), (x * xhat).sum(dim=(0, 2, 3))
+        sums = slab.view(entries, NP, 2).double().sum(0).cpu()
+        e1 = float((sums[:, 0] - s1).abs().max() / s1.abs().max()), float((sums[:, 1] - s2).abs().max() / s2.abs().max())
+        print(f"[b16k dgrad] k{ks} {cout}->{cin}[{o}:{o + NP}] B={B} {H}x{W}: identical {same:.5f}, beyond one ulp {int(bad.sum())}, "
+              f"sums {e1[0]:.1e} / {e1[1]:.1e}")
+        assert same >= 0.99 and not bad.any()
+        assert e1[0] < 1e-4 and e1[1] < 1e-4
+    assert not torch.isnan(gbuf.float()).any()
+
+
 def _subs(t, k=512):
     t = t.detach().flatten()
     return t[:: max(1, t.numel() // k)].cpu().numpy()
