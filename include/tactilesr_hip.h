@@ -146,10 +146,11 @@ int tsr_conv2d_fwd_b16(const void* in, int in_ctot, int in_coff, int cin, const 
 long long tsr_conv_weight_b16k_elems(int cout, int cin, int ks);
 int tsr_pack_conv_weight_b16k(const float* w_oihw, void* w_packed, int cout, int cin, int ks, void* stream);
 int tsr_pack_w2_b16k(const float* w2_64x128, void* w_packed, void* stream);
-/* Training with bf16 activation storage: tsr_conv2d_ex (nsplit = -1) runs the epi_mode-2 (dgrad) launches for which
- * tsr_conv2d_ex_dgrad_b16k(nprime, cout, ks) returns 1 on the same kernel; their weight is then packed by
- * tsr_pack_conv_weight_dgrad_b16k (arguments as tsr_pack_conv_weight_dgrad_bf16s with nprime = 128;
- * tsr_conv_weight_b16k_elems(128, cout, ks) elements). */
+/* Training with bf16 activation storage: a dgrad launch of tsr_conv2d_ex whose shape tsr_conv2d_ex_dgrad_b16k(nprime, cout,
+ * ks) accepts may be described with nsplit = -3 instead of -1: it then runs on the same kernel (epi_mode 2, or 0 for the
+ * unmasked partial gradient; no input / residual transform), with its weight packed by tsr_pack_conv_weight_dgrad_b16k
+ * (arguments as tsr_pack_conv_weight_dgrad_bf16s with nprime = 128; tsr_conv_weight_b16k_elems(128, cout, ks) elements).
+ * Slab entries as for nsplit = -1. */
 int tsr_conv2d_ex_dgrad_b16k(int nprime, int cout, int ks);
 int tsr_pack_conv_weight_dgrad_b16k(const float* w_oihw, void* w_packed, int cout, int cin, int ks, int ci0, void* stream);
 long long tsr_conv_weight_b16k_pair_elems(int cin);
@@ -218,7 +219,7 @@ typedef struct tsr_conv_desc {
   const float* mask_scale; const float* mask_shift;
   const float* bn_a; const float* bn_b;
   float* slab; float* slab_cnt;
-  int nsplit;   /* -1: plain bf16 operands AND bf16 CB16 tensors (in / res / mask / out address bf16 elements; w_packed as
+  int nsplit;   /* -3: as -1 on csrc/conv_b16k.hip (dgrad launches, see tsr_conv2d_ex_dgrad_b16k); -1: plain bf16 operands AND bf16 CB16 tensors (in / res / mask / out address bf16 elements; w_packed as
                    for 1): the train step with bf16 activation storage;
                    0: fp32 MFMA, w_packed from tsr_pack_conv_weight[_dgrad]; 1..3: split-bf16 MFMA (3 = fp32-equivalent),
                    w_packed from tsr_pack_conv_weight[_dgrad]_bf16s; -2: fp16 two-plane split ("fp16x3"), w_packed from

@@ -723,8 +723,8 @@ extern "C" int tsr_pack_conv_weight_b16k_pair(const float* w128_oihw5, void* w_p
   return tsr_check_launch();
 }
 
-// 1 if tsr_conv2d_ex runs a bf16-storage dgrad launch (nsplit = -1, epi_mode = 2) of this shape on conv_b16k -- it then wants
-// tsr_pack_conv_weight_dgrad_b16k's pack: 128 input channels per launch, 3x3 / 5x5, the forward conv's C_out a multiple of 32
+// 1 if tsr_conv2d_ex accepts nsplit = -3 for a dgrad launch of this shape (bf16 tensors, conv_b16k, weights from
+// tsr_pack_conv_weight_dgrad_b16k): 128 input channels per launch, 3x3 / 5x5, the forward conv's C_out a multiple of 32
 extern "C" int tsr_conv2d_ex_dgrad_b16k(int nprime, int cout_f, int ks) {
   return nprime == 128 && (ks == 3 || ks == 5) && cout_f > 0 && (cout_f & 31) == 0;
 }
@@ -738,11 +738,19 @@ extern "C" int tsr_pack_conv_weight_dgrad_b16k(const float* w_oihw, void* w_pack
   return tsr_check_launch();
 }
 
-// called by tsr_conv2d_ex's bf16-storage dispatcher (conv_mfma_split16.hip) for the launches tsr_conv2d_ex_dgrad_b16k names
-int tsr_conv_b16k_dgrad(const ConvArgs& a, int ks, hipStream_t st) {
-  if (a.in_scale || !a.mask || (a.bn_a && !a.slab) || (long long)4 * a.in_ctot * a.H * a.W * 2 >= 0x7fffffffLL) return TSR_ERR_ARG;
-  if (ks == 3) B16K_LAUNCH(3, 128, B16K_DGRAD)
-  else B16K_LAUNCH(5, 128, B16K_DGRAD)
+// tsr_conv2d_ex with nsplit = -3: a training launch on bf16 tensors whose input needs no transform (a stored gradient) -- the
+// masked dgrad (epi_mode 2) or the plain one (epi_mode 0: out = act(acc * scale + shift + res))
+int tsr_conv_b16k_ex(const ConvArgs& a, int cout, int ks, hipStream_t st) {
+  if (!tsr_conv2d_ex_dgrad_b16k(cout, a.cin, ks) || a.in_scale || a.res_scale || a.epi_mode == 1 ||
+      (long long)4 * a.in_ctot * a.H * a.W * 2 >= 0x7fffffffLL)
+    return TSR_ERR_ARG;
+  if (a.epi_mode == 2) {
+    if (ks == 3) B16K_LAUNCH(3, 128, B16K_DGRAD)
+    else B16K_LAUNCH(5, 128, B16K_DGRAD)
+  } else {
+    if (ks == 3) B16K_LAUNCH(3, 128, B16K_PLAIN)
+    else B16K_LAUNCH(5, 128, B16K_PLAIN)
+  }
   return tsr_check_launch();
 }
 

@@ -103,13 +103,12 @@ def _pack(w, cout, cin, ks, nsplit=0, w_amax=None):
     return wp
 
 
-def _pack_dgrad(w, cout, cin, ks, ci0, nprime, nsplit=0, w_amax=None, masked=True):
+def _pack_dgrad(w, cout, cin, ks, ci0, nprime, nsplit=0, w_amax=None):
+    if nsplit == -3:          # bf16 activation storage, the launch runs csrc/conv_b16k.hip: that kernel's slab layout
+        wp = torch.empty(_lib.load().tsr_conv_weight_b16k_elems(nprime, cout, ks), dtype=torch.bfloat16, device=w.device)
+        call("tsr_pack_conv_weight_dgrad_b16k", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), _I(ci0), stream())
+        return wp
     if nsplit == -1:
-        # (`masked`: the launch has the ReLU-mask epilogue, epi_mode 2 -- the only dgrad form tsr_conv2d_ex routes to conv_b16k)
-        if masked and _lib.load().tsr_conv2d_ex_dgrad_b16k(nprime, cout, ks):   # that kernel's slab layout
-            wp = torch.empty(_lib.load().tsr_conv_weight_b16k_elems(nprime, cout, ks), dtype=torch.bfloat16, device=w.device)
-            call("tsr_pack_conv_weight_dgrad_b16k", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), _I(ci0), stream())
-            return wp
         nsplit = 1
     if nsplit == -2:
         n = _lib.load().tsr_conv_weight_bf16s_elems(nprime, cout, ks, 2)
@@ -489,11 +488,16 @@ class TrainEngine:
         w = conv.weight.detach().contiguous()
         cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
         wa = c.wamax.get(id(conv))
-        wp = _pack_dgrad(w, cout, cin, ks, ci0, nprime, self.nsplit, wa, masked=mask is not None)
+        # bf16 storage: the 128-channel 3x3 / 5x5 dgrads (masked or not) run conv_b16k (nsplit -3; same tensors, its own pack)
+        ns = self.nsplit
+        if self.io16 and dz.scale is None and (res is None or res.scale is None) and \
+                _lib.load().tsr_conv2d_ex_dgrad_b16k(nprime, cout, ks):
+            ns = -3
+        wp = _pack_dgrad(w, cout, cin, ks, ci0, nprime, ns, wa)
         with self._timed(("dgrad", ks, nprime, cout)):
             conv_ex(B=c.B, H=c.H, W=c.W, src=dz, w=wp, cout=nprime, ks=ks, out=out, out_ctot=out_ctot,
                     out_coff=out_coff, res=res, epi_mode=2 if mask is not None else 0, mask=mask, bn=bn,
-                    slab=c.slab if bn else None, slab_cnt=None, nsplit=self.nsplit, w_amax=wa,
+                    slab=c.slab if bn else None, slab_cnt=None, nsplit=ns, w_amax=wa,
                     out_amax=out_amax)
         c.last_entries = self._entries(c, nprime, ks)      # what a following _bn_bwd reduces
 

@@ -133,7 +133,7 @@ def test_conv2d_dgrad_with_mask_and_bn_sums(T, ks, cin, cout, B, H, W, NP):
                                                     (3, 256, 64, 3, 13, 21, False), (5, 128, 96, 2, 40, 40, True)])
 def test_conv2d_dgrad_bf16_storage_b16k(T, ks, cin, cout, B, H, W, res):
     """Training with bf16 activation storage: the dgrad launches of the 128-input-channel 3x3 / 5x5 layers run
-    csrc/conv_b16k.hip (tsr_conv2d_ex, nsplit = -1, epi_mode = 2; weights from tsr_pack_conv_weight_dgrad_b16k).  Yardstick:
+    csrc/conv_b16k.hip (tsr_conv2d_ex, nsplit = -3, epi_mode = 2; weights from tsr_pack_conv_weight_dgrad_b16k).  Yardstick:
     the same arithmetic in fp64 on the bf16-ROUNDED operands (dz, weights, stored activation, partial gradient) -- out = bf16 of
     (conv_transpose(dz, w) + res) where the stored activation's BatchNorm + ReLU was on: >= 99 % of the elements identical, the
     rest within one bf16 ulp (+ the fp32-accumulation floor next to zero); BatchNorm-backward sums sum(x), sum(x * xhat)
@@ -159,12 +159,19 @@ def test_conv2d_dgrad_bf16_storage_b16k(T, ks, cin, cout, B, H, W, res):
     for o in range(0, cin, NP):
         assert lib.tsr_conv2d_ex_dgrad_b16k(NP, cout, ks) == 1
         slab = torch.full((entries * NP * 2,), float("nan"), device="cuda")
-        wp = _pack_dgrad(wd, cout, cin, ks, o, NP, -1)
+        wp = _pack_dgrad(wd, cout, cin, ks, o, NP, -3)
         sl = slice(o, o + NP)
         mk = Act(zd, cin, o, NP, msc[sl].cuda().contiguous(), msh[sl].cuda().contiguous(), ba[sl].cuda().contiguous(),
                  bb[sl].cuda().contiguous())
         conv_ex(B=B, H=H, W=W, src=Act(dyd, cout, 0, cout), w=wp, cout=NP, ks=ks, out=gbuf, out_ctot=cin, out_coff=o,
-                res=Act(exd, cin, o, NP) if res else None, epi_mode=2, mask=mk, bn=True, slab=slab, nsplit=-1)
+                res=Act(exd, cin, o, NP) if res else None, epi_mode=2, mask=mk, bn=True, slab=slab, nsplit=-3)
+        if o == 0:          # the unmasked form (the first half of a two-conv gradient): out = bf16(conv_transpose(dz, w))
+            g0 = torch.full((B * NP * H * W,), float("nan"), dtype=torch.bfloat16, device="cuda")
+            conv_ex(B=B, H=H, W=W, src=Act(dyd, cout, 0, cout), w=wp, cout=NP, ks=ks, out=g0, out_ctot=NP, out_coff=0, nsplit=-3)
+            r0 = full[:, sl].float().bfloat16().float()
+            d0 = (T.from_cb16(g0, B, NP, H, W).float().cpu() - r0).abs()
+            assert float((d0 == 0).float().mean()) >= 0.99
+            assert not (d0 > torch.maximum(1.01 * r0.abs() * 2.0 ** -7, torch.full_like(r0, 3e-6 * float(r0.abs().max())))).any()
         x = full[:, sl] + (extra[:, sl].double() if res else 0.0)
         on = (z[:, sl].double() * msc[sl].double().view(1, -1, 1, 1) + msh[sl].double().view(1, -1, 1, 1)) > 0
         x = torch.where(on, x, torch.zeros_like(x))
