@@ -881,6 +881,10 @@ extern "C" int tsr_conv2d_wgrad_splits(int cout, int cin, int ks, int planes, in
   return (int)ns;
 }
 
+bool tsr_wgrad_b16k_ok(int cout, int cin, int ks, int H, int W, int a_ctot, int dz_ctot);            // wgrad_b16k.hip
+int tsr_wgrad_b16k(const void* a, int a_ctot, int a_coff, int cin, const void* dz, int dz_ctot, int dz_coff, int cout, int ks,
+                   float* slab, float* bias_slab, int nsplit, int B, int H, int W, hipStream_t st);
+
 int tsr_conv2d_wgrad_tr16(const float* a, int a_ctot, int a_coff, int cin, const float* a_scale, const float* a_shift,
                           const float* dz, int dz_ctot, int dz_coff, int cout, int ks, int planes,
                           const float* a_amax, const float* dz_amax, float* slab, float* bias_slab, int nsplit,
@@ -902,6 +906,9 @@ int tsr_conv2d_wgrad_tr16(const float* a, int a_ctot, int a_coff, int cin, const
     return launch_tr16<5, 1, false>(g, st);
   }
   if (planes == -1) {       // bf16 tensors (activation storage of the "bf16" configurations), one bf16 plane
+    // no fused input transform: nothing to compute while staging -- the LDS-DMA kernel (same tiles, splits and slabs)
+    if (!a_scale && tsr_wgrad_b16k_ok(cout, cin, ks, H, W, a_ctot, dz_ctot))
+      return tsr_wgrad_b16k(a, a_ctot, a_coff, cin, dz, dz_ctot, dz_coff, cout, ks, slab, bias_slab, nsplit, B, H, W, st);
     if (ks == 1) return launch_tr16<1, 1, false, true>(g, st);
     if (ks == 3) return launch_tr16<3, 1, false, true>(g, st);
     return launch_tr16<5, 1, false, true>(g, st);

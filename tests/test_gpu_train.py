@@ -76,6 +76,48 @@ def test_conv2d_wgrad(T, ks, cin, cout, B, H, W, affine, impl):
     assert relerr(outb, gb) < 1e-5
 
 
+@pytest.mark.parametrize("ks,cin,cout,B,H,W,affine,ns", [
+    (3, 64, 64, 3, 40, 40, False, 3), (5, 64, 64, 2, 40, 40, False, 2), (3, 128, 128, 2, 40, 40, False, 7),
+    (5, 128, 128, 2, 16, 24, False, 5), (3, 128, 64, 5, 13, 21, False, 4), (5, 128, 128, 3, 13, 21, False, 1),
+    (5, 64, 128, 1, 5, 3, False, 2), (3, 256, 128, 2, 40, 40, False, 11), (5, 128, 128, 2, 40, 40, True, 3),
+    (3, 128, 128, 2, 13, 21, True, 2), (1, 256, 64, 3, 40, 40, True, 3), (1, 256, 64, 2, 13, 21, False, 2),
+])
+def test_conv2d_wgrad_bf16_storage(T, ks, cin, cout, B, H, W, affine, ns):
+    """Training with bf16 activation storage: the weight / bias gradient from bf16 CB16 tensors (tsr_conv2d_wgrad_bf16s,
+    planes = -1).  Launches without a fused input transform run csrc/wgrad_b16k.hip (LDS-DMA staging), the others
+    wgrad_mfma_tr16.hip.  Yardstick: torch autograd in fp64 on the bf16-ROUNDED operands (with `affine`, the input is
+    bf16(relu(z * scale + shift)) of the stored bf16 z, fp32 arithmetic, as the kernel forms it): products of bf16 values
+    are exact in fp32, so what is left is fp32 summation order -- 1e-5 of the gradient's scale.  Ragged images (13 x 21,
+    5 x 3), channel offsets into wider tensors and split counts that do not divide the items are part of the cases."""
+    from tactilesr_amd._lib import call, ptr, stream, c_int as I, c_float as Fl, c_longlong as L
+    g = torch.Generator().manual_seed(ks * 3 + cin + cout + B + H)
+    q = lambda t: t.bfloat16().float()
+    araw = q(torch.randn(B, cin, H, W, generator=g))
+    dz = q(torch.randn(B, cout, H, W, generator=g))
+    sc = torch.rand(cin, generator=g) + 0.5
+    sh = torch.randn(cin, generator=g) * 0.3
+    a = q(F.relu(torch.addcmul(sh.view(1, -1, 1, 1), araw, sc.view(1, -1, 1, 1)))) if affine else araw
+    w = torch.zeros(cout, cin, ks, ks, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(a.double(), w, padding=ks // 2)
+    (gw,) = torch.autograd.grad(y, w, dz.double())
+    gb = dz.double().sum(dim=(0, 2, 3))
+    ad = T.to_cb16(araw.cuda(), cin + 16, 16).to(torch.bfloat16)
+    dzd = T.to_cb16(dz.cuda(), cout + 32, 16).to(torch.bfloat16)
+    scd, shd = (sc.cuda(), sh.cuda()) if affine else (None, None)
+    n = cout * cin * ks * ks
+    slab = torch.full((ns * n,), float("nan"), device="cuda")
+    bslab = torch.full((ns * cout,), float("nan"), device="cuda")
+    call("tsr_conv2d_wgrad_bf16s", ptr(ad), I(cin + 16), I(16), I(cin), ptr(scd), ptr(shd), ptr(dzd), I(cout + 32),
+         I(16), I(cout), I(ks), I(-1), None, None, ptr(slab), ptr(bslab), I(ns), I(B), I(H), I(W), stream())
+    out = torch.empty(cout, cin, ks, ks, device="cuda")
+    outb = torch.empty(cout, device="cuda")
+    call("tsr_reduce_splits", ptr(slab), ptr(out), L(n), I(ns), Fl(1.0), stream())
+    call("tsr_reduce_splits", ptr(bslab), ptr(outb), L(cout), I(ns), Fl(1.0), stream())
+    e, eb = relerr(out, gw), relerr(outb, gb)
+    print(f"[bf16 wgrad] k{ks} {cin}->{cout} B={B} {H}x{W} affine={affine} ns={ns}: dW {e:.1e}, db {eb:.1e}")
+    assert e < 1e-5 and eb < 1e-5
+
+
 @pytest.mark.parametrize("ks,cin,cout,B,H,W,NP", [(3, 64, 64, 3, 40, 40, 64), (5, 128, 128, 2, 16, 24, 64),
                                                   (1, 256, 64, 2, 40, 40, 64), (3, 448, 64, 1, 40, 40, 64),
                                                   (1, 256, 64, 1, 40, 40, 128), (1, 256, 64, 3, 40, 40, 128),

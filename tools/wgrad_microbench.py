@@ -2,7 +2,7 @@
 """Time tsr_conv2d_wgrad_bf16s alone, on the operand pattern the train step gives it (input = relu(bn(z)) fused into
 the staging, gradient-like dz), and sanity-check the result against torch's conv weight gradient on the GPU:
 
-    python tools/wgrad_microbench.py [ks cin cout B planes [splits]]
+    python tools/wgrad_microbench.py [ks cin cout B planes [splits]]        (WG_RAW=1: no fused input transform)
 """
 import os
 import sys
@@ -32,6 +32,11 @@ if planes == -1:
     a, dz = a.to(torch.bfloat16), dz.to(torch.bfloat16)
 
 
+RAW = os.environ.get("WG_RAW") == "1"
+if RAW:
+    sc = sh = None
+
+
 def run():
     call("tsr_conv2d_wgrad_bf16s", ptr(a), I(cin), I(0), I(cin), ptr(sc), ptr(sh), ptr(dz), I(cout), I(0), I(cout),
          I(ks), I(planes), ptr(am[0:1]), ptr(am[1:2]), ptr(slab), ptr(bslab), I(ns), I(B), I(H), I(W), stream())
@@ -52,7 +57,7 @@ out = torch.empty(cout, cin, ks, ks, device="cuda")
 call("tsr_reduce_splits", ptr(slab), ptr(out), L(n), I(ns), Fl(1.0), stream())
 nb = min(B, 64)                                     # sanity reference on the first images only when B is large
 if nb == B:
-    act = F.relu(z * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).double()
+    act = (z if RAW else F.relu(z * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))).double()
     ref = torch.nn.grad.conv2d_weight(act, (cout, cin, ks, ks), dzn.double(), padding=ks // 2)
     err = float((out.double() - ref).abs().max() / ref.abs().max())
 else:
