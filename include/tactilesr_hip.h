@@ -316,6 +316,13 @@ int tsr_cb16_stats_b16(const void* z, int z_ctot, int z_coff, int B, int HW, flo
                        void* stream);
 int tsr_bn_bwd_apply_b16(void* g, int g_ctot, int g_coff, const void* z, int z_ctot, int z_coff,
                          const float* c1, const float* c2, const float* c3, int C, int B, int HW, void* stream);
+/* out[B][C/16][HW][16] (bf16) = bf16(relu(fp32(z) * scale + shift)) of channels z_coff .. z_coff + C of the stored
+ * pre-BatchNorm tensor: the MATERIALISED form of a virtual activation.  tsr_conv2d_wgrad_bf16s (planes = -1) runs the 3x3 /
+ * 5x5 launches for which tsr_conv2d_wgrad_b16k(cout, cin, ks) returns 1 on csrc/wgrad_b16k.hip (operands straight from HBM
+ * into LDS) when they carry NO input transform: a caller with a virtual input materialises it once and passes it plain. */
+int tsr_bn_relu_b16(const void* z, int z_ctot, int z_coff, int C, const float* scale, const float* shift, void* out,
+                    int B, int HW, void* stream);
+int tsr_conv2d_wgrad_b16k(int cout, int cin, int ks);
 int tsr_stem_wgrad_b16(const float* lr, int lr_ctot, int lr_coff, int hin, int win, int sf,
                        const void* dz, int dz_ctot, int dz_coff, float* slab, int nsplit, int B, void* stream);
 int tsr_head_bwd_b16(const float* dout, const float* out, const void* h0, int h_ctot, int cin,

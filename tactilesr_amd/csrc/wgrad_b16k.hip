@@ -24,6 +24,7 @@
 //   * The bias gradient (workgroups cib = 0, kg = 0) is summed from the A fragments: wave (wm, wn) sums C_out tile wn of its
 //     wm, 16 VALU operations per item.
 #include "tsr_common.h"
+#include "tactilesr_hip.h"
 #include <type_traits>
 
 typedef __bf16 gb16x8 __attribute__((ext_vector_type(8)));
@@ -46,6 +47,10 @@ __device__ __forceinline__ void wgb_dma(gi32x4 rs, int vo, unsigned m0v) {
                : "=&s"(keep) : "s"(m0v), "v"(vo), "s"(rs));
 }
 
+#ifndef TSR_WGB_PF
+#define TSR_WGB_PF 1
+#endif
+
 template <int KS, int KHW, int CO, int CI, int WM>
 struct WgradBGeom {
   static constexpr int NWM = CO / WM, NWN = CI / 32, NW = NWM * NWN, NT = 64 * NW;
@@ -56,7 +61,7 @@ struct WgradBGeom {
   // 16-B units of a slot: dz blocks (64 each), then `a` blocks (UPB each)
   static constexpr int UDZ = (CO / 16) * 64, UPB = AROWS * PITCH * 2, UA = (CI / 16) * UPB, U = UDZ + UA;
   static constexpr int NV = ((U + 63) / 64 + NW - 1) / NW;  // requests per wave and item
-  static constexpr int SLOTB = NV * NW * 1024, RING = 3, LDSB = RING * SLOTB;
+  static constexpr int SLOTB = NV * NW * 1024, RING = 3, LA = RING - 1, LDSB = RING * SLOTB;
   static_assert(MT <= NWN, "bias sums: one C_out tile per wave");
   static_assert(ACOLS <= PITCH && LDSB <= 160 * 1024, "slot");
 };
@@ -107,52 +112,66 @@ void wgrad_b16k_kernel(const WgradBArgs g) {
   const int it0 = sp * per;
   const int it1 = it0 + per < total_items ? it0 + per : total_items;
   const int nitem = it1 > it0 ? it1 - it0 : 0;
-  int nit = it0;                                                                  // next item to REQUEST
-  int nb = it0 / tpi, nty = (it0 - nb * tpi) / g.tiles_x, ntx = it0 - nb * tpi - nty * g.tiles_x;
 
-  // ---- request constants of this lane: request v of the wave is 1-KB chunk k = wave + v * NW of the slot
+  // ---- request constants of this lane: request v of the wave is 1-KB chunk k = wave + v * NW of the slot; the dz blocks
+  // are chunks 0 .. NW-1 (C_out/16 = NW in every tile shape), i.e. request 0 of every wave, requests 1.. fetch `a`
+  static_assert(CO / 16 == NW, "request 0 = the wave's dz block");
   int lc[NV], ry[NV], cx[NV];
-#pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    const int k = wave + v * NW;
-    if (k < CO / 16) {                         // a dz block: 32 pixels x 2 halves
-      const int px = lane >> 1;
-      ry[v] = px >> 3; cx[v] = px & 7;
-      lc[v] = k * HW * 32 + (ry[v] * g.W + cx[v]) * 32 + (lane & 1) * 16;
-    } else {
-      const int ua = 64 * k + lane - G::UDZ;
-      const int blk = ua / G::UPB, rem = ua - blk * G::UPB;
-      const int ra = rem / (2 * PITCH), t = rem - ra * 2 * PITCH, ca = t >> 1;
-      const bool bad = blk >= CI / 16 || ca >= G::ACOLS;      // slot padding: never fetched
-      ry[v] = bad ? 0x40000000 : ra; cx[v] = ca;
-      lc[v] = blk * HW * 32 + (ra * g.W + ca) * 32 + (t & 1) * 16;
-    }
+  {
+    const int px = lane >> 1;
+    ry[0] = px >> 3; cx[0] = px & 7;
+    lc[0] = wave * HW * 32 + (ry[0] * g.W + cx[0]) * 32 + (lane & 1) * 16;
   }
-  const unsigned long long dz_base = (unsigned long long)g.dz, a_base = (unsigned long long)g.a;
+#pragma unroll
+  for (int v = 1; v < NV; ++v) {
+    const int ua = 64 * (wave + (v - 1) * NW) + lane;
+    const int blk = ua / G::UPB, rem = ua - blk * G::UPB;
+    const int ra = rem / (2 * PITCH), t = rem - ra * 2 * PITCH, ca = t >> 1;
+    const bool bad = blk >= CI / 16 || ca >= G::ACOLS;      // slot padding: never fetched
+    ry[v] = bad ? 0x40000000 : ra; cx[v] = ca;
+    lc[v] = blk * HW * 32 + (ra * g.W + ca) * 32 + (t & 1) * 16;
+  }
   const unsigned lds_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds;
 
+  // next item to REQUEST: running 64-bit addresses of its corner in both tensors (the input's shifted by the kernel-row
+  // group's first tap), advanced by one of three precomputed steps (next patch / next patch row / next image)
+  int left = nitem;
+  int ntx, nty;
+  unsigned long long pd, pa;
+  {
+    const int b = it0 / tpi;
+    nty = (it0 - b * tpi) / g.tiles_x; ntx = it0 - b * tpi - nty * g.tiles_x;
+    pd = (unsigned long long)g.dz + (((unsigned long long)b * dz_blocks + (dz_c0 >> 4)) * HW + nty * 4 * g.W + ntx * 8) * 32;
+    pa = (unsigned long long)g.a +
+         (unsigned long long)((((long long)b * a_blocks + (a_c0 >> 4)) * HW + (nty * 4 + kh0 - P) * g.W + (ntx * 8 - P)) * 32);
+  }
+  const long long step_row = ((long long)4 * g.W - (g.tiles_x - 1) * 8) * 32;
+  const long long last_off = ((long long)(g.tiles_y - 1) * 4 * g.W + (g.tiles_x - 1) * 8) * 32;
+  const long long step_img_d = (long long)dz_blocks * HW * 32 - last_off, step_img_a = (long long)a_blocks * HW * 32 - last_off;
+  unsigned long long q_pd = 0, q_pa = 0;      // the item being requested
+  int q_y = 0, q_x = 0, q_nr = 0;
+  auto item_next = [&]() __attribute__((always_inline)) {
+    q_pd = pd; q_pa = pa; q_y = nty * 4; q_x = ntx * 8;
+    q_nr = 0x7fffffff & -(int)(left > 0);
+    --left;
+    const bool wx = ntx + 1 == g.tiles_x, wy = wx && nty + 1 == g.tiles_y;
+    pd += wx ? (wy ? step_img_d : step_row) : 256;
+    pa += wx ? (wy ? step_img_a : step_row) : 256;
+    nty = wx ? (wy ? 0 : nty + 1) : nty;
+    ntx = wx ? 0 : ntx + 1;
+  };
+  auto dma = [&](auto vc, int slot) __attribute__((always_inline)) {
+    constexpr int v = decltype(vc)::value;
+    const unsigned long long bs = v == 0 ? q_pd : q_pa;
+    const int Y = v == 0 ? q_y : q_y + kh0 - P, X = v == 0 ? q_x : q_x - P;
+    const bool ok = ((unsigned)(Y + ry[v]) < (unsigned)g.H) & ((unsigned)(X + cx[v]) < (unsigned)g.W);
+    const int vo = ok ? lc[v] : (int)0x80000000;
+    const gi32x4 rs = {(int)bs, (int)(bs >> 32) & 0xffff, q_nr, 0x00020000};
+    wgb_dma(rs, vo, lds_a + slot * SLOTB + 1024 * (wave + v * NW));
+  };
   auto request = [&](int slot) __attribute__((always_inline)) {
-    const int real = -(int)(nit < it1);
-    ++nit;
-    const int b = nb, y0 = nty * 4, x0 = ntx * 8;
-    if (++ntx == g.tiles_x) {
-      ntx = 0;
-      if (++nty == g.tiles_y) { nty = 0; ++nb; }
-    }
-    const unsigned long long bd = dz_base + (((unsigned long long)b * dz_blocks + (dz_c0 >> 4)) * HW + y0 * g.W + x0) * 32;
-    const long long ao = (((long long)b * a_blocks + (a_c0 >> 4)) * HW + (y0 + kh0 - P) * g.W + (x0 - P)) * 32;
-    const unsigned long long ba = a_base + (unsigned long long)ao;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int k = wave + v * NW;
-      const bool dzk = k < CO / 16;            // wave-uniform
-      const unsigned long long bs = dzk ? bd : ba;
-      const int Y = dzk ? y0 : y0 + kh0 - P, X = dzk ? x0 : x0 - P;
-      const bool ok = ((unsigned)(Y + ry[v]) < (unsigned)g.H) & ((unsigned)(X + cx[v]) < (unsigned)g.W);
-      const int vo = ok ? lc[v] : (int)0x80000000;
-      const gi32x4 rs = {(int)bs, (int)(bs >> 32) & 0xffff, 0x7fffffff & real, 0x00020000};
-      wgb_dma(rs, vo, lds_a + slot * SLOTB + 1024 * k);
-    }
+    item_next();
+    wgb_static_for<0, NV>([&](auto vc) __attribute__((always_inline)) { dma(vc, slot); });
   };
 #define WGB_VM_WAIT(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14))
 #define WGB_STEP_END(n_)                      \
@@ -185,16 +204,18 @@ void wgrad_b16k_kernel(const WgradBArgs g) {
 
   auto run = [&](auto bias_c) __attribute__((always_inline)) {
     constexpr bool BIAS = decltype(bias_c)::value;
-    // prologue: items 0 and 1 landed
-    request(0);
-    request(1);
+    static_assert(NV < NTAP, "one request per tap");
+    // prologue: the first LA items landed
+#pragma unroll
+    for (int i = 0; i < G::LA; ++i) request(i);
     WGB_STEP_END(0);
     int slot = 0;
     for (int s = 0; s < nitem; ++s) {
-      const int slot2 = slot == 0 ? 2 : slot - 1;            // (slot + 2) % 3
+      const int slot2 = slot == 0 ? G::RING - 1 : slot - 1;   // (slot + LA) % RING
       const char* sa = lds + slot * SLOTB + a_lane;
       const char* sb = lds + slot * SLOTB + b_lane;
-      gb16x8 af[MT], bf[2][2];
+      constexpr int PF = TSR_WGB_PF;             // B fragments are read PF taps ahead of their MFMAs
+      gb16x8 af[MT], bf[PF + 1][2];
       auto load_b = [&](gb16x8* dst, int tap) __attribute__((always_inline)) {
         const int khl = tap / KS, kw = tap - khl * KS;
 #pragma unroll
@@ -206,27 +227,31 @@ void wgrad_b16k_kernel(const WgradBArgs g) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
         af[m] = __builtin_shufflevector(frag(sa + m * 1024), frag(sa + m * 1024 + 512), 0, 1, 2, 3, 4, 5, 6, 7);
-      load_b(bf[0], 0);
-      __builtin_amdgcn_sched_barrier(0);
-      request(slot2);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (BIAS) {
-        typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
-        gu32x4 sel = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int m = 0; m < MT; ++m) sel = wn == m ? __builtin_bit_cast(gu32x4, af[m]) : sel;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bsum += __uint_as_float(sel[i] << 16) + __uint_as_float(sel[i] & 0xffff0000u);
-      }
+      for (int t = 0; t < PF; ++t) load_b(bf[t], t);
+      item_next();
+      __builtin_amdgcn_sched_barrier(0);
       wgb_static_for<0, NTAP>([&](auto tc) __attribute__((always_inline)) {
         constexpr int u = decltype(tc)::value;
-        if constexpr (u + 1 < NTAP) load_b(bf[(u + 1) & 1], u + 1);
+        if constexpr (u + PF < NTAP) load_b(bf[(u + PF) % (PF + 1)], u + PF);
+        // item s + LA, one request per tap (the wave's instruction issue is the scarce thing: a request is ~12 scalar /
+        // vector instructions, which fit between a tap's MFMAs; all of them in one block at the step's top would stop both
+        // waves of the SIMD at the same time)
+        if constexpr (u < NV) dma(std::integral_constant<int, u>(), slot2);
+        if constexpr (BIAS && u == NV) {
+          typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
+          gu32x4 sel = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MT; ++m) sel = wn == m ? __builtin_bit_cast(gu32x4, af[m]) : sel;
 #pragma unroll
-          for (int n = 0; n < 2; ++n)
-            acc[m][n][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[u & 1][n], acc[m][n][u], 0, 0, 0);
-        if constexpr (u + 1 < NTAP) {
+          for (int e = 0; e < 4; ++e) bsum += __uint_as_float(sel[e] << 16) + __uint_as_float(sel[e] & 0xffff0000u);
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[m][n][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[u % (PF + 1)][n], acc[m][n][u], 0, 0, 0);
+        if constexpr (u + PF < NTAP) {
           constexpr int PER = (2 * MT) / 4 > 0 ? (2 * MT) / 4 : 1;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -236,8 +261,8 @@ void wgrad_b16k_kernel(const WgradBArgs g) {
         }
         __builtin_amdgcn_sched_barrier(0);
       });
-      WGB_STEP_END(NV);
-      slot = slot == 2 ? 0 : slot + 1;
+      WGB_STEP_END((G::LA - 1) * NV);
+      slot = slot == G::RING - 1 ? 0 : slot + 1;
     }
     WGB_VM_WAIT(0);        // (the trailing zero-range requests)
   };
@@ -299,3 +324,42 @@ int tsr_wgrad_b16k(const void* a, int a_ctot, int a_coff, int cin, const void* d
   if (ks == 5) return big5 ? wgb_launch<5, 1, 128, 128, 64>(g, st) : wgb_launch<5, 2, 64, 64, 32>(g, st);
   return big3 ? wgb_launch<3, 3, 128, 64, 32>(g, st) : wgb_launch<3, 3, 64, 64, 32>(g, st);
 }
+
+// The stored input of a conv that follows a train-mode BatchNorm + ReLU is the pre-BatchNorm z (`virtual` activation:
+// relu(z * scale + shift), the transform fused into its consumers' staging).  The LDS-DMA kernels cannot transform while
+// staging, so their launches read this tensor's MATERIALISED form: out = bf16(relu(fp32(z) * scale + shift)), dense bf16
+// CB16 with C channels -- exactly the value wgrad_tr16_kernel<.., IO16> forms while staging.  One workgroup per (image,
+// 16-channel block) plane: a thread keeps one 8-channel half (its scale / shift in registers) and walks the plane's pixels.
+__global__ __launch_bounds__(256) void bn_relu_b16_kernel(const char* z, int z_blocks, int z_blk0, int cblocks, const float* scale,
+                                                          const float* shift, char* out, int HW) {
+  const int blk = blockIdx.x % cblocks, b = blockIdx.x / cblocks;
+  const int half = threadIdx.x & 1;
+  const f32x4 s0 = *(const f32x4*)(scale + blk * 16 + half * 8), s1 = *(const f32x4*)(scale + blk * 16 + half * 8 + 4);
+  const f32x4 t0 = *(const f32x4*)(shift + blk * 16 + half * 8), t1 = *(const f32x4*)(shift + blk * 16 + half * 8 + 4);
+  const char* zp = z + ((size_t)b * z_blocks + z_blk0 + blk) * HW * 32;
+  char* op = out + ((size_t)b * cblocks + blk) * HW * 32;
+  for (int c = threadIdx.x; c < 2 * HW; c += 256) {
+    const gb16x8 v = *(const gb16x8*)(zp + (size_t)c * 16);
+    gb16x8 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[i] = (__bf16)tsr_relu(fmaf((float)v[i], s0[i], t0[i]));
+      o[4 + i] = (__bf16)tsr_relu(fmaf((float)v[4 + i], s1[i], t1[i]));
+    }
+    *(gb16x8*)(op + (size_t)c * 16) = o;
+  }
+}
+
+extern "C" int tsr_bn_relu_b16(const void* z, int z_ctot, int z_coff, int C, const float* scale, const float* shift, void* out,
+                               int B, int HW, void* stream) {
+  if (!z || !scale || !shift || !out || B <= 0 || HW <= 0 || C <= 0 || (C & 15) || (z_ctot & 15) || (z_coff & 15) ||
+      z_coff + C > z_ctot || (long long)B * (C >> 4) > 0x7fffffffLL)
+    return TSR_ERR_ARG;
+  hipLaunchKernelGGL(bn_relu_b16_kernel, dim3(B * (C >> 4)), dim3(256), 0, (hipStream_t)stream, (const char*)z, z_ctot >> 4,
+                     z_coff >> 4, C >> 4, scale, shift, (char*)out, HW);
+  return tsr_check_launch();
+}
+
+// 1 if tsr_conv2d_wgrad_bf16s (planes = -1) runs a launch of this shape WITHOUT an input transform on this file's kernel: a
+// caller holding a virtual input may then materialise it once (tsr_bn_relu_b16) and pass it plain
+extern "C" int tsr_conv2d_wgrad_b16k(int cout, int cin, int ks) { return (ks == 3 || ks == 5) && (cout % 64) == 0 && (cin % 64) == 0; }

@@ -50,12 +50,13 @@ def _p(t):
 
 class Act:
     """A CB16 activation slice, optionally 'virtual': value = relu(buf*scale+shift)."""
-    __slots__ = ("buf", "ctot", "coff", "c", "scale", "shift", "xa", "xb", "amax")
+    __slots__ = ("buf", "ctot", "coff", "c", "scale", "shift", "xa", "xb", "amax", "mat")
 
     def __init__(self, buf, ctot, coff, c, scale=None, shift=None, xa=None, xb=None, amax=None):
         self.buf, self.ctot, self.coff, self.c = buf, ctot, coff, c
         self.scale, self.shift, self.xa, self.xb = scale, shift, xa, xb
         self.amax = amax     # fp16x3 only: 1-element device tensor holding max|buf| (of the raw stored values)
+        self.mat = None      # bf16 storage: the materialised relu(buf*scale+shift) once a kernel needed it plain
 
 
 def conv_ex(*, B, H, W, src: Act, w, cout, ks, out, out_ctot, out_coff, scale=None, shift=None, relu=0,
@@ -458,6 +459,14 @@ class TrainEngine:
     def _wgrad(self, c, a: Act, dz: Act, conv, grads, name, with_bias):
         w = conv.weight
         cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
+        if self.io16 and a.scale is not None and _lib.load().tsr_conv2d_wgrad_b16k(cout, cin, ks):
+            # the LDS-DMA weight-gradient kernel takes its operands as they are stored: a virtual input is materialised
+            # once (both convs of an MSRB stage share it)
+            if a.mat is None:
+                a.mat = torch.empty(c.B * a.c * c.HW, dtype=torch.bfloat16, device=w.device)
+                call("tsr_bn_relu_b16", ptr(a.buf), _I(a.ctot), _I(a.coff), _I(a.c), ptr(a.scale), ptr(a.shift), ptr(a.mat),
+                     _I(c.B), _I(c.HW), stream())
+            a = Act(a.mat, a.c, 0, a.c)
         if self.nsplit:       # 16-bit MFMA form: the library sizes the batch split for its tile shape
             ns = _lib.load().tsr_conv2d_wgrad_splits(cout, cin, ks, self.nsplit, c.B, c.H, c.W)
         else:

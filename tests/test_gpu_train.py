@@ -116,6 +116,18 @@ def test_conv2d_wgrad_bf16_storage(T, ks, cin, cout, B, H, W, affine, ns):
     e, eb = relerr(out, gw), relerr(outb, gb)
     print(f"[bf16 wgrad] k{ks} {cin}->{cout} B={B} {H}x{W} affine={affine} ns={ns}: dW {e:.1e}, db {eb:.1e}")
     assert e < 1e-5 and eb < 1e-5
+    if affine and T._lib.load().tsr_conv2d_wgrad_b16k(cout, cin, ks):
+        # what the train engine does with a virtual input: materialise it once (tsr_bn_relu_b16 -- bit-identical to
+        # bf16(relu(fma(z, scale, shift)))), then the launch without a transform (csrc/wgrad_b16k.hip)
+        mat = torch.full((B * cin * H * W,), float("nan"), dtype=torch.bfloat16, device="cuda")
+        call("tsr_bn_relu_b16", ptr(ad), I(cin + 16), I(16), I(cin), ptr(scd), ptr(shd), ptr(mat), I(B), I(H * W), stream())
+        assert torch.equal(T.from_cb16(mat, B, cin, H, W).float().cpu(), a)
+        slab.fill_(float("nan")); bslab.fill_(float("nan"))
+        call("tsr_conv2d_wgrad_bf16s", ptr(mat), I(cin), I(0), I(cin), None, None, ptr(dzd), I(cout + 32),
+             I(16), I(cout), I(ks), I(-1), None, None, ptr(slab), ptr(bslab), I(ns), I(B), I(H), I(W), stream())
+        call("tsr_reduce_splits", ptr(slab), ptr(out), L(n), I(ns), Fl(1.0), stream())
+        call("tsr_reduce_splits", ptr(bslab), ptr(outb), L(cout), I(ns), Fl(1.0), stream())
+        assert relerr(out, gw) < 1e-5 and relerr(outb, gb) < 1e-5
 
 
 @pytest.mark.parametrize("ks,cin,cout,B,H,W,NP", [(3, 64, 64, 3, 40, 40, 64), (5, 128, 128, 2, 16, 24, 64),
