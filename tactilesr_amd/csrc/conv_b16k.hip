@@ -86,7 +86,7 @@ template <int KS, int COUT, int NW> struct B16KGeom {
   static constexpr int LDS_B = HALO_B + RING * WTAP_B;
 };
 
-enum { B16K_PLAIN = 0, B16K_FUSED = 1, B16K_PAIR = 2, B16K_DGRAD = 3 };
+enum { B16K_PLAIN = 0, B16K_FUSED = 1, B16K_PAIR = 2, B16K_DGRAD = 3, B16K_TRAIN = 4 };
 
 
 // compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (the scheduling hints need constant operands)
@@ -357,6 +357,60 @@ __device__ __forceinline__ void b16k_epilogue_dgrad(const ConvArgs& a, f32x4 (&a
   }
 }
 
+// Training with bf16 activation storage, the FORWARD launches of the 128-channel 3x3 / 5x5 layers that feed a BatchNorm
+// (tsr_conv2d_ex, epi_mode 1; the input is a materialised activation -- tsr_bn_relu_b16 -- or a stored block output): out =
+// bf16(acc), the raw bias-free conv output, and the Welford partial (mean, M2) of the fp32 accumulators over this image's valid
+// pixels of the patch, per (workgroup, image, channel) into the slab, the count into slab_cnt (entry numbering as above).
+template <int MT>
+__device__ __forceinline__ void b16k_epilogue_train(const ConvArgs& a, f32x4 (&acc)[MT][4], int bid, int wm, int b, int y0, int x0,
+                                                    int m, int g, int HW) {
+  constexpr int NT = 4;
+  const bool img_ok = b < a.B;
+  const int bsafe = img_ok ? b : 0;
+  bool ok[NT];
+  unsigned po[NT];
+  float cnt = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int gy = y0 + 2 * nt + (m >> 3), gx = x0 + (m & 7);
+    ok[nt] = img_ok && gy < a.H && gx < a.W;
+    po[nt] = (ok[nt] ? (unsigned)(gy * a.W + gx) * 32u : 0u) + 8u * g;
+    cnt += ok[nt] ? 1.f : 0.f;
+  }
+  cnt = b16k_row_sum(cnt);
+  const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+  const unsigned plane = (unsigned)HW * 32u;
+  char* ob = (char*)a.out + ((size_t)bsafe * (a.out_ctot >> 4) + (a.out_coff >> 4)) * plane;
+  const size_t e = (size_t)bid * 4 + wm;
+  float* sl = a.slab + (e * 128 + 4 * g) * 2;
+  if (m == 0 && g == 0) a.slab_cnt[e] = cnt;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    f32x4 mean = {0.f, 0.f, 0.f, 0.f}, m2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) mean[c] += ok[nt] ? acc[mt][nt][c] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) mean[c] = b16k_row_sum(mean[c]) * inv;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float d = ok[nt] ? acc[mt][nt][c] - mean[c] : 0.f;
+        m2[c] = fmaf(d, d, m2[c]);
+      }
+      if (ok[nt]) *(kb16x4*)(ob + (mt * plane + po[nt])) = __builtin_convertvector(acc[mt][nt], kb16x4);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) m2[c] = b16k_row_sum(m2[c]);
+    if (m == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { sl[(mt * 16 + c) * 2] = mean[c]; sl[(mt * 16 + c) * 2 + 1] = m2[c]; }
+    }
+  }
+}
+
 // Halo-row requests of step t of a block (two slots; -1 = none): row r of the CURRENT block = r, of the NEXT block = 16 + r.
 // Constraints (checked by hand against the circular-buffer rule in the kernel): a slot is requested only after the step
 // whose tap last read its old row (old row q < KS-1 dies with kernel row q, the others with the block), at least two
@@ -412,7 +466,8 @@ template <int KS, int MODE> struct B16KSteps {
 
 template <int KS, int COUT, int MODE, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_b16k_kernel(const ConvArgs a) {
-  static_assert(MODE == B16K_PLAIN || (COUT == 128 && (MODE == B16K_FUSED || MODE == B16K_DGRAD || KS == 5)), "fused / pair / dgrad: 128 channels");
+  static_assert(MODE == B16K_PLAIN || (COUT == 128 && (MODE == B16K_FUSED || MODE == B16K_DGRAD || MODE == B16K_TRAIN || KS == 5)),
+                "fused / pair / dgrad / train: 128 channels");
   typedef B16KGeom<KS, COUT, NW> G;
   constexpr int P = KS / 2, HH = G::HH, T = G::T, MT = COUT / 16, NT = 4;
   constexpr int PIXB = G::PIXB, ROWB = G::ROWB, IMGB = G::IMGB, HALO_B = G::HALO_B, WTAP_B = G::WTAP_B;
@@ -620,6 +675,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_b16k_kernel(con
     b16k_epilogue_dgrad<MT>(a, acc, bid, wm, b0 + wm, y0, x0, m, g, HW);
     return;
   }
+  if constexpr (MODE == B16K_TRAIN) {
+    b16k_epilogue_train<MT>(a, acc, bid, wm, b0 + wm, y0, x0, m, g, HW);
+    return;
+  }
   // (fused form: the 1x1 weight's halves sit in the ring slots of the two requests past the stream's end, slabs S and S+1)
   b16k_epilogue<MT, MODE>(a, acc, b0 + wm, y0, x0, m, g, HW, wbuf + slot * WTAP_B, wbuf + (slot == 2 ? 0 : slot + 1) * WTAP_B);
 }
@@ -738,15 +797,21 @@ extern "C" int tsr_pack_conv_weight_dgrad_b16k(const float* w_oihw, void* w_pack
   return tsr_check_launch();
 }
 
-// tsr_conv2d_ex with nsplit = -3: a training launch on bf16 tensors whose input needs no transform (a stored gradient) -- the
-// masked dgrad (epi_mode 2) or the plain one (epi_mode 0: out = act(acc * scale + shift + res))
+// tsr_conv2d_ex with nsplit = -3: a training launch on bf16 tensors whose input needs no transform (a stored gradient, a
+// stored block output, a materialised activation): epi_mode 0 = out = act(acc * scale + shift + res) (the forward weight
+// pack, or the dgrad pack for an unmasked partial gradient), 1 = raw output + Welford partials (forward pack), 2 = the masked
+// dgrad (dgrad pack)
 int tsr_conv_b16k_ex(const ConvArgs& a, int cout, int ks, hipStream_t st) {
-  if (!tsr_conv2d_ex_dgrad_b16k(cout, a.cin, ks) || a.in_scale || a.res_scale || a.epi_mode == 1 ||
+  if (!tsr_conv2d_ex_dgrad_b16k(cout, a.cin, ks) || a.in_scale || a.res_scale ||
       (long long)4 * a.in_ctot * a.H * a.W * 2 >= 0x7fffffffLL)
     return TSR_ERR_ARG;
   if (a.epi_mode == 2) {
     if (ks == 3) B16K_LAUNCH(3, 128, B16K_DGRAD)
     else B16K_LAUNCH(5, 128, B16K_DGRAD)
+  } else if (a.epi_mode == 1) {
+    if (!a.slab || !a.slab_cnt) return TSR_ERR_ARG;
+    if (ks == 3) B16K_LAUNCH(3, 128, B16K_TRAIN)
+    else B16K_LAUNCH(5, 128, B16K_TRAIN)
   } else {
     if (ks == 3) B16K_LAUNCH(3, 128, B16K_PLAIN)
     else B16K_LAUNCH(5, 128, B16K_PLAIN)

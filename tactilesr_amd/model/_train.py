@@ -247,14 +247,40 @@ class TrainEngine:
         wa = c.wamax.get(id(conv))
         return _pack(w, w.shape[0], w.shape[1], w.shape[2], self.nsplit, wa), wa
 
+    def _plain(self, c, a: Act) -> Act:
+        """bf16 storage: `a` as a tensor the LDS-DMA kernels (conv_b16k / wgrad_b16k: operands go from HBM to LDS as stored)
+        can read -- a virtual activation relu(buf*scale+shift) is materialised ONCE (tsr_bn_relu_b16) and kept on the Act:
+        the forward convs of an MSRB's second stage and, in backward, their weight gradients all read the same tensor."""
+        if a.scale is None:
+            return a
+        if a.mat is None:
+            a.mat = torch.empty(c.B * a.c * c.HW, dtype=torch.bfloat16, device=a.buf.device)
+            call("tsr_bn_relu_b16", ptr(a.buf), _I(a.ctot), _I(a.coff), _I(a.c), ptr(a.scale), ptr(a.shift), ptr(a.mat),
+                 _I(c.B), _I(c.HW), stream())
+        return Act(a.mat, a.c, 0, a.c)
+
+    def _b16k(self, cout, cin, ks):
+        """bf16 storage: this forward conv shape runs csrc/conv_b16k.hip (tsr_conv2d_ex, nsplit = -3)."""
+        return self.io16 and bool(_lib.load().tsr_conv2d_ex_dgrad_b16k(cout, cin, ks))
+
+    def _packw_b16k(self, conv):
+        w = conv.weight.detach().contiguous()
+        cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
+        wp = torch.empty(_lib.load().tsr_conv_weight_b16k_elems(cout, cin, ks), dtype=torch.bfloat16, device=w.device)
+        call("tsr_pack_conv_weight_b16k", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), stream())
+        return wp
+
     def _conv_bn(self, c: _Ctx, src: Act, conv, bn, out, out_ctot, out_coff, out_amax=None):
         """conv (bias-free raw output) + batch statistics; returns the 4xC BN vectors."""
         w = conv.weight
         cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
-        wp, wis = self._packw(c, conv)
+        if self._b16k(cout, cin, ks):
+            src, wp, wis, ns = self._plain(c, src), self._packw_b16k(conv), None, -3
+        else:
+            (wp, wis), ns = self._packw(c, conv), self.nsplit
         with self._timed(("fwd", ks, cout, cin)):
             conv_ex(B=c.B, H=c.H, W=c.W, src=src, w=wp, cout=cout, ks=ks, out=out, out_ctot=out_ctot,
-                    out_coff=out_coff, epi_mode=1, slab=c.slab, slab_cnt=c.slab_cnt, nsplit=self.nsplit,
+                    out_coff=out_coff, epi_mode=1, slab=c.slab, slab_cnt=c.slab_cnt, nsplit=ns,
                     w_amax=wis, out_amax=out_amax)
         return self._bn_finalize(c, conv.bias, bn, c.slab, c.slab_cnt, self._entries(c, cout, ks), cout)
 
@@ -392,9 +418,12 @@ class TrainEngine:
             c.res.append(s)
         # ---- head
         c.h0 = buf(128)
-        wh, wish = self._packw(c, m.output_layer[0])
+        if self._b16k(128, 128, 3):
+            wh, wish, nsh = self._packw_b16k(m.output_layer[0]), None, -3
+        else:
+            (wh, wish), nsh = self._packw(c, m.output_layer[0]), self.nsplit
         conv_ex(B=B, H=H, W=W, src=Act(c.hcat, 128, 0, 128, amax=c.am_hcat), w=wh, cout=128, ks=3, out=c.h0,
-                out_ctot=128, out_coff=0, relu=1, nsplit=self.nsplit, w_amax=wish)
+                out_ctot=128, out_coff=0, relu=1, nsplit=nsh, w_amax=wish)
         out = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
         call("tsr_head_fwd_b16" if self.io16 else "tsr_head_fwd", ptr(c.h0), _I(128), _I(128),
              ptr(m.output_layer[2].weight.detach()), ptr(out), _I(1), _I(B), _I(H), _I(W), stream())
@@ -459,14 +488,8 @@ class TrainEngine:
     def _wgrad(self, c, a: Act, dz: Act, conv, grads, name, with_bias):
         w = conv.weight
         cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
-        if self.io16 and a.scale is not None and _lib.load().tsr_conv2d_wgrad_b16k(cout, cin, ks):
-            # the LDS-DMA weight-gradient kernel takes its operands as they are stored: a virtual input is materialised
-            # once (both convs of an MSRB stage share it)
-            if a.mat is None:
-                a.mat = torch.empty(c.B * a.c * c.HW, dtype=torch.bfloat16, device=w.device)
-                call("tsr_bn_relu_b16", ptr(a.buf), _I(a.ctot), _I(a.coff), _I(a.c), ptr(a.scale), ptr(a.shift), ptr(a.mat),
-                     _I(c.B), _I(c.HW), stream())
-            a = Act(a.mat, a.c, 0, a.c)
+        if self.io16 and _lib.load().tsr_conv2d_wgrad_b16k(cout, cin, ks):
+            a = self._plain(c, a)      # the LDS-DMA weight-gradient kernel takes its operands as they are stored
         if self.nsplit:       # 16-bit MFMA form: the library sizes the batch split for its tile shape
             ns = _lib.load().tsr_conv2d_wgrad_splits(cout, cin, ks, self.nsplit, c.B, c.H, c.W)
         else:

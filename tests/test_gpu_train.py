@@ -247,6 +247,50 @@ def test_conv2d_dgrad_bf16_storage_b16k(T, ks, cin, cout, B, H, W, res):
     assert not torch.isnan(gbuf.float()).any()
 
 
+@pytest.mark.parametrize("ks,cin,B,H,W", [(5, 128, 5, 16, 24), (3, 128, 2, 40, 40), (3, 256, 3, 13, 21), (5, 64, 1, 5, 3)])
+def test_conv2d_train_forward_bf16_storage_b16k(T, ks, cin, B, H, W):
+    """Training with bf16 activation storage: the forward launches of the 128-output-channel 3x3 / 5x5 layers that feed a
+    BatchNorm run csrc/conv_b16k.hip (tsr_conv2d_ex, nsplit = -3, epi_mode = 1; weights from tsr_pack_conv_weight_b16k) on a
+    plain (materialised) bf16 input.  Yardstick: the convolution in fp64 on the bf16-ROUNDED operands -- out = bf16 of it
+    (>= 99 % identical, the rest one ulp / the fp32-accumulation floor) and, merged over every slab entry (Chan), the
+    per-channel mean / biased variance of the UNROUNDED output within 1e-5 of the tensor's scale; counts sum to B*H*W."""
+    from tactilesr_amd.model._train import conv_ex, Act
+    from tactilesr_amd._lib import load, call, ptr, stream, c_int as I
+    g = torch.Generator().manual_seed(ks * 5 + cin + B + H)
+    cout = 128
+    q = lambda t: t.bfloat16().float()
+    x = q(torch.randn(B, cin, H, W, generator=g))
+    w = torch.randn(cout, cin, ks, ks, generator=g) * 0.05
+    lib = load()
+    assert lib.tsr_conv2d_ex_dgrad_b16k(cout, cin, ks) == 1
+    xd = T.to_cb16(x.cuda(), cin + 16, 16).to(torch.bfloat16)
+    wp = torch.empty(lib.tsr_conv_weight_b16k_elems(cout, cin, ks), dtype=torch.bfloat16, device="cuda")
+    call("tsr_pack_conv_weight_b16k", ptr(w.cuda().contiguous()), ptr(wp), I(cout), I(cin), I(ks), stream())
+    entries = lib.tsr_conv2d_slab_entries_ex(B, H, W, cout, ks, -1)
+    slab = torch.full((entries * cout * 2,), float("nan"), device="cuda")
+    cnt = torch.full((entries,), float("nan"), device="cuda")
+    out = torch.full((B * (cout + 32) * H * W,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    conv_ex(B=B, H=H, W=W, src=Act(xd, cin + 16, 16, cin), w=wp, cout=cout, ks=ks, out=out, out_ctot=cout + 32, out_coff=16,
+            epi_mode=1, slab=slab, slab_cnt=cnt, nsplit=-3)
+    ref = F.conv2d(x.double(), q(w).double(), padding=ks // 2)
+    r16 = ref.float().bfloat16().float()
+    got = T.from_cb16(out, B, cout + 32, H, W)[:, 16:16 + cout].float().cpu()
+    d = (got - r16).abs()
+    same = float((d == 0).float().mean())
+    bad = d > torch.maximum(1.01 * r16.abs() * 2.0 ** -7, torch.full_like(r16, 3e-6 * float(r16.abs().max())))
+    n_e = cnt.double().cpu()
+    sl = slab.view(entries, cout, 2).double().cpu()
+    N = float(n_e.sum())
+    mean = (sl[:, :, 0] * n_e[:, None]).sum(0) / N
+    m2 = (sl[:, :, 1] + n_e[:, None] * (sl[:, :, 0] - mean[None]) ** 2).sum(0)
+    rm, rv = ref.mean(dim=(0, 2, 3)), ref.var(dim=(0, 2, 3), unbiased=False)
+    e_m, e_v = float((mean - rm).abs().max() / ref.abs().max()), float((m2 / N - rv).abs().max() / rv.max())
+    print(f"[b16k train fwd] k{ks} {cin}->{cout} B={B} {H}x{W}: identical {same:.5f}, beyond one ulp {int(bad.sum())}, "
+          f"mean {e_m:.1e}, var {e_v:.1e}")
+    assert N == B * H * W and same >= 0.99 and not bad.any()
+    assert e_m < 1e-5 and e_v < 1e-5
+
+
 def _subs(t, k=512):
     t = t.detach().flatten()
     return t[:: max(1, t.numel() // k)].cpu().numpy()
