@@ -150,7 +150,10 @@ int tsr_pack_w2_b16k(const float* w2_64x128, void* w_packed, void* stream);
  * ks) accepts may be described with nsplit = -3 instead of -1: it then runs on the same kernel (epi_mode 2, or 0 for the
  * unmasked partial gradient; no input / residual transform), with its weight packed by tsr_pack_conv_weight_dgrad_b16k
  * (arguments as tsr_pack_conv_weight_dgrad_bf16s with nprime = 128; tsr_conv_weight_b16k_elems(128, cout, ks) elements).
- * Slab entries as for nsplit = -1. */
+ * Slab entries as for nsplit = -1.  The same nsplit = -3 runs the FORWARD launches of that shape class (C_out = 128, C_in a
+ * multiple of 32, 3x3 / 5x5, plain input) there too: epi_mode 1 (raw output + Welford partials; weights from
+ * tsr_pack_conv_weight_b16k) and epi_mode 0 with that pack; nsplit = -4 is epi_mode 1 of the stage-1 pair of an MSRB
+ * (conv_3_1 || conv_5_1 as one 5x5 launch with 128 output channels, weights from tsr_pack_conv_weight_b16k_pair). */
 int tsr_conv2d_ex_dgrad_b16k(int nprime, int cout, int ks);
 int tsr_pack_conv_weight_dgrad_b16k(const float* w_oihw, void* w_packed, int cout, int cin, int ks, int ci0, void* stream);
 long long tsr_conv_weight_b16k_pair_elems(int cin);
@@ -219,7 +222,7 @@ typedef struct tsr_conv_desc {
   const float* mask_scale; const float* mask_shift;
   const float* bn_a; const float* bn_b;
   float* slab; float* slab_cnt;
-  int nsplit;   /* -3: as -1 on csrc/conv_b16k.hip (dgrad launches, see tsr_conv2d_ex_dgrad_b16k); -1: plain bf16 operands AND bf16 CB16 tensors (in / res / mask / out address bf16 elements; w_packed as
+  int nsplit;   /* -3 / -4: as -1 on csrc/conv_b16k.hip (see tsr_conv2d_ex_dgrad_b16k); -1: plain bf16 operands AND bf16 CB16 tensors (in / res / mask / out address bf16 elements; w_packed as
                    for 1): the train step with bf16 activation storage;
                    0: fp32 MFMA, w_packed from tsr_pack_conv_weight[_dgrad]; 1..3: split-bf16 MFMA (3 = fp32-equivalent),
                    w_packed from tsr_pack_conv_weight[_dgrad]_bf16s; -2: fp16 two-plane split ("fp16x3"), w_packed from

@@ -86,7 +86,8 @@ template <int KS, int COUT, int NW> struct B16KGeom {
   static constexpr int LDS_B = HALO_B + RING * WTAP_B;
 };
 
-enum { B16K_PLAIN = 0, B16K_FUSED = 1, B16K_PAIR = 2, B16K_DGRAD = 3, B16K_TRAIN = 4 };
+enum { B16K_PLAIN = 0, B16K_FUSED = 1, B16K_PAIR = 2, B16K_DGRAD = 3, B16K_TRAIN = 4, B16K_PAIR_TRAIN = 5 };
+constexpr bool b16k_pair(int mode) { return mode == B16K_PAIR || mode == B16K_PAIR_TRAIN; }
 
 
 // compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1 (the scheduling hints need constant operands)
@@ -99,7 +100,7 @@ template <int I, int N, class F> __device__ __forceinline__ void b16k_static_for
 // pair form: first C_out tile with work at tap t (the 3x3 conv, tiles 0..3, has no weight outside the inner 3x3 taps)
 template <int KS, int MODE, int MT> constexpr int b16k_tap_rows(int t) {
   const int kh = t / KS, kw = t - kh * KS;
-  return (MODE != B16K_PAIR || (kh >= 1 && kh <= 3 && kw >= 1 && kw <= 3)) ? 0 : MT / 2;
+  return (!b16k_pair(MODE) || (kh >= 1 && kh <= 3 && kw >= 1 && kw <= 3)) ? 0 : MT / 2;
 }
 
 typedef float kf32x8 __attribute__((ext_vector_type(8)));
@@ -449,7 +450,7 @@ template <> struct B16KJobs<3> {       // HH = 10: next rows 0..5 -> never-used 
 template <int KS, int MODE> struct B16KSteps {
   static constexpr int T = KS * KS;
   struct Tab { int n = 0; int first[T] = {}; int ntap[T] = {}; int step_of[T] = {}; };
-  static constexpr bool outer(int t) { return MODE == B16K_PAIR && b16k_tap_rows<KS, MODE, 8>(t) != 0; }
+  static constexpr bool outer(int t) { return b16k_pair(MODE) && b16k_tap_rows<KS, MODE, 8>(t) != 0; }
   static constexpr Tab make() {
     Tab tb;
     int t = 0;
@@ -466,7 +467,7 @@ template <int KS, int MODE> struct B16KSteps {
 
 template <int KS, int COUT, int MODE, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_b16k_kernel(const ConvArgs a) {
-  static_assert(MODE == B16K_PLAIN || (COUT == 128 && (MODE == B16K_FUSED || MODE == B16K_DGRAD || MODE == B16K_TRAIN || KS == 5)),
+  static_assert(MODE == B16K_PLAIN || (COUT == 128 && (MODE == B16K_FUSED || MODE == B16K_DGRAD || MODE == B16K_TRAIN || (b16k_pair(MODE) && KS == 5))),
                 "fused / pair / dgrad / train: 128 channels");
   typedef B16KGeom<KS, COUT, NW> G;
   constexpr int P = KS / 2, HH = G::HH, T = G::T, MT = COUT / 16, NT = 4;
@@ -675,7 +676,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_b16k_kernel(con
     b16k_epilogue_dgrad<MT>(a, acc, bid, wm, b0 + wm, y0, x0, m, g, HW);
     return;
   }
-  if constexpr (MODE == B16K_TRAIN) {
+  if constexpr (MODE == B16K_TRAIN || MODE == B16K_PAIR_TRAIN) {      // (pair: tsr_conv2d_ex, nsplit = -4)
     b16k_epilogue_train<MT>(a, acc, bid, wm, b0 + wm, y0, x0, m, g, HW);
     return;
   }
@@ -800,11 +801,16 @@ extern "C" int tsr_pack_conv_weight_dgrad_b16k(const float* w_oihw, void* w_pack
 // tsr_conv2d_ex with nsplit = -3: a training launch on bf16 tensors whose input needs no transform (a stored gradient, a
 // stored block output, a materialised activation): epi_mode 0 = out = act(acc * scale + shift + res) (the forward weight
 // pack, or the dgrad pack for an unmasked partial gradient), 1 = raw output + Welford partials (forward pack), 2 = the masked
-// dgrad (dgrad pack)
-int tsr_conv_b16k_ex(const ConvArgs& a, int cout, int ks, hipStream_t st) {
+// dgrad (dgrad pack).  nsplit = -4 (`pair`): epi_mode 1 of the stage-1 pair (one 128-channel output, two convs).
+int tsr_conv_b16k_ex(const ConvArgs& a, int cout, int ks, bool pair, hipStream_t st) {
   if (!tsr_conv2d_ex_dgrad_b16k(cout, a.cin, ks) || a.in_scale || a.res_scale ||
       (long long)4 * a.in_ctot * a.H * a.W * 2 >= 0x7fffffffLL)
     return TSR_ERR_ARG;
+  if (pair) {      // nsplit = -4: conv_3_1 || conv_5_1 of an MSRB in train mode (weights: tsr_pack_conv_weight_b16k_pair)
+    if (ks != 5 || a.epi_mode != 1 || !a.slab || !a.slab_cnt) return TSR_ERR_ARG;
+    B16K_LAUNCH(5, 128, B16K_PAIR_TRAIN)
+    return tsr_check_launch();
+  }
   if (a.epi_mode == 2) {
     if (ks == 3) B16K_LAUNCH(3, 128, B16K_DGRAD)
     else B16K_LAUNCH(5, 128, B16K_DGRAD)

@@ -337,7 +337,7 @@ extern "C" int tsr_conv2d_ex(const tsr_conv_desc* d, void* stream) {
   a.mask_scale = d->mask_scale; a.mask_shift = d->mask_shift;
   a.bn_a = d->bn_a; a.bn_b = d->bn_b;
   a.slab = d->slab; a.slab_cnt = d->slab_cnt;
-  if (d->nsplit != -3 && d->nsplit != -2 && d->nsplit != -1 && (d->nsplit < 0 || d->nsplit > 3)) return TSR_ERR_ARG;
+  if (d->nsplit < -4 || d->nsplit > 3) return TSR_ERR_ARG;
   a.in_amax = d->in_amax; a.w_inv_scale = d->w_inv_scale; a.out_amax = d->out_amax; a.w_amax = d->w_amax;
   if (d->nsplit == -2 && (!d->in_amax || (!d->w_amax && !(d->w_inv_scale > 0.f)))) return TSR_ERR_ARG;
   if (d->nsplit != 0) return tsr_conv2d_ex_bf16s(a, d->cout, d->ks, d->nsplit, (hipStream_t)stream);

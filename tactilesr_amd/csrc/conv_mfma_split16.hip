@@ -784,7 +784,7 @@ static int launch_b16_ex(const ConvArgs& a, hipStream_t st) {
   return tsr_check_launch();
 }
 
-int tsr_conv_b16k_ex(const ConvArgs& a, int cout, int ks, hipStream_t st);       // conv_b16k.hip
+int tsr_conv_b16k_ex(const ConvArgs& a, int cout, int ks, bool pair, hipStream_t st);       // conv_b16k.hip
 static int dispatch_b16_ex(const ConvArgs& a, int cout, int ks, hipStream_t st) {
   if (cout == 64) {
     if (ks == 1) return launch_b16_ex<1, 64>(a, st);
@@ -800,7 +800,7 @@ static int dispatch_b16_ex(const ConvArgs& a, int cout, int ks, hipStream_t st) 
 
 // tsr_conv2d_ex with nsplit != 0 lands here (argument checks were done by the caller)
 int tsr_conv2d_ex_bf16s(const ConvArgs& a, int cout, int ks, int nsplit, hipStream_t st) {
-  if (nsplit == -3) return tsr_conv_b16k_ex(a, cout, ks, st);                   // bf16 storage, conv_b16k.hip (dgrad launches)
+  if (nsplit == -3 || nsplit == -4) return tsr_conv_b16k_ex(a, cout, ks, nsplit == -4, st);   // bf16 storage, conv_b16k.hip
   if (nsplit == -1) return dispatch_b16_ex(a, cout, ks, st);                    // bf16 storage + bf16 operands
   if (nsplit == -2) return dispatch_bf16s<2, true, true>(a, cout, ks, st);      // fp16x3
   if (nsplit == 3) return dispatch_bf16s<3, true>(a, cout, ks, st);

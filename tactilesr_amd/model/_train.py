@@ -270,6 +270,33 @@ class TrainEngine:
         call("tsr_pack_conv_weight_b16k", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), stream())
         return wp
 
+    def _pair_bn(self, c: _Ctx, X: Act, blk, cat1):
+        """bf16 storage: conv_3_1 || conv_5_1 of an MSRB (reference model/tactileSR_model.py:198-200) as ONE 5x5 launch with
+        128 output channels on conv_b16k (tsr_conv2d_ex, nsplit = -4: the 3x3 weight sits in the inner taps of its half) and
+        ONE statistics pass over the 128 channels; returns the 4x128 BN vectors [conv_3_1 | conv_5_1]."""
+        c3, b3, c5, b5 = blk.conv_3_1[0], blk.conv_3_1[1], blk.conv_5_1[0], blk.conv_5_1[1]
+        if b3.momentum != b5.momentum or b3.eps != b5.eps or (c3.bias is None) != (c5.bias is None):
+            raise _lib.TactileSRHipError("stage-1 pair: the two conv + BatchNorm layers differ in momentum / eps / bias")
+        cin = c3.weight.shape[1]
+        w = torch.cat([torch.nn.functional.pad(c3.weight.detach(), (1, 1, 1, 1)), c5.weight.detach()], 0).contiguous()
+        wp = torch.empty(_lib.load().tsr_conv_weight_b16k_pair_elems(cin), dtype=torch.bfloat16, device=w.device)
+        call("tsr_pack_conv_weight_b16k_pair", ptr(w), ptr(wp), _I(cin), stream())
+        with self._timed(("fwd", 5, 128, cin)):
+            conv_ex(B=c.B, H=c.H, W=c.W, src=self._plain(c, X), w=wp, cout=128, ks=5, out=cat1, out_ctot=128, out_coff=0,
+                    epi_mode=1, slab=c.slab, slab_cnt=c.slab_cnt, nsplit=-4)
+        cat = lambda a, b: torch.cat([a.detach(), b.detach()])
+        vec = torch.empty(4, 128, dtype=torch.float32, device=w.device)
+        rm, rv = cat(b3.running_mean, b5.running_mean), cat(b3.running_var, b5.running_var)
+        bias = cat(c3.bias, c5.bias) if c3.bias is not None else None
+        gamma, beta = cat(b3.weight, b5.weight), cat(b3.bias, b5.bias)     # (named: a temporary's block would be reused)
+        call("tsr_bn_stats_finalize", ptr(c.slab), ptr(c.slab_cnt), _I(self._entries(c, 128, 5)), _I(128), ptr(bias),
+             ptr(gamma), ptr(beta), ptr(rm), ptr(rv), _F(b3.momentum), _F(b3.eps),
+             ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), ptr(c.work), stream())
+        b3.running_mean.copy_(rm[:64]); b5.running_mean.copy_(rm[64:])
+        b3.running_var.copy_(rv[:64]); b5.running_var.copy_(rv[64:])
+        b3.num_batches_tracked.add_(1); b5.num_batches_tracked.add_(1)
+        return vec
+
     def _conv_bn(self, c: _Ctx, src: Act, conv, bn, out, out_ctot, out_coff, out_amax=None):
         """conv (bias-free raw output) + batch statistics; returns the 4xC BN vectors."""
         w = conv.weight
@@ -312,8 +339,11 @@ class TrainEngine:
         s.bn_c1 = torch.empty(4, 128, dtype=torch.float32, device=dev)
         s.bn_c2 = torch.empty(4, 256, dtype=torch.float32, device=dev)
         am_c1, am_c2 = new_amax(), new_amax()
-        s.bn_c1[:, 0:64] = self._conv_bn(c, X, blk.conv_3_1[0], blk.conv_3_1[1], s.cat1, 128, 0, am_c1)
-        s.bn_c1[:, 64:128] = self._conv_bn(c, X, blk.conv_5_1[0], blk.conv_5_1[1], s.cat1, 128, 64, am_c1)
+        if self._b16k(128, X.c, 5) and blk.conv_3_1[0].weight.shape[0] == 64:
+            s.bn_c1[:] = self._pair_bn(c, X, blk, s.cat1)
+        else:
+            s.bn_c1[:, 0:64] = self._conv_bn(c, X, blk.conv_3_1[0], blk.conv_3_1[1], s.cat1, 128, 0, am_c1)
+            s.bn_c1[:, 64:128] = self._conv_bn(c, X, blk.conv_5_1[0], blk.conv_5_1[1], s.cat1, 128, 64, am_c1)
         A1 = Act(s.cat1, 128, 0, 128, s.bn_c1[0], s.bn_c1[1], s.bn_c1[2], s.bn_c1[3], amax=am_c1)
         s.bn_c2[:, 0:128] = self._conv_bn(c, A1, blk.conv_3_2[0], blk.conv_3_2[1], s.cat2, 256, 0, am_c2)
         s.bn_c2[:, 128:256] = self._conv_bn(c, A1, blk.conv_5_2[0], blk.conv_5_2[1], s.cat2, 256, 128, am_c2)

@@ -291,6 +291,47 @@ def test_conv2d_train_forward_bf16_storage_b16k(T, ks, cin, B, H, W):
     assert e_m < 1e-5 and e_v < 1e-5
 
 
+@pytest.mark.parametrize("cin,B,H,W", [(64, 5, 16, 24), (64, 2, 40, 40), (96, 3, 13, 21)])
+def test_conv2d_train_forward_pair_bf16_storage_b16k(T, cin, B, H, W):
+    """The stage-1 pair of an MSRB in train mode with bf16 storage (tsr_conv2d_ex, nsplit = -4): conv_3_1 || conv_5_1 as one
+    launch -- channels 0..63 = the 3x3 conv, 64..127 = the 5x5 conv of the same input, raw bf16 output + Welford partials.
+    Yardstick as test_conv2d_train_forward_bf16_storage_b16k, each half against its own fp64 convolution."""
+    from tactilesr_amd.model._train import conv_ex, Act
+    from tactilesr_amd._lib import load, call, ptr, stream, c_int as I
+    g = torch.Generator().manual_seed(cin + B + H)
+    q = lambda t: t.bfloat16().float()
+    x = q(torch.randn(B, cin, H, W, generator=g))
+    w3, w5 = torch.randn(64, cin, 3, 3, generator=g) * 0.08, torch.randn(64, cin, 5, 5, generator=g) * 0.05
+    lib = load()
+    xd = T.to_cb16(x.cuda()).to(torch.bfloat16)
+    w = torch.cat([F.pad(w3, (1, 1, 1, 1)), w5], 0).cuda().contiguous()
+    wp = torch.empty(lib.tsr_conv_weight_b16k_pair_elems(cin), dtype=torch.bfloat16, device="cuda")
+    call("tsr_pack_conv_weight_b16k_pair", ptr(w), ptr(wp), I(cin), stream())
+    entries = lib.tsr_conv2d_slab_entries_ex(B, H, W, 128, 5, -1)
+    slab = torch.full((entries * 128 * 2,), float("nan"), device="cuda")
+    cnt = torch.full((entries,), float("nan"), device="cuda")
+    out = torch.full((B * 128 * H * W,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    conv_ex(B=B, H=H, W=W, src=Act(xd, cin, 0, cin), w=wp, cout=128, ks=5, out=out, out_ctot=128, out_coff=0,
+            epi_mode=1, slab=slab, slab_cnt=cnt, nsplit=-4)
+    ref = torch.cat([F.conv2d(x.double(), q(w3).double(), padding=1), F.conv2d(x.double(), q(w5).double(), padding=2)], 1)
+    r16 = ref.float().bfloat16().float()
+    got = T.from_cb16(out, B, 128, H, W).float().cpu()
+    d = (got - r16).abs()
+    same = float((d == 0).float().mean())
+    bad = d > torch.maximum(1.01 * r16.abs() * 2.0 ** -7, torch.full_like(r16, 3e-6 * float(r16.abs().max())))
+    n_e = cnt.double().cpu()
+    sl = slab.view(entries, 128, 2).double().cpu()
+    N = float(n_e.sum())
+    mean = (sl[:, :, 0] * n_e[:, None]).sum(0) / N
+    m2 = (sl[:, :, 1] + n_e[:, None] * (sl[:, :, 0] - mean[None]) ** 2).sum(0)
+    rm, rv = ref.mean(dim=(0, 2, 3)), ref.var(dim=(0, 2, 3), unbiased=False)
+    e_m, e_v = float((mean - rm).abs().max() / ref.abs().max()), float(((m2 / N - rv).abs() / rv).max())
+    print(f"[b16k train pair] {cin}->64|64 B={B} {H}x{W}: identical {same:.5f}, beyond one ulp {int(bad.sum())}, "
+          f"mean {e_m:.1e}, var {e_v:.1e}")
+    assert N == B * H * W and same >= 0.99 and not bad.any()
+    assert e_m < 1e-5 and e_v < 1e-5
+
+
 def _subs(t, k=512):
     t = t.detach().flatten()
     return t[:: max(1, t.numel() // k)].cpu().numpy()
