@@ -449,6 +449,7 @@ def run_train(args, world, rank, dev):
         cv_alg = wg_flop / (cv_ms * 1e-3) if cv else None
         wname = ("wgrad_mfma_f32_kernel<5" if impl == "f32" else
                  "wgrad_k32_kernel<5, 1, 128, 128" if impl == "fp16x3" else
+                 "wgrad_b16k_kernel<5, 1, 128, 128" if impl == "bf16" else     # (bf16 tensors: csrc/wgrad_b16k.hip)
                  "wgrad_tr16_kernel<5, 1, 128, 128")
         traffic, traffic_src = pmc_traffic(wname, "trainbf16" if impl == "bf16" else "train") if B == 2048 and not args.seqs else (None, None)
         res = {
