@@ -150,7 +150,9 @@ int tsr_pack_w2_b16k(const float* w2_64x128, void* w_packed, void* stream);
  * ks) accepts may be described with nsplit = -3 instead of -1: it then runs on the same kernel (epi_mode 2, or 0 for the
  * unmasked partial gradient; no input / residual transform), with its weight packed by tsr_pack_conv_weight_dgrad_b16k
  * (arguments as tsr_pack_conv_weight_dgrad_bf16s with nprime = 128; tsr_conv_weight_b16k_elems(128, cout, ks) elements).
- * Slab entries as for nsplit = -1.  The same nsplit = -3 runs the FORWARD launches of that shape class (C_out = 128, C_in a
+ * Slab entries as for nsplit = -1 (tsr_conv2d_slab_entries_ex accepts -3 / -4).  The predicate also accepts (128, 64, 1): the
+ * masked dgrad of a 1x1 conv with 64 output channels (epi_mode 2, no partial gradient) as a streaming kernel without LDS
+ * (csrc/conv1x1_b16k.hip; one slab entry per workgroup: ask tsr_conv2d_slab_entries_ex with nsplit = -3).  The same nsplit = -3 runs the FORWARD launches of that shape class (C_out = 128, C_in a
  * multiple of 32, 3x3 / 5x5, plain input) there too: epi_mode 1 (raw output + Welford partials; weights from
  * tsr_pack_conv_weight_b16k) and epi_mode 0 with that pack; nsplit = -4 is epi_mode 1 of the stage-1 pair of an MSRB
  * (conv_3_1 || conv_5_1 as one 5x5 launch with 128 output channels, weights from tsr_pack_conv_weight_b16k_pair). */

@@ -784,8 +784,10 @@ extern "C" int tsr_pack_conv_weight_b16k_pair(const float* w128_oihw5, void* w_p
 }
 
 // 1 if tsr_conv2d_ex accepts nsplit = -3 for a dgrad launch of this shape (bf16 tensors, conv_b16k, weights from
-// tsr_pack_conv_weight_dgrad_b16k): 128 input channels per launch, 3x3 / 5x5, the forward conv's C_out a multiple of 32
+// tsr_pack_conv_weight_dgrad_b16k): 128 input channels per launch, 3x3 / 5x5, the forward conv's C_out a multiple of 32;
+// or 1x1 with the forward conv's C_out = 64 (masked form only: epi_mode 2, no partial gradient)
 extern "C" int tsr_conv2d_ex_dgrad_b16k(int nprime, int cout_f, int ks) {
+  if (ks == 1) return nprime == 128 && cout_f == 64;        // the masked dgrad of a 1x1 conv (conv1x1_b16k.hip)
   return nprime == 128 && (ks == 3 || ks == 5) && cout_f > 0 && (cout_f & 31) == 0;
 }
 
@@ -802,10 +804,12 @@ extern "C" int tsr_pack_conv_weight_dgrad_b16k(const float* w_oihw, void* w_pack
 // stored block output, a materialised activation): epi_mode 0 = out = act(acc * scale + shift + res) (the forward weight
 // pack, or the dgrad pack for an unmasked partial gradient), 1 = raw output + Welford partials (forward pack), 2 = the masked
 // dgrad (dgrad pack).  nsplit = -4 (`pair`): epi_mode 1 of the stage-1 pair (one 128-channel output, two convs).
+int tsr_dgrad1x1_b16k(const ConvArgs& a, hipStream_t st);       // conv1x1_b16k.hip
 int tsr_conv_b16k_ex(const ConvArgs& a, int cout, int ks, bool pair, hipStream_t st) {
   if (!tsr_conv2d_ex_dgrad_b16k(cout, a.cin, ks) || a.in_scale || a.res_scale ||
       (long long)4 * a.in_ctot * a.H * a.W * 2 >= 0x7fffffffLL)
     return TSR_ERR_ARG;
+  if (ks == 1) return pair ? TSR_ERR_ARG : tsr_dgrad1x1_b16k(a, st);
   if (pair) {      // nsplit = -4: conv_3_1 || conv_5_1 of an MSRB in train mode (weights: tsr_pack_conv_weight_b16k_pair)
     if (ks != 5 || a.epi_mode != 1 || !a.slab || !a.slab_cnt) return TSR_ERR_ARG;
     B16K_LAUNCH(5, 128, B16K_PAIR_TRAIN)

@@ -304,7 +304,10 @@ extern "C" int tsr_conv2d_slab_entries(int B, int H, int W) {
 // Slab entries a tsr_conv2d_ex launch with these parameters writes: one per (workgroup, image slot).  The fp16-split
 // 3x3 / 5x5 kernels (tsr_conv_f16s_images: 4 images, 2 for the 1x1 and TSR_CONV_K32_256) and every one-plane 3x3 / 5x5 kernel put 4 images in a
 // workgroup, everything else 2 (must match launch_bf16s in conv_mfma_split16.hip).
+int tsr_dgrad1x1_b16k_grid(int B, int H, int W);           // conv1x1_b16k.hip
 extern "C" int tsr_conv2d_slab_entries_ex(int B, int H, int W, int cout, int ks, int nsplit) {
+  if (nsplit == -3 && ks == 1) return tsr_dgrad1x1_b16k_grid(B, H, W);        // one entry per workgroup of the streaming kernel
+  if (nsplit == -3 || nsplit == -4) nsplit = -1;
   const int img = nsplit == -2 ? tsr_conv_f16s_images(cout, ks) : ((ks > 1 && (nsplit == 1 || nsplit == -1)) ? 4 : 2);
   return ((B + img - 1) / img) * ((W + 7) / 8) * ((H + 7) / 8) * img;
 }

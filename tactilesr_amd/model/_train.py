@@ -237,9 +237,9 @@ class TrainEngine:
             call("tsr_stem_fwd", ptr(x), _I(ctot_in), _I(coff), _I(A), _I(hin), _I(win), _I(sf), ptr(w), ptr(None),
                  ptr(None), ptr(dst), _I(64), _I(0), _I(relu), _I(B), ptr(am), stream())
 
-    def _entries(self, c, cout, ks):
-        """Statistics-slab entries the conv launch (cout, ks) of this engine's arithmetic writes."""
-        return _lib.load().tsr_conv2d_slab_entries_ex(c.B, c.H, c.W, cout, ks, self.nsplit)
+    def _entries(self, c, cout, ks, nsplit=None):
+        """Statistics-slab entries the conv launch (cout, ks) of this engine's arithmetic (or of the form `nsplit`) writes."""
+        return _lib.load().tsr_conv2d_slab_entries_ex(c.B, c.H, c.W, cout, ks, self.nsplit if nsplit is None else nsplit)
 
     def _packw(self, c, conv):
         """(packed weight, device scalar max|w| or None)"""
@@ -261,7 +261,7 @@ class TrainEngine:
 
     def _b16k(self, cout, cin, ks):
         """bf16 storage: this forward conv shape runs csrc/conv_b16k.hip (tsr_conv2d_ex, nsplit = -3)."""
-        return self.io16 and bool(_lib.load().tsr_conv2d_ex_dgrad_b16k(cout, cin, ks))
+        return self.io16 and ks > 1 and bool(_lib.load().tsr_conv2d_ex_dgrad_b16k(cout, cin, ks))
 
     def _packw_b16k(self, conv):
         w = conv.weight.detach().contiguous()
@@ -324,6 +324,8 @@ class TrainEngine:
         # kernel variant of (C_out, k, arithmetic) puts in a workgroup -- ask the library for every shape in use
         e64 = max(lib.tsr_conv2d_slab_entries_ex(B, H, W, 64, k, self.nsplit) for k in (1, 3, 5))
         e128 = max(c.entries, max(lib.tsr_conv2d_slab_entries_ex(B, H, W, 128, k, self.nsplit) for k in (1, 3, 5)))
+        if self.io16:
+            e128 = max(e128, lib.tsr_conv2d_slab_entries_ex(B, H, W, 128, 1, -3))
         c.slab = torch.empty(max(e128 * 128 * 2, e64 * 64 * 2, st_entries * 64 * 2), dtype=torch.float32, device=dev)
         c.slab_cnt = torch.empty(max(e128, e64, st_entries), dtype=torch.float32, device=dev)
         c.work = torch.empty(512 * 128 * 3, dtype=torch.float64, device=dev)
@@ -553,7 +555,7 @@ class TrainEngine:
         # bf16 storage: the 128-channel 3x3 / 5x5 dgrads (masked or not) run conv_b16k (nsplit -3; same tensors, its own pack)
         ns = self.nsplit
         if self.io16 and dz.scale is None and (res is None or res.scale is None) and \
-                _lib.load().tsr_conv2d_ex_dgrad_b16k(nprime, cout, ks):
+                (ks > 1 or (mask is not None and res is None)) and _lib.load().tsr_conv2d_ex_dgrad_b16k(nprime, cout, ks):
             ns = -3
         wp = _pack_dgrad(w, cout, cin, ks, ci0, nprime, ns, wa)
         with self._timed(("dgrad", ks, nprime, cout)):
@@ -561,7 +563,7 @@ class TrainEngine:
                     out_coff=out_coff, res=res, epi_mode=2 if mask is not None else 0, mask=mask, bn=bn,
                     slab=c.slab if bn else None, slab_cnt=None, nsplit=ns, w_amax=wa,
                     out_amax=out_amax)
-        c.last_entries = self._entries(c, nprime, ks)      # what a following _bn_bwd reduces
+        c.last_entries = self._entries(c, nprime, ks, ns)      # what a following _bn_bwd reduces
 
     def _bn_bwd(self, c, g_buf, g_ctot, g_coff, z: Act, zoff, C, bn_vec, bn_mod, grads, name, out_amax=None):
         """Finish BatchNorm backward for C channels whose masked gradient g sits in g_buf (slab sums

@@ -184,10 +184,13 @@ def test_conv2d_dgrad_with_mask_and_bn_sums(T, ks, cin, cout, B, H, W, NP):
 
 
 @pytest.mark.parametrize("ks,cin,cout,B,H,W,res", [(5, 128, 128, 5, 16, 24, True), (3, 128, 128, 1, 40, 40, True),
-                                                    (3, 256, 64, 3, 13, 21, False), (5, 128, 96, 2, 40, 40, True)])
+                                                    (3, 256, 64, 3, 13, 21, False), (5, 128, 96, 2, 40, 40, True),
+                                                    (1, 256, 64, 3, 13, 21, False), (1, 256, 64, 2, 40, 40, False),
+                                                    (1, 128, 64, 70, 12, 12, False)])
 def test_conv2d_dgrad_bf16_storage_b16k(T, ks, cin, cout, B, H, W, res):
     """Training with bf16 activation storage: the dgrad launches of the 128-input-channel 3x3 / 5x5 layers run
-    csrc/conv_b16k.hip (tsr_conv2d_ex, nsplit = -3, epi_mode = 2; weights from tsr_pack_conv_weight_dgrad_b16k).  Yardstick:
+    csrc/conv_b16k.hip (tsr_conv2d_ex, nsplit = -3, epi_mode = 2; weights from tsr_pack_conv_weight_dgrad_b16k), the masked
+    dgrad of the 1x1 `confusion` (64 output channels) the streaming kernel of csrc/conv1x1_b16k.hip.  Yardstick:
     the same arithmetic in fp64 on the bf16-ROUNDED operands (dz, weights, stored activation, partial gradient) -- out = bf16 of
     (conv_transpose(dz, w) + res) where the stored activation's BatchNorm + ReLU was on: >= 99 % of the elements identical, the
     rest within one bf16 ulp (+ the fp32-accumulation floor next to zero); BatchNorm-backward sums sum(x), sum(x * xhat)
@@ -207,7 +210,7 @@ def test_conv2d_dgrad_bf16_storage_b16k(T, ks, cin, cout, B, H, W, res):
     to16 = lambda t, ctot=None, coff=0: T.to_cb16(t.cuda(), ctot, coff).to(torch.bfloat16)
     dyd, zd, exd = to16(dy), to16(z), to16(extra)
     gbuf = torch.full((B * cin * H * W,), float("nan"), dtype=torch.bfloat16, device="cuda")
-    entries = lib.tsr_conv2d_slab_entries_ex(B, H, W, NP, ks, -1)
+    entries = lib.tsr_conv2d_slab_entries_ex(B, H, W, NP, ks, -3)
     wd = w.cuda().contiguous()
     full = F.conv_transpose2d(dy.double(), q(w).double(), padding=ks // 2)
     for o in range(0, cin, NP):
@@ -219,7 +222,7 @@ def test_conv2d_dgrad_bf16_storage_b16k(T, ks, cin, cout, B, H, W, res):
                  bb[sl].cuda().contiguous())
         conv_ex(B=B, H=H, W=W, src=Act(dyd, cout, 0, cout), w=wp, cout=NP, ks=ks, out=gbuf, out_ctot=cin, out_coff=o,
                 res=Act(exd, cin, o, NP) if res else None, epi_mode=2, mask=mk, bn=True, slab=slab, nsplit=-3)
-        if o == 0:          # the unmasked form (the first half of a two-conv gradient): out = bf16(conv_transpose(dz, w))
+        if o == 0 and ks > 1:   # the unmasked form (the first half of a two-conv gradient): out = bf16(conv_transpose(dz, w))
             g0 = torch.full((B * NP * H * W,), float("nan"), dtype=torch.bfloat16, device="cuda")
             conv_ex(B=B, H=H, W=W, src=Act(dyd, cout, 0, cout), w=wp, cout=NP, ks=ks, out=g0, out_ctot=NP, out_coff=0, nsplit=-3)
             r0 = full[:, sl].float().bfloat16().float()
