@@ -333,11 +333,116 @@ extern "C" int tsr_head_fwd(const float* in, int in_ctot, int cin, const float* 
   return head_launch<false>(in, in_ctot, cin, w_oihw, out_nchw, relu, B, H, W, stream);
 }
 
+// Head on a bf16 CB16 input as a matrix product (bf16 activation storage; cin = 64 / 128).  The LDS-tiled kernel above moves
+// 1.2 TB/s on bf16 tensors: 8 barriers per 8x8 patch, a 10x10 halo per patch (1.56x the bytes through L2), 8-B loads.  Here
+//   D[tap][pixel] = sum_c w[c][tap] * h0[c][pixel]      (v_mfma_f32_16x16x32_bf16, channels as K, the 9 taps as rows)
+// is formed for every pixel of a band of rows (+ one halo row above and below) straight from global memory -- the B operand
+// of lane (pixel n, k group g) is ONE 16-B load: 8 consecutive channels of its pixel -- then the nine shifted planes are summed
+// from LDS: out[y][x] = sum_(kh,kw) D[kh*3+kw][y+kh-1][x+kw-1].  The stored activation is exact in bf16; the fp32 weight enters
+// as three bf16 planes w1 + w2 + w3 (24 significant bits), three MFMAs per K step, fp32 accumulation: fp32-grade like the FMA
+// form, in a different summation order.
+typedef __bf16 hm_bf16x8 __attribute__((ext_vector_type(8)));
+template <int NK>
+__global__ __launch_bounds__(256) void head_mfma_b16_kernel(const char* __restrict__ in, int in_ctot, const float* __restrict__ w,
+                                                            float* __restrict__ out, int relu, int H, int W, int R, int bands) {
+  extern __shared__ __attribute__((aligned(16))) float dl[];      // [9 taps][RW + pad]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / bands, band = blockIdx.x - b * bands;
+  const int y0 = band * R;
+  const int rows = (H - y0 < R ? H - y0 : R) + 2;
+  const int RW = rows * W, RWP = (R + 2) * W + 1;
+  const int HW = H * W;
+  // weights: row (tap) n of the A operand, channels 32 kk + 8 g .. + 7, three bf16 planes
+  hm_bf16x8 A[3][NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = n < 9 ? w[(kk * 32 + 8 * g + j) * 9 + n] : 0.f;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const __bf16 q = (__bf16)v;
+        A[pl][kk][j] = q;
+        v -= (float)q;
+      }
+    }
+  const size_t plane = (size_t)HW * 32;
+  const char* ib = in + (size_t)b * (in_ctot >> 4) * plane + (size_t)(g >> 1) * plane + (g & 1) * 16;
+  const int P0 = (y0 - 1) * W;                                   // image pixel index of region pixel 0
+  const int ngrp = (RW + 15) >> 4;
+  for (int q0 = wv; q0 < ngrp; q0 += 8) {                        // two groups in flight per wave
+    hm_bf16x8 Bf[2][NK];
+    int r[2];
+    bool ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = q0 + 4 * u;
+      r[u] = q * 16 + n;
+      const int P = P0 + r[u];
+      ok[u] = q < ngrp && r[u] < RW && P >= 0 && P < HW;
+      const unsigned po = (unsigned)(ok[u] ? P : 0) * 32u;
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) Bf[u][kk] = *(const hm_bf16x8*)(ib + (size_t)(2 * kk) * plane + po);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pl = 2; pl >= 0; --pl)                              // small terms first
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[pl][kk], Bf[u][kk], acc, 0, 0, 0);
+      if (q0 + 4 * u < ngrp && r[u] < RW) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (4 * g + j < 9) dl[(4 * g + j) * RWP + r[u]] = ok[u] ? acc[j] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  const int npx = (rows - 2) * W;
+  for (int i = threadIdx.x; i < npx; i += 256) {
+    const int y = i / W, x = i - y * W;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const float* d = dl + (kh * 3) * RWP + (y + kh) * W + x;
+      const float l = x > 0 ? d[-1] : 0.f, c = d[RWP], rr = x + 1 < W ? d[2 * RWP + 1] : 0.f;
+      const float t = (l + c) + rr;
+      if (kh == 0) s0 = t; else if (kh == 1) s1 = t; else s2 = t;
+    }
+    float v = (s0 + s1) + s2;
+    if (relu) v = tsr_relu(v);
+    out[(size_t)b * HW + (y0 + y) * W + x] = v;
+  }
+}
+
+static int head_mfma_launch(const void* in, int in_ctot, int cin, const float* w, float* out, int relu, int B, int H, int W,
+                            void* stream) {
+  int R = 32 * 1024 / (W * 36) - 2;                               // band rows: nine fp32 planes of (R + 2) rows within 32 KB
+  if (R > H) R = H;
+  if (R < 1) return -1;                                           // (very wide images: the LDS-tiled kernel)
+  const int bands = (H + R - 1) / R;
+  const size_t smem = (size_t)9 * ((R + 2) * W + 1) * 4;
+  if ((long long)B * bands > 0x7fffffffLL) return -1;
+  if (cin == 128)
+    hipLaunchKernelGGL(head_mfma_b16_kernel<4>, dim3(B * bands), dim3(256), smem, (hipStream_t)stream, (const char*)in, in_ctot, w,
+                       out, relu, H, W, R, bands);
+  else
+    hipLaunchKernelGGL(head_mfma_b16_kernel<2>, dim3(B * bands), dim3(256), smem, (hipStream_t)stream, (const char*)in, in_ctot, w,
+                       out, relu, H, W, R, bands);
+  return tsr_check_launch();
+}
+
 // bf16 activation storage: `in` is bf16 CB16; the image comes out fp32 NCHW as always
 extern "C" int tsr_head_fwd_b16(const void* in_bf16, int in_ctot, int cin, const float* w_oihw, float* out_nchw,
                                 int relu, int B, int H, int W, void* stream) {
   if (!in_bf16 || !w_oihw || !out_nchw || B <= 0 || (cin & 15) || (in_ctot & 15) || cin > in_ctot || cin <= 0)
     return TSR_ERR_ARG;
+  if (cin == 128 || cin == 64) {
+    const int st = head_mfma_launch(in_bf16, in_ctot, cin, w_oihw, out_nchw, relu, B, H, W, stream);
+    if (st >= 0) return st;
+  }
   return head_launch<true>((const float*)in_bf16, in_ctot, cin, w_oihw, out_nchw, relu, B, H, W, stream);
 }
 

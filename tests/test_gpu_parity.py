@@ -113,6 +113,25 @@ def test_head_fwd(T, B, H, W):
     assert relerr(out, ref) < TOL
 
 
+@pytest.mark.parametrize("B,C,H,W,relu", [(2, 128, 40, 40, 1), (1, 128, 100, 100, 1), (3, 128, 9, 17, 0), (5, 64, 13, 21, 1),
+                                          (2, 128, 3, 2, 0), (1, 128, 40, 1000, 1)])
+def test_head_fwd_bf16_storage(T, B, C, H, W, relu):
+    """The head on a bf16 CB16 input (tsr_head_fwd_b16: MFMA form -- the stored activation is exact in bf16, the fp32 weight
+    enters as three bf16 planes -- or, for very wide images, the LDS-tiled form): fp32-grade against the convolution of the
+    bf16-ROUNDED input with the fp32 weight in fp64 (1e-5 of the output's scale; ragged sizes, one- and two-band images,
+    a C_in of 64, with and without the ReLU)."""
+    from tactilesr_amd._lib import call, ptr, stream, c_int as I
+    g = torch.Generator().manual_seed(B + H + C)
+    x = torch.randn(B, C, H, W, generator=g).bfloat16().float()
+    w = torch.randn(1, C, 3, 3, generator=g) * 0.05
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    ref = F.relu(ref) if relu else ref
+    out = torch.full((B, 1, H, W), float("nan"), device="cuda")
+    x_d, w_d = T.to_cb16(x.cuda(), C + 16, 0).to(torch.bfloat16), w.cuda()
+    call("tsr_head_fwd_b16", ptr(x_d), I(C + 16), I(C), ptr(w_d), ptr(out), I(relu), I(B), I(H), I(W), stream())
+    assert relerr(out, ref) < TOL
+
+
 GOLD_CFG = {"t1": dict(), "t7": dict(seqsCnt=7), "sf25t8": dict(scale_factor=25, seqsCnt=8),
             "t1_l2": dict(patternFeatureExtraLayerCnt=2)}
 
