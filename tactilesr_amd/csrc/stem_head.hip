@@ -22,9 +22,13 @@ __device__ __forceinline__ void bilin_src(int dst, float scale, int n_in, int& i
   lam = src - (float)i0;
 }
 
-// One workgroup = a band of RB output rows of one image.  A thread item = 4 consecutive pixels of a row x one
-// 16-channel block: per (input channel, kernel row) it reads 6 upsampled values and per tap the 16 weights, i.e.
-// 162 LDS reads for 1728 FMAs (a pixel-per-thread mapping needs 4x the weight reads and is LDS/issue bound).
+// One workgroup = a band of RB output rows of one image: the upsampled band (+ halo) is formed in LDS, then the 3x3 conv
+// 3 -> 64 runs as a matrix product on v_mfma_f32_16x16x32_bf16 with the 27 (channel, tap) products as K (padded to 32) and
+// channels as rows: D[channel][pixel].  Both operands are fp32 values, so each enters as THREE bf16 planes (x = x1 + x2 + x3,
+// 24 significant bits) and a product is all nine plane pairs -- exact products, fp32 accumulation, small terms first:
+// fp32-grade, like the VALU form it replaces (1728 FMAs per pixel: the kernel was VALU-bound at 0.54 / 0.75 ms for 0.84 / 1.7
+// GB written at B = 4096).  The B operand of lane (pixel n, k group g) is 8 LDS reads of the upsampled band; the
+// accumulator's 4 channels per lane are 16 B (8 B in bf16) of the CB16 output: a wave's store covers whole lines.
 typedef __bf16 sh_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 sh_bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -36,128 +40,115 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ lr,
                                                    const float* __restrict__ scale,
                                                    const float* __restrict__ shift,
                                                    float* __restrict__ out, int out_ctot, int out_coff,
-                                                   int relu, int B, int RB, float* __restrict__ out_amax) {
+                                                   int relu, int B, int RB, int IPW, float* __restrict__ out_amax) {
+  static_assert(CIN * 9 <= 32, "one K step");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = hin * sf, W = win * sf;
-  const int NQ = (W + 3) >> 2;            // pixel quads per row
-  const int WP = NQ * 4 + 2;              // padded row of the upsampled band (zero beyond the image)
-  float* wl = smem;                       // [9*CIN][64]
-  float* tax = wl + 9 * CIN * 64;         // [CIN][hin*win]
+  const int WP = ((W + 3) & ~3) + 2;      // padded row of the upsampled band (zero beyond the image)
+  float* tax = smem;                      // [CIN][hin*win]
   float* up = tax + ((CIN * hin * win + 3) & ~3);  // [CIN][RB+2][WP]
   const int tid = threadIdx.x;
-  const int b = blockIdx.y;
   const int y0 = blockIdx.x * RB;
   const int rows = (H - y0) < RB ? (H - y0) : RB;
 
-  for (int i = tid; i < 9 * CIN * 64; i += 256) {
-    const int n = i & 63, kc = i >> 6;         // kc = tap*CIN + c
-    const int tap = kc / CIN, c = kc - tap * CIN;
-    wl[i] = w[(n * CIN + c) * 9 + tap];        // (a coalesced read + transposing LDS write measured slower: 0.90 vs 0.85 ms)
+  // ---- operands (once per workgroup; it then walks IPW images).  K slot k = 8 g + j of lane (n, g) is (channel c, tap kh,
+  // kw) = (k / 9, (k % 9) / 3, k % 3); slots >= 9 CIN carry a zero weight (and read band element 0).  A: row n of tile mt =
+  // output channel 16 mt + n, three planes.
+  const int lane = tid & 63, wv = tid >> 6;
+  const int n = lane & 15, g = lane >> 4;
+  int koff[8];
+  sh_bf16x8 A[3][4];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 8 * g + j;
+    const bool real = k < 9 * CIN;
+    const int c = k / 9, r9 = k - c * 9, kh = r9 / 3, kw = r9 - kh * 3;
+    koff[j] = real ? (c * (RB + 2) + kh) * WP + kw : 0;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      float v = real ? w[((mt * 16 + n) * CIN + c) * 9 + r9] : 0.f;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const __bf16 q = (__bf16)v;
+        A[pl][mt][j] = q;
+        v -= (float)q;
+      }
+    }
   }
-  for (int i = tid; i < CIN * hin * win; i += 256)
-    tax[i] = lr[((size_t)b * lr_ctot + lr_coff) * hin * win + i];
-  __syncthreads();
-
+  f32x4 scv[4], shv[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    scv[mt] = scale ? *(const f32x4*)(scale + mt * 16 + 4 * g) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    shv[mt] = shift ? *(const f32x4*)(shift + mt * 16 + 4 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   const float sc = 1.0f / (float)sf;
   const int nup = CIN * (RB + 2) * WP;
-  for (int i = tid; i < nup; i += 256) {
-    const int c = i / ((RB + 2) * WP);
-    const int rem = i - c * ((RB + 2) * WP);
-    const int yy = rem / WP, xx = rem - yy * WP;
-    const int gy = y0 - 1 + yy, gx = xx - 1;
-    float v = 0.f;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-      int ya, yb, xa, xb;
-      float ly, lx;
-      bilin_src(gy, sc, hin, ya, yb, ly);
-      bilin_src(gx, sc, win, xa, xb, lx);
-      const float* t = tax + c * hin * win;
-      const float top = (1.f - lx) * t[ya * win + xa] + lx * t[ya * win + xb];
-      const float bot = (1.f - lx) * t[yb * win + xa] + lx * t[yb * win + xb];
-      v = (1.f - ly) * top + ly * bot;
-    }
-    up[i] = v;
-  }
-  __syncthreads();
-
   const int HW = H * W;
-  const int nq = rows * NQ;
+  const int npx = rows * W;
   const int out_blocks = out_ctot >> 4;
   float amax = 0.f;
-  const int jq = tid & 3;                              // lane within its quad
-  for (int it0 = 0; it0 < nq * 4; it0 += 256) {        // every thread runs every pass (the store phase exchanges lanes)
-    const int it = it0 + tid;
-    const bool live = it < nq * 4;
-    const int itc = live ? it : nq * 4 - 1;
-    const int blk = itc / nq, p = itc - blk * nq;
-    const int y = p / NQ, x0 = (p - y * NQ) * 4;
-    float acc[4][16];
-#pragma unroll
-    for (int px = 0; px < 4; ++px)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[px][j] = 0.f;
-#pragma unroll 1
-    for (int ck = 0; ck < CIN * 3; ++ck) {          // (input channel, kernel row): rolled, the body is 192 FMAs
-        const int c = ck / 3, kh = ck - c * 3;
-        const float* ur = up + (c * (RB + 2) + y + kh) * WP + x0;
-        float u[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) u[j] = ur[j];
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const f32x4* wr = (const f32x4*)(wl + ((kh * 3 + kw) * CIN + c) * 64 + blk * 16);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 wv = wr[q];
-#pragma unroll
-            for (int px = 0; px < 4; ++px)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) acc[px][4 * q + j] = fmaf(u[px + kw], wv[j], acc[px][4 * q + j]);
-          }
-        }
-    }
-    const int oc = out_coff + blk * 16;
-    const unsigned oidx = (unsigned)(((oc >> 4) * HW + (y0 + y) * W + x0) * 16);     // element offset inside image b (< 2^31)
-    unsigned vm = 0;                                    // bit px: pixel x0 + px exists (and this item is live)
-#pragma unroll
-    for (int px = 0; px < 4; ++px) vm |= (unsigned)(live && x0 + px < W) << px;
-    // scale / shift / ReLU in place, max |.| of the live values
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 scv = scale ? *(const f32x4*)(scale + blk * 16 + 4 * q) : (f32x4){1.f, 1.f, 1.f, 1.f};
-      const f32x4 shv = shift ? *(const f32x4*)(shift + blk * 16 + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int px = 0; px < 4; ++px)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float t = acc[px][4 * q + j] * scv[j] + shv[j];
-          const float v = relu ? tsr_relu(t) : t;
-          acc[px][4 * q + j] = v;
-          if ((vm >> px) & 1) amax = fmaxf(amax, fabsf(v));
-        }
-    }
-    // Store phase.  A thread owns 4 pixels x 16 channels; stored as such, one store instruction would put 16 B into each
-    // of 64 different 64-B lines (256-B lane stride) -- the kernel ran at 1.9 TB/s of writes.  A 4x4 transpose inside
-    // every lane quad (lane l's channel quad q  <->  lane q's copy of lane l's pixel) makes the four lanes of a quad
-    // write the four 16-B quarters of ONE pixel line: a wave instruction then covers whole lines.
-    unsigned oi[4], vl[4];
-    oi[0] = __builtin_amdgcn_mov_dpp(oidx, 0x00, 0xF, 0xF, true); vl[0] = __builtin_amdgcn_mov_dpp(vm, 0x00, 0xF, 0xF, true);
-    oi[1] = __builtin_amdgcn_mov_dpp(oidx, 0x55, 0xF, 0xF, true); vl[1] = __builtin_amdgcn_mov_dpp(vm, 0x55, 0xF, 0xF, true);
-    oi[2] = __builtin_amdgcn_mov_dpp(oidx, 0xAA, 0xF, 0xF, true); vl[2] = __builtin_amdgcn_mov_dpp(vm, 0xAA, 0xF, 0xF, true);
-    oi[3] = __builtin_amdgcn_mov_dpp(oidx, 0xFF, 0xF, 0xF, true); vl[3] = __builtin_amdgcn_mov_dpp(vm, 0xFF, 0xF, 0xF, true);
-    const size_t ib = (size_t)b * out_blocks * HW * 16;
-#pragma unroll
-    for (int px = 0; px < 4; ++px) {
-      f32x4 wq[4];                                      // wq[l] = channels 4 jq .. 4 jq + 3 of lane l's pixel px
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float t0 = acc[px][c], t1 = acc[px][4 + c], t2 = acc[px][8 + c], t3 = acc[px][12 + c];
-        quad_transpose(t0, t1, t2, t3, jq);
-        wq[0][c] = t0; wq[1][c] = t1; wq[2][c] = t2; wq[3][c] = t3;
+
+  for (int b = blockIdx.y * IPW; b < B && b < (blockIdx.y + 1) * IPW; ++b) {
+    __syncthreads();                                 // (the previous image's band has been read)
+    for (int i = tid; i < CIN * hin * win; i += 256)
+      tax[i] = lr[((size_t)b * lr_ctot + lr_coff) * hin * win + i];
+    __syncthreads();
+    for (int i = tid; i < nup; i += 256) {
+      const int c = i / ((RB + 2) * WP);
+      const int rem = i - c * ((RB + 2) * WP);
+      const int yy = rem / WP, xx = rem - yy * WP;
+      const int gy = y0 - 1 + yy, gx = xx - 1;
+      float v = 0.f;
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        int ya, yb, xa, xb;
+        float ly, lx;
+        bilin_src(gy, sc, hin, ya, yb, ly);
+        bilin_src(gx, sc, win, xa, xb, lx);
+        const float* t = tax + c * hin * win;
+        const float top = (1.f - lx) * t[ya * win + xa] + lx * t[ya * win + xb];
+        const float bot = (1.f - lx) * t[yb * win + xa] + lx * t[yb * win + xb];
+        v = (1.f - ly) * top + ly * bot;
       }
+      up[i] = v;
+    }
+    __syncthreads();
+
+    const size_t obase = ((size_t)b * out_blocks + (out_coff >> 4)) * HW * 16 + 4 * g;      // + mt * HW * 16 + pixel * 16
+    for (int q = wv; q * 16 < npx; q += 4) {
+      const int i = q * 16 + n;
+      const bool live = i < npx;
+      const int ic = live ? i : npx - 1;
+      const int y = ic / W, x = ic - y * W;
+      const float* ub = up + y * WP + x;
+      sh_bf16x8 U[3];
 #pragma unroll
-      for (int l = 0; l < 4; ++l)
-        if ((vl[l] >> px) & 1) tsr_st4<OUT16>(out, ib + oi[l] + px * 16 + jq * 4, wq[l]);
+      for (int j = 0; j < 8; ++j) {
+        float v = ub[koff[j]];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const __bf16 qv = (__bf16)v;
+          U[pl][j] = qv;
+          v -= (float)qv;
+        }
+      }
+      const size_t po = obase + (size_t)((y0 + y) * W + x) * 16;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};                           // all nine plane pairs, smallest terms first
+#pragma unroll
+        for (int s9 = 4; s9 >= 0; --s9)
+#pragma unroll
+          for (int pa = 2; pa >= 0; --pa)
+            if (s9 - pa >= 0 && s9 - pa <= 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[pa][mt], U[s9 - pa], acc, 0, 0, 0);
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float t = acc[c] * scv[mt][c] + shv[mt][c];
+          o[c] = relu ? tsr_relu(t) : t;
+          if (live) amax = fmaxf(amax, fabsf(o[c]));
+        }
+        if (live) tsr_st4<OUT16>(out, po + (size_t)mt * HW * 16, o);
+      }
     }
   }
   if (out_amax) {      // max |output| for the fp16-split consumer's power-of-two scale
@@ -175,32 +166,36 @@ static int stem_fwd_impl(const float* lr, int lr_ctot, int lr_coff, int axis_cnt
   if ((out_ctot & 15) || (out_coff & 15) || out_coff + 64 > out_ctot || lr_coff + axis_cnt > lr_ctot)
     return TSR_ERR_ARG;
   const int H = hin * sf, W = win * sf;
-  const int NQ = (W + 3) >> 2, WP = NQ * 4 + 2;
-  // rows per workgroup: the band (RB+2 rows of 3 channels) must fit 64 KB of LDS with the weights; among the
-  // fitting sizes take the one whose item count (rows x quads x 4 blocks) fills its 256-thread passes best
-  const size_t fixed = (size_t)(9 * 3 * 64 + ((3 * hin * win + 3) & ~3)) * 4;
+  const int WP = ((W + 3) & ~3) + 2;
+  // rows per workgroup: the upsampled band (RB + 2 rows of 3 channels) within 32 KB of LDS; among the fitting sizes the one
+  // whose pixel count fills its 64-pixel passes (4 waves x 16 pixels) best
+  const size_t fixed = (size_t)((3 * hin * win + 3) & ~3) * 4;
   int RB = 0;
   double best = -1.0;
-  for (int rb = 4; rb <= H; ++rb) {
-    if (fixed + (size_t)3 * (rb + 2) * WP * 4 > 64 * 1024) break;
+  for (int rb = 2; rb <= H; ++rb) {
+    if (fixed + (size_t)3 * (rb + 2) * WP * 4 > 32 * 1024) break;
     long items = 0, slots = 0;
     for (int y = 0; y < H; y += rb) {
       const int r = H - y < rb ? H - y : rb;
-      items += (long)r * NQ * 4;
-      slots += ((long)r * NQ * 4 + 255) / 256 * 256;
+      items += (long)r * W;
+      slots += ((long)r * W + 63) / 64 * 64;
     }
     const double eff = (double)items / (double)slots;
     if (eff > best + 1e-9) { best = eff; RB = rb; }
   }
   if (RB == 0) return TSR_ERR_ARG;
   const size_t smem = fixed + (size_t)3 * (RB + 2) * WP * 4;
-  dim3 grid((H + RB - 1) / RB, B);
+  // images per workgroup (the weight planes are built once per workgroup): as many as still leave >= 4 workgroups per CU
+  const int bands = (H + RB - 1) / RB;
+  int IPW = (int)(((long long)B * bands) / (256 * 4));
+  IPW = IPW < 1 ? 1 : (IPW > 16 ? 16 : IPW);
+  dim3 grid(bands, (B + IPW - 1) / IPW);
   if (out16)
     hipLaunchKernelGGL((stem_kernel<3, true>), grid, dim3(256), smem, (hipStream_t)stream, lr, lr_ctot, lr_coff, hin,
-                       win, sf, w_oihw, scale, shift, out, out_ctot, out_coff, relu, B, RB, out_amax);
+                       win, sf, w_oihw, scale, shift, out, out_ctot, out_coff, relu, B, RB, IPW, out_amax);
   else
     hipLaunchKernelGGL((stem_kernel<3, false>), grid, dim3(256), smem, (hipStream_t)stream, lr, lr_ctot, lr_coff, hin,
-                       win, sf, w_oihw, scale, shift, out, out_ctot, out_coff, relu, B, RB, out_amax);
+                       win, sf, w_oihw, scale, shift, out, out_ctot, out_coff, relu, B, RB, IPW, out_amax);
   return tsr_check_launch();
 }
 
