@@ -34,6 +34,7 @@ typedef int gi32x4 __attribute__((ext_vector_type(4)));
 
 struct WgradBArgs {
   const char* a;  int a_ctot; int a_coff; int cin;
+  const float* a_scale; const float* a_shift;  // XF kernels: the input is relu(a * scale + shift), formed in LDS
   const char* dz; int dz_ctot; int dz_coff; int cout;
   float* slab; float* bslab;
   int B, H, W, nsplit;
@@ -51,7 +52,7 @@ __device__ __forceinline__ void wgb_dma(gi32x4 rs, int vo, unsigned m0v) {
 #define TSR_WGB_PF 1
 #endif
 
-template <int KS, int KHW, int CO, int CI, int WM>
+template <int KS, int KHW, int CO, int CI, int WM, bool XF = false>
 struct WgradBGeom {
   static constexpr int NWM = CO / WM, NWN = CI / 32, NW = NWM * NWN, NT = 64 * NW;
   static constexpr int MT = WM / 16;
@@ -61,7 +62,10 @@ struct WgradBGeom {
   // 16-B units of a slot: dz blocks (64 each), then `a` blocks (UPB each)
   static constexpr int UDZ = (CO / 16) * 64, UPB = AROWS * PITCH * 2, UA = (CI / 16) * UPB, U = UDZ + UA;
   static constexpr int NV = ((U + 63) / 64 + NW - 1) / NW;  // requests per wave and item
-  static constexpr int SLOTB = NV * NW * 1024, RING = 3, LA = RING - 1, LDSB = RING * SLOTB;
+  // XF: one more slot -- an item is transformed in place during the step BEFORE the one that multiplies it
+  static constexpr int SLOTB = NV * NW * 1024, RING = XF ? 4 : 3, LA = RING - 1, LDSB = RING * SLOTB;
+  static constexpr int NXF = (UA + NT - 1) / NT;              // 16-B units of the input tile a thread transforms per item
+  static constexpr bool DZ0 = CO / 16 == NW;                  // request 0 of EVERY wave is its dz block (no run-time kinds)
   static_assert(MT <= NWN, "bias sums: one C_out tile per wave");
   static_assert(ACOLS <= PITCH && LDSB <= 160 * 1024, "slot");
 };
@@ -73,10 +77,10 @@ template <int I, int N, class F> __device__ __forceinline__ void wgb_static_for(
   }
 }
 
-template <int KS, int KHW, int CO, int CI, int WM>
-__global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, (CO / WM) * (CI / 32) == 8 ? 1 : 2)
+template <int KS, int KHW, int CO, int CI, int WM, bool XF = false>
+__global__ __launch_bounds__((CO / WM) * (CI / 32) * 64, (CO / WM) * (CI / 32) >= 8 ? 1 : 2)
 void wgrad_b16k_kernel(const WgradBArgs g) {
-  typedef WgradBGeom<KS, KHW, CO, CI, WM> G;
+  typedef WgradBGeom<KS, KHW, CO, CI, WM, XF> G;
   typedef __attribute__((address_space(3))) gv4i16* lds_v4;
   constexpr int P = KS / 2, MT = G::MT, NTAP = G::NTAP, NW = G::NW, NV = G::NV, PITCH = G::PITCH;
   constexpr int SLOTB = G::SLOTB;
@@ -114,22 +118,26 @@ void wgrad_b16k_kernel(const WgradBArgs g) {
   const int nitem = it1 > it0 ? it1 - it0 : 0;
 
   // ---- request constants of this lane: request v of the wave is 1-KB chunk k = wave + v * NW of the slot; the dz blocks
-  // are chunks 0 .. NW-1 (C_out/16 = NW in every tile shape), i.e. request 0 of every wave, requests 1.. fetch `a`
-  static_assert(CO / 16 == NW, "request 0 = the wave's dz block");
+  // are chunks 0 .. C_out/16 - 1.  In most tile shapes C_out/16 = NW, i.e. request 0 of every wave is its dz block and
+  // requests 1.. fetch `a` (G::DZ0: the kind is a compile-time fact); otherwise it is a wave-uniform run-time flag.
   int lc[NV], ry[NV], cx[NV];
-  {
-    const int px = lane >> 1;
-    ry[0] = px >> 3; cx[0] = px & 7;
-    lc[0] = wave * HW * 32 + (ry[0] * g.W + cx[0]) * 32 + (lane & 1) * 16;
-  }
+  bool isdz[NV];
 #pragma unroll
-  for (int v = 1; v < NV; ++v) {
-    const int ua = 64 * (wave + (v - 1) * NW) + lane;
-    const int blk = ua / G::UPB, rem = ua - blk * G::UPB;
-    const int ra = rem / (2 * PITCH), t = rem - ra * 2 * PITCH, ca = t >> 1;
-    const bool bad = blk >= CI / 16 || ca >= G::ACOLS;      // slot padding: never fetched
-    ry[v] = bad ? 0x40000000 : ra; cx[v] = ca;
-    lc[v] = blk * HW * 32 + (ra * g.W + ca) * 32 + (t & 1) * 16;
+  for (int v = 0; v < NV; ++v) {
+    const int k = wave + v * NW;
+    isdz[v] = G::DZ0 ? v == 0 : k < CO / 16;
+    if (isdz[v]) {
+      const int px = lane >> 1;
+      ry[v] = px >> 3; cx[v] = px & 7;
+      lc[v] = k * HW * 32 + (ry[v] * g.W + cx[v]) * 32 + (lane & 1) * 16;
+    } else {
+      const int ua = 64 * (k - CO / 16) + lane;
+      const int blk = ua / G::UPB, rem = ua - blk * G::UPB;
+      const int ra = rem / (2 * PITCH), t = rem - ra * 2 * PITCH, ca = t >> 1;
+      const bool bad = blk >= CI / 16 || ca >= G::ACOLS;      // slot padding: never fetched
+      ry[v] = bad ? 0x40000000 : ra; cx[v] = ca;
+      lc[v] = blk * HW * 32 + (ra * g.W + ca) * 32 + (t & 1) * 16;
+    }
   }
   const unsigned lds_a = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds;
 
@@ -162,8 +170,9 @@ void wgrad_b16k_kernel(const WgradBArgs g) {
   };
   auto dma = [&](auto vc, int slot) __attribute__((always_inline)) {
     constexpr int v = decltype(vc)::value;
-    const unsigned long long bs = v == 0 ? q_pd : q_pa;
-    const int Y = v == 0 ? q_y : q_y + kh0 - P, X = v == 0 ? q_x : q_x - P;
+    const bool dk = G::DZ0 ? v == 0 : isdz[v];
+    const unsigned long long bs = dk ? q_pd : q_pa;
+    const int Y = dk ? q_y : q_y + kh0 - P, X = dk ? q_x : q_x - P;
     const bool ok = ((unsigned)(Y + ry[v]) < (unsigned)g.H) & ((unsigned)(X + cx[v]) < (unsigned)g.W);
     const int vo = ok ? lc[v] : (int)0x80000000;
     const gi32x4 rs = {(int)bs, (int)(bs >> 32) & 0xffff, q_nr, 0x00020000};
@@ -174,6 +183,14 @@ void wgrad_b16k_kernel(const WgradBArgs g) {
     wgb_static_for<0, NV>([&](auto vc) __attribute__((always_inline)) { dma(vc, slot); });
   };
 #define WGB_VM_WAIT(n_) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n_) & 15) | (((n_) >> 4) << 14))
+// (XF: also lgkmcnt(0) -- this thread's transformed units are in LDS before the barrier)
+#define WGB_STEP_END_X(n_)                                                                \
+  {                                                                                      \
+    asm volatile("" ::: "memory");                                                       \
+    __builtin_amdgcn_s_waitcnt(0x0070 | ((n_) & 15) | (((n_) >> 4) << 14));              \
+    __builtin_amdgcn_s_barrier();                                                        \
+    asm volatile("" ::: "memory");                                                       \
+  }
 #define WGB_STEP_END(n_)                      \
   {                                          \
     asm volatile("" ::: "memory");           \
@@ -204,11 +221,63 @@ void wgrad_b16k_kernel(const WgradBArgs g) {
 
   auto run = [&](auto bias_c) __attribute__((always_inline)) {
     constexpr bool BIAS = decltype(bias_c)::value;
-    static_assert(NV < NTAP, "one request per tap");
-    // prologue: the first LA items landed
+    // XF: this thread's 16-B units of the input tile (8 channels of one pixel each) and their BatchNorm scale / shift
+    int xoff[XF ? G::NXF : 1];
+    f32x4 xsc[XF ? G::NXF : 1][2], xsh[XF ? G::NXF : 1][2];
+    if constexpr (XF) {
+#pragma unroll
+      for (int i = 0; i < G::NXF; ++i) {
+        const int u = threadIdx.x + i * G::NT;
+        const int uc = u < G::UA ? u : G::UA - 1;
+        const int blk = uc / G::UPB, half = uc & 1;
+        xoff[i] = u < G::UA ? G::UDZ * 16 + u * 16 : -1;
+        const float* sp_ = g.a_scale + cib * CI + blk * 16 + half * 8;
+        const float* hp_ = g.a_shift + cib * CI + blk * 16 + half * 8;
+        xsc[i][0] = *(const f32x4*)sp_ * 0.5f; xsc[i][1] = *(const f32x4*)(sp_ + 4) * 0.5f;
+        xsh[i][0] = *(const f32x4*)hp_ * 0.5f; xsh[i][1] = *(const f32x4*)(hp_ + 4) * 0.5f;
+      }
+    }
+    // in place: bf16(relu(fp32(z) * scale + shift)) -- what wgrad_tr16_kernel<.., IO16> forms while staging (bit for bit: halving
+    // the two vectors is exact).  (Pixels outside the
+    // image arrive as zeros and become relu(shift): their dz is zero, so they add nothing.)
+    // two halves: the unit reads are issued at the top of a step (their latency passes under the step's MFMAs), the arithmetic
+    // and the write-back follow the MFMAs
+    gb16x8 xz[XF ? G::NXF : 1];
+    constexpr bool XALL = G::UA % G::NT == 0;           // every thread has all its NXF units
+    auto xf_load = [&](int slot) __attribute__((always_inline)) {
+      if constexpr (XF) {
+#pragma unroll
+        for (int i = 0; i < G::NXF; ++i)
+          if (XALL || xoff[i] >= 0) xz[i] = *(const gb16x8*)(lds + slot * SLOTB + xoff[i]);
+      }
+    };
+    auto xf_store = [&](int slot) __attribute__((always_inline)) {
+      if constexpr (XF) {
+#pragma unroll
+        for (int i = 0; i < G::NXF; ++i) {
+          if (XALL || xoff[i] >= 0) {
+            gb16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {      // (scale / shift are HALVED: relu(t) = t/2 + |t/2|, one instruction, NaN-propagating)
+              o[e] = (__bf16)tsr_relu_x2(fmaf((float)xz[i][e], xsc[i][0][e], xsh[i][0][e]));
+              o[4 + e] = (__bf16)tsr_relu_x2(fmaf((float)xz[i][4 + e], xsc[i][1][e], xsh[i][1][e]));
+            }
+            *(gb16x8*)(lds + slot * SLOTB + xoff[i]) = o;
+          }
+        }
+      }
+    };
+    // prologue: the first LA items requested; item 0 (XF: items 0 and 1) landed
 #pragma unroll
     for (int i = 0; i < G::LA; ++i) request(i);
-    WGB_STEP_END(0);
+    if constexpr (XF) {
+      WGB_STEP_END((G::LA - 2) * NV);
+      xf_load(0);
+      xf_store(0);
+      WGB_STEP_END_X((G::LA - 2) * NV);
+    } else {
+      WGB_STEP_END(0);
+    }
     int slot = 0;
     for (int s = 0; s < nitem; ++s) {
       const int slot2 = slot == 0 ? G::RING - 1 : slot - 1;   // (slot + LA) % RING
@@ -230,15 +299,18 @@ void wgrad_b16k_kernel(const WgradBArgs g) {
 #pragma unroll
       for (int t = 0; t < PF; ++t) load_b(bf[t], t);
       item_next();
+      xf_load(slot == G::RING - 1 ? 0 : slot + 1);      // XF: item s + 1 (landed before this step began)
       __builtin_amdgcn_sched_barrier(0);
       wgb_static_for<0, NTAP>([&](auto tc) __attribute__((always_inline)) {
         constexpr int u = decltype(tc)::value;
         if constexpr (u + PF < NTAP) load_b(bf[(u + PF) % (PF + 1)], u + PF);
         // item s + LA, one request per tap (the wave's instruction issue is the scarce thing: a request is ~12 scalar /
         // vector instructions, which fit between a tap's MFMAs; all of them in one block at the step's top would stop both
-        // waves of the SIMD at the same time)
-        if constexpr (u < NV) dma(std::integral_constant<int, u>(), slot2);
-        if constexpr (BIAS && u == NV) {
+        // waves of the SIMD at the same time); a step with fewer taps than requests issues the rest with its last tap
+        if constexpr (u < NV && u < NTAP - 1) dma(std::integral_constant<int, u>(), slot2);
+        if constexpr (u == NTAP - 1)
+          wgb_static_for<(NTAP - 1 < NV ? NTAP - 1 : NV), NV>([&](auto vc) __attribute__((always_inline)) { dma(vc, slot2); });
+        if constexpr (BIAS && u == (NV < NTAP - 1 ? NV : NTAP - 1)) {
           typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
           gu32x4 sel = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -261,7 +333,12 @@ void wgrad_b16k_kernel(const WgradBArgs g) {
         }
         __builtin_amdgcn_sched_barrier(0);
       });
-      WGB_STEP_END((G::LA - 1) * NV);
+      if constexpr (XF) {       // item s + 1 (landed before this step began) becomes the activation, for the next step's reads
+        xf_store(slot == G::RING - 1 ? 0 : slot + 1);
+        WGB_STEP_END_X((G::LA - 2) * NV);
+      } else {
+        WGB_STEP_END((G::LA - 1) * NV);
+      }
       slot = slot == G::RING - 1 ? 0 : slot + 1;
     }
     WGB_VM_WAIT(0);        // (the trailing zero-range requests)
@@ -297,29 +374,37 @@ void wgrad_b16k_kernel(const WgradBArgs g) {
   }
 }
 
-template <int KS, int KHW, int CO, int CI, int WM>
+template <int KS, int KHW, int CO, int CI, int WM, bool XF = false>
 static int wgb_launch(const WgradBArgs& g, hipStream_t st) {
-  typedef WgradBGeom<KS, KHW, CO, CI, WM> G;
+  typedef WgradBGeom<KS, KHW, CO, CI, WM, XF> G;
   const int grid = g.nsplit * G::NKG * (g.cout / CO) * (g.cin / CI);
-  hipLaunchKernelGGL((wgrad_b16k_kernel<KS, KHW, CO, CI, WM>), dim3(grid), dim3(G::NT), 0, st, g);
+  hipLaunchKernelGGL((wgrad_b16k_kernel<KS, KHW, CO, CI, WM, XF>), dim3(grid), dim3(G::NT), 0, st, g);
   return tsr_check_launch();
 }
 
 // 1 if tsr_conv2d_wgrad_bf16s (planes = -1, no input transform) runs this shape here: 3x3 / 5x5, the tiles of
 // wgrad_mfma_tr16.hip's WgradTCfg (so tsr_conv2d_wgrad_splits and the slab layout are the same for both kernels)
 bool tsr_wgrad_b16k_ok(int cout, int cin, int ks, int H, int W, int a_ctot, int dz_ctot) {
-  if (ks != 3 && ks != 5) return false;
   if ((long long)(a_ctot > dz_ctot ? a_ctot : dz_ctot) * H * W * 2 >= 0x7fffffffLL) return false;   // 32-bit offsets inside an image
+  if (ks == 1) return cout == 64 && (cin % 256) == 0;       // the MSRB `confusion`: one workgroup = 64 x 256, input transform in LDS
+  if (ks != 3 && ks != 5) return false;
   return (cout % 64) == 0 && (cin % 64) == 0;
 }
+// 1x1 (cout = 64, cin a multiple of 256): workgroups per batch split
+int tsr_wgrad_b16k_1x1_wgs(int cout, int cin) { return cout == 64 && (cin % 256) == 0 ? cin / 256 : 0; }
 
-int tsr_wgrad_b16k(const void* a, int a_ctot, int a_coff, int cin, const void* dz, int dz_ctot, int dz_coff, int cout, int ks,
-                   float* slab, float* bias_slab, int nsplit, int B, int H, int W, hipStream_t st) {
+// `a_scale` / `a_shift` (the input is relu(a * scale + shift)): 1x1 only -- the 3x3 / 5x5 launches take a plain input
+int tsr_wgrad_b16k(const void* a, int a_ctot, int a_coff, int cin, const float* a_scale, const float* a_shift, const void* dz,
+                   int dz_ctot, int dz_coff, int cout, int ks, float* slab, float* bias_slab, int nsplit, int B, int H, int W,
+                   hipStream_t st) {
   WgradBArgs g;
-  g.a = (const char*)a; g.a_ctot = a_ctot; g.a_coff = a_coff; g.cin = cin;
+  g.a = (const char*)a; g.a_ctot = a_ctot; g.a_coff = a_coff; g.cin = cin; g.a_scale = a_scale; g.a_shift = a_shift;
   g.dz = (const char*)dz; g.dz_ctot = dz_ctot; g.dz_coff = dz_coff; g.cout = cout;
   g.slab = slab; g.bslab = bias_slab; g.B = B; g.H = H; g.W = W; g.nsplit = nsplit;
   g.tiles_x = (W + 7) / 8; g.tiles_y = (H + 3) / 4;
+  // (a 16-wave form of the 1x1 tile -- WM = 32 -- and ring depths 5 / 6 measured the same as this one)
+  if (ks == 1) return a_scale ? wgb_launch<1, 1, 64, 256, 64, true>(g, st) : wgb_launch<1, 1, 64, 256, 64, false>(g, st);
+  if (a_scale) return TSR_ERR_ARG;
   const bool big5 = (cout % 128) == 0 && (cin % 128) == 0, big3 = (cout % 128) == 0 && (cin % 64) == 0;
   if (ks == 5) return big5 ? wgb_launch<5, 1, 128, 128, 64>(g, st) : wgb_launch<5, 2, 64, 64, 32>(g, st);
   return big3 ? wgb_launch<3, 3, 128, 64, 32>(g, st) : wgb_launch<3, 3, 64, 64, 32>(g, st);

@@ -852,6 +852,8 @@ static int launch_tr16(const WgradTArgs& g, hipStream_t st) {
   }
 }
 
+int tsr_wgrad_b16k_1x1_wgs(int cout, int cin);          // wgrad_b16k.hip
+
 template <int KS> static int tr16_wgs(int cout, int cin, int planes) {
   if (planes == 3) {
     typedef WgradTCfg<KS, 3> C;
@@ -865,6 +867,7 @@ template <int KS> static int tr16_wgs(int cout, int cin, int planes) {
 
 // workgroups one batch split of this layer launches (the caller sizes nsplit so that splits x this fills the chip)
 extern "C" int tsr_conv2d_wgrad_wgs_per_split(int cout, int cin, int ks, int planes) {
+  if (planes == -1 && ks == 1 && tsr_wgrad_b16k_1x1_wgs(cout, cin)) return tsr_wgrad_b16k_1x1_wgs(cout, cin);      // wgrad_b16k.hip
   return ks == 1 ? tr16_wgs<1>(cout, cin, planes) : (ks == 3 ? tr16_wgs<3>(cout, cin, planes) : tr16_wgs<5>(cout, cin, planes));
 }
 
@@ -873,7 +876,7 @@ extern "C" int tsr_conv2d_wgrad_wgs_per_split(int cout, int cin, int ks, int pla
 extern "C" int tsr_conv2d_wgrad_splits(int cout, int cin, int ks, int planes, int B, int H, int W) {
   const int wgs = tsr_conv2d_wgrad_wgs_per_split(cout, cin, ks, planes);
   const int ci_big = planes == 3 ? 64 : (ks == 3 ? 64 : 128);
-  const bool big = tr16_big(cout, cin, ci_big);
+  const bool big = tr16_big(cout, cin, ci_big) || (planes == -1 && ks == 1 && tsr_wgrad_b16k_1x1_wgs(cout, cin));   // 8-wave tiles
   const long items = (long)B * ((H + 3) / 4) * ((W + 7) / 8);
   long ns = (big ? 256 : 512) / wgs;
   if (ns < 1) ns = 1;
@@ -882,8 +885,9 @@ extern "C" int tsr_conv2d_wgrad_splits(int cout, int cin, int ks, int planes, in
 }
 
 bool tsr_wgrad_b16k_ok(int cout, int cin, int ks, int H, int W, int a_ctot, int dz_ctot);            // wgrad_b16k.hip
-int tsr_wgrad_b16k(const void* a, int a_ctot, int a_coff, int cin, const void* dz, int dz_ctot, int dz_coff, int cout, int ks,
-                   float* slab, float* bias_slab, int nsplit, int B, int H, int W, hipStream_t st);
+int tsr_wgrad_b16k(const void* a, int a_ctot, int a_coff, int cin, const float* a_scale, const float* a_shift, const void* dz,
+                   int dz_ctot, int dz_coff, int cout, int ks, float* slab, float* bias_slab, int nsplit, int B, int H, int W,
+                   hipStream_t st);
 
 int tsr_conv2d_wgrad_tr16(const float* a, int a_ctot, int a_coff, int cin, const float* a_scale, const float* a_shift,
                           const float* dz, int dz_ctot, int dz_coff, int cout, int ks, int planes,
@@ -907,8 +911,10 @@ int tsr_conv2d_wgrad_tr16(const float* a, int a_ctot, int a_coff, int cin, const
   }
   if (planes == -1) {       // bf16 tensors (activation storage of the "bf16" configurations), one bf16 plane
     // no fused input transform: nothing to compute while staging -- the LDS-DMA kernel (same tiles, splits and slabs)
-    if (!a_scale && tsr_wgrad_b16k_ok(cout, cin, ks, H, W, a_ctot, dz_ctot))
-      return tsr_wgrad_b16k(a, a_ctot, a_coff, cin, dz, dz_ctot, dz_coff, cout, ks, slab, bias_slab, nsplit, B, H, W, st);
+    // (the 1x1 `confusion` too: its input transform runs in LDS behind the DMA)
+    if ((!a_scale || ks == 1) && tsr_wgrad_b16k_ok(cout, cin, ks, H, W, a_ctot, dz_ctot))
+      return tsr_wgrad_b16k(a, a_ctot, a_coff, cin, a_scale, a_shift, dz, dz_ctot, dz_coff, cout, ks, slab, bias_slab, nsplit, B,
+                            H, W, st);
     if (ks == 1) return launch_tr16<1, 1, false, true>(g, st);
     if (ks == 3) return launch_tr16<3, 1, false, true>(g, st);
     return launch_tr16<5, 1, false, true>(g, st);
