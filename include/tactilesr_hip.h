@@ -157,6 +157,10 @@ int tsr_pack_w2_b16k(const float* w2_64x128, void* w_packed, void* stream);
  * tsr_pack_conv_weight_b16k) and epi_mode 0 with that pack; nsplit = -4 is epi_mode 1 of the stage-1 pair of an MSRB
  * (conv_3_1 || conv_5_1 as one 5x5 launch with 128 output channels, weights from tsr_pack_conv_weight_b16k_pair). */
 int tsr_conv2d_ex_dgrad_b16k(int nprime, int cout, int ks);
+/* 1 if tsr_conv2d_ex accepts nsplit = -3 for the FORWARD of a 1x1 conv of this shape whose input is VIRTUAL (in_scale /
+ * in_shift set: relu(z * scale + shift) of the stored pre-BatchNorm tensor, formed in LDS behind the DMA): epi_mode 0 (shift =
+ * bias, residual, ReLU), weights from tsr_pack_conv_weight_b16k(.., ks = 1).  csrc/conv1x1_b16k.hip. */
+int tsr_conv2d_ex_fwd1x1_b16k(int cout, int cin);
 int tsr_pack_conv_weight_dgrad_b16k(const float* w_oihw, void* w_packed, int cout, int cin, int ks, int ci0, void* stream);
 long long tsr_conv_weight_b16k_pair_elems(int cin);
 int tsr_pack_conv_weight_b16k_pair(const float* w128_oihw5, void* w_packed, int cin, void* stream);

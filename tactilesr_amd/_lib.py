@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TSR_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libtactilesr_hip.so")   # override: kernel A/B experiments
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _P, _I, _F, _L = c_void_p, c_int, c_float, c_longlong
 
@@ -73,6 +73,7 @@ SIGNATURES = {
     "tsr_bn_bwd_apply_b16": [_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _I, _P],
     "tsr_bn_relu_b16": [_P, _I, _I, _I, _P, _P, _P, _I, _I, _P],
     "tsr_conv2d_wgrad_b16k": [_I, _I, _I],
+    "tsr_conv2d_ex_fwd1x1_b16k": [_I, _I],
     "tsr_stem_wgrad_b16": [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P, _I, _I, _P],
     "tsr_head_bwd_b16": [_P, _P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P],
     "tsr_target_prep": [_P, _P, _F, _I, _I, _I, _I, _I, _P],

@@ -766,7 +766,8 @@ static bool b16k_shape_ok(int cout, int cin, int ks) {
 }
 
 extern "C" int tsr_pack_conv_weight_b16k(const float* w_oihw, void* w_packed, int cout, int cin, int ks, void* stream) {
-  if (!w_oihw || !w_packed || !b16k_shape_ok(cout, cin, ks)) return TSR_ERR_ARG;
+  // (ks = 1: the forward of a 1x1 conv with 64 output channels, conv1x1_b16k.hip -- the same slab layout with one tap)
+  if (!w_oihw || !w_packed || !(b16k_shape_ok(cout, cin, ks) || (ks == 1 && cout == 64 && cin > 0 && (cin & 31) == 0))) return TSR_ERR_ARG;
   const size_t total = (size_t)cout * cin * ks * ks;
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(pack_b16k_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
@@ -791,6 +792,10 @@ extern "C" int tsr_conv2d_ex_dgrad_b16k(int nprime, int cout_f, int ks) {
   return nprime == 128 && (ks == 3 || ks == 5) && cout_f > 0 && (cout_f & 31) == 0;
 }
 
+// 1 if tsr_conv2d_ex accepts nsplit = -3 for the FORWARD of a 1x1 conv of this shape on a virtual input (in_scale / in_shift
+// set; epi_mode 0: bias, residual, ReLU; weights from tsr_pack_conv_weight_b16k): conv1x1_b16k.hip
+extern "C" int tsr_conv2d_ex_fwd1x1_b16k(int cout, int cin) { return cout == 64 && (cin == 256 || cin == 128); }
+
 extern "C" int tsr_pack_conv_weight_dgrad_b16k(const float* w_oihw, void* w_packed, int cout, int cin, int ks, int ci0, void* stream) {
   if (!w_oihw || !w_packed || !tsr_conv2d_ex_dgrad_b16k(128, cout, ks) || ci0 < 0 || ci0 + 128 > cin) return TSR_ERR_ARG;
   const size_t total = (size_t)128 * cout * ks * ks;
@@ -805,7 +810,10 @@ extern "C" int tsr_pack_conv_weight_dgrad_b16k(const float* w_oihw, void* w_pack
 // pack, or the dgrad pack for an unmasked partial gradient), 1 = raw output + Welford partials (forward pack), 2 = the masked
 // dgrad (dgrad pack).  nsplit = -4 (`pair`): epi_mode 1 of the stage-1 pair (one 128-channel output, two convs).
 int tsr_dgrad1x1_b16k(const ConvArgs& a, hipStream_t st);       // conv1x1_b16k.hip
+int tsr_fwd1x1_b16k(const ConvArgs& a, int cout, hipStream_t st);
 int tsr_conv_b16k_ex(const ConvArgs& a, int cout, int ks, bool pair, hipStream_t st) {
+  // the forward of a 1x1 conv with 64 output channels on a VIRTUAL input (the only form here that takes an input transform)
+  if (ks == 1 && cout == 64 && a.epi_mode == 0 && !pair) return tsr_fwd1x1_b16k(a, cout, st);
   if (!tsr_conv2d_ex_dgrad_b16k(cout, a.cin, ks) || a.in_scale || a.res_scale ||
       (long long)4 * a.in_ctot * a.H * a.W * 2 >= 0x7fffffffLL)
     return TSR_ERR_ARG;

@@ -351,10 +351,15 @@ class TrainEngine:
         s.bn_c2[:, 128:256] = self._conv_bn(c, A1, blk.conv_5_2[0], blk.conv_5_2[1], s.cat2, 256, 128, am_c2)
         A2 = Act(s.cat2, 256, 0, 256, s.bn_c2[0], s.bn_c2[1], s.bn_c2[2], s.bn_c2[3], amax=am_c2)
         s.A1, s.A2 = A1, A2
-        wp, wis = self._packw(c, blk.confusion)
-        conv_ex(B=c.B, H=c.H, W=c.W, src=A2, w=wp, cout=64, ks=1, out=out, out_ctot=octot, out_coff=ocoff,
-                shift=blk.confusion.bias.detach(), relu=1, res=X, nsplit=self.nsplit, w_amax=wis,
-                out_amax=am_o)
+        if self.io16 and _lib.load().tsr_conv2d_ex_fwd1x1_b16k(64, 256):
+            # bf16 storage: the virtual 256-channel input is transformed in LDS behind the DMA (csrc/conv1x1_b16k.hip)
+            wp, wis, nsc = self._packw_b16k(blk.confusion), None, -3
+        else:
+            (wp, wis), nsc = self._packw(c, blk.confusion), self.nsplit
+        with self._timed(("fwd", 1, 64, 256)):
+            conv_ex(B=c.B, H=c.H, W=c.W, src=A2, w=wp, cout=64, ks=1, out=out, out_ctot=octot, out_coff=ocoff,
+                    shift=blk.confusion.bias.detach(), relu=1, res=X, nsplit=nsc, w_amax=wis,
+                    out_amax=am_o)
         s.Y = Act(out, octot, ocoff, 64, amax=am_o)
         return s
 

@@ -335,6 +335,53 @@ def test_conv2d_train_forward_pair_bf16_storage_b16k(T, cin, B, H, W):
     assert e_m < 1e-5 and e_v < 1e-5
 
 
+@pytest.mark.parametrize("cin,B,H,W,relu,res", [(256, 3, 13, 21, 1, True), (256, 2, 40, 40, 1, "virtual"), (128, 70, 12, 12, 0, False),
+                                               (256, 1, 5, 3, 1, True)])
+def test_conv1x1_forward_virtual_input_bf16_storage_b16k(T, cin, B, H, W, relu, res):
+    """The forward of the MSRB's 1x1 `confusion` with bf16 storage (tsr_conv2d_ex, nsplit = -3, ks = 1, epi_mode 0;
+    csrc/conv1x1_b16k.hip): the input is VIRTUAL -- relu(z * in_scale + in_shift) of the stored bf16 z, formed in LDS behind the
+    DMA, rounded to bf16 like the register-staging kernels do -- the weight bf16, bias + residual + ReLU in the epilogue.
+    Yardstick: the same arithmetic in fp64 on the bf16-ROUNDED operands; >= 99 % of the outputs identical, the rest within
+    one bf16 ulp (+ the fp32-accumulation floor).  Ragged pixel counts, a C_in of 128, with / without residual and ReLU."""
+    from tactilesr_amd.model._train import conv_ex, Act
+    from tactilesr_amd._lib import load, call, ptr, stream, c_int as I
+    g = torch.Generator().manual_seed(cin + B + H)
+    q = lambda t: t.bfloat16().float()
+    z = q(torch.randn(B, cin, H, W, generator=g))
+    sc, sh = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.3
+    w = torch.randn(64, cin, 1, 1, generator=g) * 0.08
+    bias = torch.randn(64, generator=g) * 0.1
+    r = q(torch.randn(B, 64, H, W, generator=g))
+    lib = load()
+    assert lib.tsr_conv2d_ex_fwd1x1_b16k(64, cin) == 1
+    a = q(F.relu(torch.addcmul(sh.view(1, -1, 1, 1), z, sc.view(1, -1, 1, 1))))
+    rsc, rsh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    rterm = 0.0
+    if res == "virtual":        # the first MSRB's residual: relu(r * scale + shift) of a stored pre-BatchNorm tensor (fp32, not rounded)
+        rterm = F.relu(torch.addcmul(rsh.view(1, -1, 1, 1), r, rsc.view(1, -1, 1, 1))).double()
+    elif res:
+        rterm = r.double()
+    ref = F.conv2d(a.double(), q(w).double()) + bias.double().view(1, -1, 1, 1) + rterm
+    ref = F.relu(ref) if relu else ref
+    r16 = ref.float().bfloat16().float()
+    zd = T.to_cb16(z.cuda(), cin + 16, 16).to(torch.bfloat16)
+    rd = T.to_cb16(r.cuda(), 96, 32).to(torch.bfloat16)
+    wp = torch.empty(lib.tsr_conv_weight_b16k_elems(64, cin, 1), dtype=torch.bfloat16, device="cuda")
+    call("tsr_pack_conv_weight_b16k", ptr(w.cuda().contiguous()), ptr(wp), I(64), I(cin), I(1), stream())
+    out = torch.full((B * 80 * H * W,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    conv_ex(B=B, H=H, W=W, src=Act(zd, cin + 16, 16, cin, sc.cuda(), sh.cuda()), w=wp, cout=64, ks=1, out=out, out_ctot=80,
+            out_coff=16, shift=bias.cuda(), relu=relu,
+            res=(Act(rd, 96, 32, 64, rsc.cuda(), rsh.cuda()) if res == "virtual" else Act(rd, 96, 32, 64)) if res else None, nsplit=-3)
+    full = T.from_cb16(out, B, 80, H, W).float().cpu()
+    got = full[:, 16:80]
+    d = (got - r16).abs()
+    same = float((d == 0).float().mean())
+    bad = d > torch.maximum(1.01 * r16.abs() * 2.0 ** -7, torch.full_like(r16, 3e-6 * float(r16.abs().max())))
+    print(f"[b16k 1x1 fwd] {cin}->64 B={B} {H}x{W}: identical {same:.5f}, beyond one ulp {int(bad.sum())}")
+    assert same >= 0.99 and not bad.any()
+    assert torch.isnan(full[:, :16]).all()          # outside the slice: untouched
+
+
 def _subs(t, k=512):
     t = t.detach().flatten()
     return t[:: max(1, t.numel() // k)].cpu().numpy()
