@@ -449,14 +449,37 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
     __syncthreads();
     if (ph < ngrp) {
       const size_t ho = (((size_t)b * (h_ctot >> 4) + (c >> 4)) * HW) * 16 + (c & 15);
-      for (int q = ph; q < HW; q += ngrp) {
-        const float hv = tsr_ld1<B16>(h0, ho + (size_t)q * 16);
-        const int y = q / W, x = q - y * W;
+      // rows y = ph, ph + ngrp, .. in chunks of PU pixels: the chunk's activation loads are requested together (one dependent
+      // 2- / 4-byte load per pixel was a chain of memory latencies) and the 3x3 window of the masked output gradient slides in
+      // registers (out pixel p = q - (tap - 1); padded index + 1: tap (kh, kw) of pixel x reads column x - kw + 2)
+      constexpr int PU = 8;
+      for (int y = ph; y < H; y += ngrp) {
+        for (int x0 = 0; x0 < W; x0 += PU) {
+          float hv[PU];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+          for (int u = 0; u < PU; ++u) {
+            const int x = x0 + u;
+            const float v = tsr_ld1<B16>(h0, ho + (size_t)(y * W + (x < W ? x : x0)) * 16);
+            hv[u] = x < W ? v : 0.f;
+          }
+          float col[3][3];                     // col[j % 3][kh] = dpt[y - kh + 2][x0 + j]
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw)   // out pixel p = q - (tap - 1); padded index +1
-            acc[kh * 3 + kw] = fmaf(hv, dpt[(y - kh + 2) * WP + (x - kw + 2)], acc[kh * 3 + kw]);
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) col[j][kh] = dpt[(y - kh + 2) * WP + x0 + j];
+#pragma unroll
+          for (int u = 0; u < PU; ++u) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+              for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = fmaf(hv[u], col[(u + 2 - kw) % 3][kh], acc[kh * 3 + kw]);
+            if (u + 1 < PU) {
+              const int xn = x0 + u + 3 < WP ? x0 + u + 3 : WP - 1;
+#pragma unroll
+              for (int kh = 0; kh < 3; ++kh) col[u % 3][kh] = dpt[(y - kh + 2) * WP + xn];
+            }
+          }
+        }
       }
     }
   }
