@@ -225,8 +225,15 @@ class TrainEngine:
              ptr(conv_bias.detach() if conv_bias is not None else None), ptr(bn.weight.detach()),
              ptr(bn.bias.detach()), ptr(bn.running_mean), ptr(bn.running_var), _F(bn.momentum), _F(bn.eps),
              ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), ptr(c.work), stream())
-        bn.num_batches_tracked.add_(1)
+        c.nbt.append(bn.num_batches_tracked)      # (+1 for all of them in one launch at the end of forward)
         return vec   # rows: scale, shift, xhat_a, xhat_b
+
+    @staticmethod
+    def _bump_nbt(c):
+        """num_batches_tracked += 1 of every BatchNorm layer the forward ran, as ONE launch (27 one-element launches before)."""
+        if c.nbt:
+            torch._foreach_add_(c.nbt, 1)
+            c.nbt = []
 
     def _stem(self, x, ctot_in, coff, A, hin, win, sf, w, dst, relu, B, am):
         """bilinear x sf + conv 3 -> 64 (raw or ReLU'd) into a 64-channel CB16 buffer of the engine's storage type."""
@@ -294,7 +301,7 @@ class TrainEngine:
              ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), ptr(c.work), stream())
         b3.running_mean.copy_(rm[:64]); b5.running_mean.copy_(rm[64:])
         b3.running_var.copy_(rv[:64]); b5.running_var.copy_(rv[64:])
-        b3.num_batches_tracked.add_(1); b5.num_batches_tracked.add_(1)
+        c.nbt += [b3.num_batches_tracked, b5.num_batches_tracked]
         return vec
 
     def _conv_bn(self, c: _Ctx, src: Act, conv, bn, out, out_ctot, out_coff, out_amax=None):
@@ -317,6 +324,7 @@ class TrainEngine:
         c = _Ctx()
         HW = H * W
         c.B, c.H, c.W, c.HW = B, H, W, HW
+        c.nbt = []          # BatchNorm num_batches_tracked counters this forward updates (bumped together: _bump_nbt)
         lib = _lib.load()
         c.entries = lib.tsr_conv2d_slab_entries(B, H, W)
         c.st_entries = st_entries = lib.tsr_cb16_stats_entries(B, HW)
@@ -465,6 +473,7 @@ class TrainEngine:
         call("tsr_head_fwd_b16" if self.io16 else "tsr_head_fwd", ptr(c.h0), _I(128), _I(128),
              ptr(m.output_layer[2].weight.detach()), ptr(out), _I(1), _I(B), _I(H), _I(W), stream())
         c.out = out
+        self._bump_nbt(c)
         self.last_ctx = c if self.keep_ctx else None
         return out, c
 
@@ -570,14 +579,19 @@ class TrainEngine:
                     out_amax=out_amax)
         c.last_entries = self._entries(c, nprime, ks, ns)      # what a following _bn_bwd reduces
 
-    def _bn_bwd(self, c, g_buf, g_ctot, g_coff, z: Act, zoff, C, bn_vec, bn_mod, grads, name, out_amax=None):
+    def _bn_bwd(self, c, g_buf, g_ctot, g_coff, z: Act, zoff, C, bn_vec, bn_mod, grads, name, out_amax=None, gnames=None):
         """Finish BatchNorm backward for C channels whose masked gradient g sits in g_buf (slab sums
-        were just produced by the dgrad epilogue over the same C channels)."""
+        were just produced by the dgrad epilogue over the same C channels).  `gnames` = (weight, bias) parameter names:
+        dgamma / dbeta are then written straight into their gradient slots (no copy launches)."""
         dev = g_buf.device
         out = torch.empty(5, C, dtype=torch.float32, device=dev)
+        dg, db = (grads.dest(gnames[0], (C,)), grads.dest(gnames[1], (C,))) if gnames else (out[0], out[1])
         call("tsr_bn_bwd_finalize", ptr(c.slab), _I(c.last_entries), _I(C), _D(float(c.B * c.HW)),
-             ptr(bn_vec[0]), ptr(bn_vec[2]), ptr(bn_vec[3]), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]),
+             ptr(bn_vec[0]), ptr(bn_vec[2]), ptr(bn_vec[3]), ptr(dg), ptr(db), ptr(out[2]), ptr(out[3]),
              ptr(out[4]), ptr(c.work), stream())
+        if gnames:
+            grads.put(gnames[0], dg)
+            grads.put(gnames[1], db)
         if self.io16:
             call("tsr_bn_bwd_apply_b16", ptr(g_buf), _I(g_ctot), _I(g_coff), ptr(z.buf), _I(z.ctot), _I(z.coff + zoff),
                  ptr(out[2]), ptr(out[3]), ptr(out[4]), _I(C), _I(c.B), _I(c.HW), stream())
@@ -617,10 +631,8 @@ class TrainEngine:
             mk = Act(s.cat2, 256, o, 128, s.bn_c2[0, o:o + 128], s.bn_c2[1, o:o + 128], s.bn_c2[2, o:o + 128],
                      s.bn_c2[3, o:o + 128])
             self._dgrad(c, dpre, blk.confusion, o, 128, g2, 256, o, mask=mk, bn=True)
-            r = self._bn_bwd(c, g2, 256, o, Act(s.cat2, 256, 0, 256), o, 128, s.bn_c2[:, o:o + 128], bnm, grads,
-                             nm, out_amax=am_g2[half])
-            grads.put_copy(f"{name}{nm}.1.weight", r[0])
-            grads.put_copy(f"{name}{nm}.1.bias", r[1])
+            self._bn_bwd(c, g2, 256, o, Act(s.cat2, 256, 0, 256), o, 128, s.bn_c2[:, o:o + 128], bnm, grads,
+                         nm, out_amax=am_g2[half], gnames=(f"{name}{nm}.1.weight", f"{name}{nm}.1.bias"))
         if self.debug is not None:
             self.debug[f"{tag}.dz2"] = g2.clone()
         DZ32, DZ52 = Act(g2, 256, 0, 128, amax=am_g2[0]), Act(g2, 256, 128, 128, amax=am_g2[1])
@@ -709,9 +721,8 @@ class TrainEngine:
             dpre = self._msrb_bwd(c, c.blocks[i], m.patternFeatureExtra_layer[i], f"patternFeatureExtra_layer.{i}", dpre,
                                   grads, new_amax, buf, tag=f"msrb{i}")
         # X of block 0 is the fuse conv's relu(bn(zf)): finish its BN backward -> dzf
-        r = self._bn_bwd(c, dpre.buf, 64, 0, Act(c.zf, 64, 0, 64), 0, 64, c.bnf, None, grads, "", out_amax=dpre.amax)
-        grads.put_copy("inputContact_layer.1.weight", r[0])
-        grads.put_copy("inputContact_layer.1.bias", r[1])
+        self._bn_bwd(c, dpre.buf, 64, 0, Act(c.zf, 64, 0, 64), 0, 64, c.bnf, None, grads, "", out_amax=dpre.amax,
+                     gnames=("inputContact_layer.1.weight", "inputContact_layer.1.bias"))
         T = m.seqsCnt
         AT = Act(c.catT, 64 * T, 0, 64 * T, c.bn2[0], c.bn2[1], c.bn2[2], c.bn2[3], amax=c.am_catT)
         self._wgrad(c, AT, dpre, m.inputContact_layer[0], grads, "inputContact_layer.0", False)
@@ -723,19 +734,16 @@ class TrainEngine:
                      c.bn2[3, o:o + 64])
             self._dgrad(c, dpre, m.inputContact_layer[0], o, 64, gT, 64 * T, o, mask=mk, bn=True)
             am_gT = new_amax()
-            r = self._bn_bwd(c, gT, 64 * T, o, Act(c.catT, 64 * T, 0, 64 * T), o, 64, c.bn2[:, o:o + 64], None, grads,
-                             "", out_amax=am_gT)
-            grads.put_copy(name + ".5.weight", r[0])
-            grads.put_copy(name + ".5.bias", r[1])
+            self._bn_bwd(c, gT, 64 * T, o, Act(c.catT, 64 * T, 0, 64 * T), o, 64, c.bn2[:, o:o + 64], None, grads,
+                         "", out_amax=am_gT, gnames=(name + ".5.weight", name + ".5.bias"))
             DZ2 = Act(gT, 64 * T, o, 64, amax=am_gT)
             v1 = c.bn1[t]
             A1 = Act(c.z1[t], 64, 0, 64, v1[0], v1[1], v1[2], v1[3], amax=c.am_z1[t])
             self._wgrad(c, A1, DZ2, seq[4], grads, name + ".4", False)
             g1 = buf(64)
             self._dgrad(c, DZ2, seq[4], 0, 64, g1, 64, 0, mask=A1, bn=True)
-            r = self._bn_bwd(c, g1, 64, 0, Act(c.z1[t], 64, 0, 64), 0, 64, v1, None, grads, "")
-            grads.put_copy(name + ".2.weight", r[0])
-            grads.put_copy(name + ".2.bias", r[1])
+            self._bn_bwd(c, g1, 64, 0, Act(c.z1[t], 64, 0, 64), 0, 64, v1, None, grads, "",
+                         gnames=(name + ".2.weight", name + ".2.bias"))
             ns = max(1, min(B, 2048))     # image splits: ~8 resident workgroups per CU hide the load latency
             sslab = torch.empty(ns * 64 * 27, dtype=torch.float32, device=dev)
             call("tsr_stem_wgrad_b16" if self.io16 else "tsr_stem_wgrad", ptr(c.x), _I(c.x.shape[1]), _I(m.axisCnt * t),
@@ -816,6 +824,7 @@ class BlockEngine(TrainEngine):
         out, am_o = buf(64), new_amax()
         fwd = self._msrb_fwd if self.kind == "msrb" else self._res_fwd
         c.s = fwd(c, self.block, X, out, 64, 0, am_o, new_amax, buf)
+        self._bump_nbt(c)
         self.last_ctx = c if self.keep_ctx else None
         return from_cb16(out, B, 64, H, W), c
 
