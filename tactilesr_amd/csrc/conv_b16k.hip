@@ -21,7 +21,10 @@
 // ahead, refilled in place as the rows of the step retire) during step s-1 only, so slab s+3 is requested at the START of
 // step s into the slot slab s just left and has two whole steps to land.  Per step and wave: 32 MFMAs, 12 ds_read_b128.
 // Forms: plain / FUSED (stage 2 of an MSRB + its 1x1 half) / PAIR (stage 1: conv_3_1 || conv_5_1 on one halo; the 3x3
-// half's MFMAs and fragment reads are skipped on the 16 outer taps).
+// half's MFMAs and fragment reads are skipped on the 16 outer taps).  The bf16-storage TRAIN step runs its 128-channel
+// launches on the same loop (tsr_conv2d_ex, nsplit = -3 / -4): DGRAD (ReLU-mask + BatchNorm-backward-sum epilogue), TRAIN and
+// PAIR_TRAIN (raw output + Welford partials) -- their inputs are stored gradients, stored block outputs or materialised
+// activations (tsr_bn_relu_b16), i.e. nothing needs transforming while staging.
 #include "tsr_common.h"
 #include "conv_args.h"
 #include "tactilesr_hip.h"

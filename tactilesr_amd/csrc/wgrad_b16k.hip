@@ -23,6 +23,11 @@
 //     immediate offset of the B fragment's address.
 //   * The bias gradient (workgroups cib = 0, kg = 0) is summed from the A fragments: wave (wm, wn) sums C_out tile wn of its
 //     wm, 16 VALU operations per item.
+//   * XF instantiations (the 1x1 `confusion`: one workgroup = 64 x 256 outputs) DO take a fused input transform: the raw z
+//     tile lands in LDS like any other and every thread rewrites its share in place -- bf16(relu(z * scale + shift)), the value
+//     the register-staging kernel formed -- one step AHEAD of the step that multiplies the item (4-slot ring).  The 3x3 / 5x5
+//     launches of a virtual input read its materialised form instead (tsr_bn_relu_b16, at the end of this file): that tensor is
+//     shared with the forward convolutions of the same stage.
 #include "tsr_common.h"
 #include "tactilesr_hip.h"
 #include <type_traits>
