@@ -235,33 +235,40 @@ __device__ __forceinline__ void bilin_src_t(int dst, float scale, int n_in, int&
   lam = src - (float)i0;
 }
 
-// one workgroup per image-split; thread = (co = tid&63, pixel phase = tid>>6)
+// one workgroup per (image split, band of rows); thread = (co = tid&63, pixel phase = tid>>6).  `bands` > 1 for tall images:
+// a workgroup then holds only its band of the upsampled image (+ one halo row each side) in LDS -- at 100 x 100 the whole
+// image is 125 KB, i.e. one workgroup per CU -- and the slab entries are (band, image split) pairs, nsplit in all.
 template <bool B16>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ lr, int lr_ctot, int lr_coff,
                                                          int hin, int win, int sf, const float* __restrict__ dz,
                                                          int dz_ctot, int dz_coff, float* __restrict__ slab, int B,
-                                                         int nsplit) {
+                                                         int nsplit, int bands) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int H = hin * sf, W = win * sf, WP = W + 2, HP = H + 2;
+  const int Himg = hin * sf, W = win * sf, WP = W + 2;
+  const int RBAND = (Himg + bands - 1) / bands;
+  const int yb0 = blockIdx.y * RBAND;
+  const int H = Himg - yb0 < RBAND ? Himg - yb0 : RBAND;      // rows of this band
+  const int HP = RBAND + 2;
   float* tax = smem;                                   // [3][hin*win]
-  float* up = smem + ((3 * hin * win + 3) & ~3);       // [3][HP][WP] zero padded
+  float* up = smem + ((3 * hin * win + 3) & ~3);       // [3][HP][WP] zero padded: band rows yb0 - 1 .. yb0 + RBAND
   const int tid = threadIdx.x;
   const int co = tid & 63, ph = tid >> 6;
-  const int HW = H * W;
+  const int HW = Himg * W;
   float acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.f;
   const float sc = 1.0f / (float)sf;
   const int oc = dz_coff + co;
+  nsplit /= bands;                                     // image splits
   for (int b = blockIdx.x; b < B; b += nsplit) {
     __syncthreads();
     for (int i = tid; i < 3 * hin * win; i += 256) tax[i] = lr[((size_t)b * lr_ctot + lr_coff) * hin * win + i];
     __syncthreads();
     for (int i = tid; i < 3 * HP * WP; i += 256) {
       const int c = i / (HP * WP), rem = i - c * (HP * WP);
-      const int gy = rem / WP - 1, gx = rem % WP - 1;
+      const int gy = yb0 + rem / WP - 1, gx = rem % WP - 1;
       float v = 0.f;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      if (gy >= 0 && gy < Himg && gx >= 0 && gx < W) {
         int ya, yb, xa, xb; float ly, lx;
         bilin_src_t(gy, sc, hin, ya, yb, ly);
         bilin_src_t(gx, sc, win, xa, xb, lx);
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
 #pragma unroll
         for (int u = 0; u < PU; ++u) {
           const int x = x0 + u;
-          const float v = tsr_ld1<B16>(dz, dzo + (size_t)(y * W + (x < W ? x : x0)) * 16);
+          const float v = tsr_ld1<B16>(dz, dzo + (size_t)((yb0 + y) * W + (x < W ? x : x0)) * 16);
           d[u] = x < W ? v : 0.f;                  // (a chunk's tail beyond the row adds nothing; its window reads stay in the padding)
         }
         float col[3][9];                           // col[(x - x0) % 3][c * 3 + kh] = up[c][y + kh][x]
@@ -315,7 +322,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   for (int k = 0; k < 27; ++k) red[(ph * 64 + co) * 27 + k] = acc[k];
   __syncthreads();
   for (int i = tid; i < 64 * 27; i += 256)
-    slab[(size_t)blockIdx.x * 64 * 27 + i] = (red[i] + red[64 * 27 + i]) + (red[2 * 64 * 27 + i] + red[3 * 64 * 27 + i]);
+    slab[((size_t)blockIdx.y * nsplit + blockIdx.x) * 64 * 27 + i] =
+        (red[i] + red[64 * 27 + i]) + (red[2 * 64 * 27 + i] + red[3 * 64 * 27 + i]);
 }
 
 static int stem_wgrad_impl(const float* lr, int lr_ctot, int lr_coff, int hin, int win, int sf,
@@ -324,7 +332,12 @@ static int stem_wgrad_impl(const float* lr, int lr_ctot, int lr_coff, int hin, i
   if (!lr || !dz || !slab || nsplit <= 0 || B <= 0 || (dz_ctot & 15) || (dz_coff & 15) || dz_coff + 64 > dz_ctot)
     return TSR_ERR_ARG;
   const int H = hin * sf, W = win * sf;
-  size_t fl = ((3 * hin * win + 3) & ~3) + (size_t)3 * (H + 2) * (W + 2);
+  // bands of rows per image: the band (+ halo) within 32 KB of LDS, if the splits divide (slab entries = nsplit either way)
+  int bands = 1;
+  while (bands < 8 && (size_t)3 * ((H + bands - 1) / bands + 2) * (W + 2) * 4 > 32 * 1024 && nsplit % (2 * bands) == 0 &&
+         nsplit / (2 * bands) >= 1)
+    bands *= 2;
+  size_t fl = ((3 * hin * win + 3) & ~3) + (size_t)3 * ((H + bands - 1) / bands + 2) * (W + 2);
   if (fl < 4 * 64 * 27) fl = 4 * 64 * 27;
   if (fl * 4 > 160 * 1024) return TSR_ERR_ARG;
   static bool attr_set = false;
@@ -334,11 +347,11 @@ static int stem_wgrad_impl(const float* lr, int lr_ctot, int lr_coff, int hin, i
     attr_set = true;
   }
   if (b16)
-    hipLaunchKernelGGL(stem_wgrad_kernel<true>, dim3(nsplit), dim3(256), fl * 4, (hipStream_t)stream, lr, lr_ctot, lr_coff,
-                       hin, win, sf, dz, dz_ctot, dz_coff, slab, B, nsplit);
+    hipLaunchKernelGGL(stem_wgrad_kernel<true>, dim3(nsplit / bands, bands), dim3(256), fl * 4, (hipStream_t)stream, lr, lr_ctot,
+                       lr_coff, hin, win, sf, dz, dz_ctot, dz_coff, slab, B, nsplit, bands);
   else
-    hipLaunchKernelGGL(stem_wgrad_kernel<false>, dim3(nsplit), dim3(256), fl * 4, (hipStream_t)stream, lr, lr_ctot, lr_coff,
-                       hin, win, sf, dz, dz_ctot, dz_coff, slab, B, nsplit);
+    hipLaunchKernelGGL(stem_wgrad_kernel<false>, dim3(nsplit / bands, bands), dim3(256), fl * 4, (hipStream_t)stream, lr, lr_ctot,
+                       lr_coff, hin, win, sf, dz, dz_ctot, dz_coff, slab, B, nsplit, bands);
   return tsr_check_launch();
 }
 

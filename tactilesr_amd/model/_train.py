@@ -676,7 +676,7 @@ class TrainEngine:
         new_amax = self._amax_pool(c, dev)      # a gradient tensor consumed by an MFMA launch carries max|.|
         dout = dout.contiguous().float()
         # ---- head: out = relu(conv(h0)), h0 = relu(conv(hcat))
-        ns = max(1, min(B, 2048))     # image splits: ~8 resident workgroups per CU hide the load latency
+        ns = max(1, min(B * (8 if H > 64 else 1), 2048))     # (image split, row band) entries: ~8 resident workgroups per CU
         dz_h0 = buf(128)
         am_dzh0 = new_amax()
         wslab = torch.empty(ns * 128 * 9, dtype=torch.float32, device=dev)
@@ -744,7 +744,7 @@ class TrainEngine:
             self._dgrad(c, DZ2, seq[4], 0, 64, g1, 64, 0, mask=A1, bn=True)
             self._bn_bwd(c, g1, 64, 0, Act(c.z1[t], 64, 0, 64), 0, 64, v1, None, grads, "",
                          gnames=(name + ".2.weight", name + ".2.bias"))
-            ns = max(1, min(B, 2048))     # image splits: ~8 resident workgroups per CU hide the load latency
+            ns = max(1, min(B * (8 if H > 64 else 1), 2048))     # (image split, row band) entries
             sslab = torch.empty(ns * 64 * 27, dtype=torch.float32, device=dev)
             call("tsr_stem_wgrad_b16" if self.io16 else "tsr_stem_wgrad", ptr(c.x), _I(c.x.shape[1]), _I(m.axisCnt * t),
                  _I(c.hin), _I(c.win), _I(m.scale_factor), ptr(g1), _I(64), _I(0), ptr(sslab), _I(ns), _I(B), stream())
