@@ -220,6 +220,8 @@ def run_legs(args, dev):
     leg("seqs_eval_bf16_b512", run_infer, seqs=True, impl="bf16", impl_given=True, steps=3, warmup=1,    # configs[4] is a bf16 configuration
         no_cpu_baseline=True)
     leg("seqs_train_b256", run_train, mode="train", seqs=True, steps=3, warmup=1)
+    leg("seqs_train_bf16_b256", run_train, mode="train", seqs=True, impl="bf16", impl_given=True, steps=3, warmup=1,   # configs[4] as worded
+        no_cpu_baseline=True)
     try:
         legs["eval_b8_latency"] = small_batch_latency(dev)
     except Exception as e:

@@ -786,6 +786,46 @@ def test_bf16_train_mode_is_a_reduced_precision_of_the_same_step(T, golden):
         assert cos > 0.98, (k, cos)
 
 
+def test_seqs_bf16_storage_train_step_B256_full_size_tiling_invariance(T):
+    """BASELINE configs[4] as worded ("tactileSRSeqs (T=8) 4x4 -> 100x100, bf16") at the size bench.py's `seqs_train_bf16_b256`
+    leg runs: the full sf = 25 / T = 8 model (6 MSRBs), bf16 activation / gradient storage, B = 256 = 2 base frame-stacks x
+    128.  Replicas bit-identical; loss within 2e-3 of the bf16-EMULATING oracle's on the 2 base stacks; every parameter gradient
+    pointing the emulated one's way (cosine >= 0.99: eight plain-bf16 stems feed a 512-channel fuse conv, the small Seqs
+    reduced-precision test measures 0.978 against fp64 there) with the norm within 5 %."""
+    torch.cuda.empty_cache()
+    cfg = dict(scale_factor=25, seqsCnt=8)
+    torch.manual_seed(4242)
+    m = T.TactileSR(**cfg)
+    m.train_impl = "bf16"
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(4243)
+    LRb, HRb = torch.rand(2, 24, 4, 4, generator=g) * 8, torch.rand(2, 1, 100, 100, generator=g) * 25
+    m = m.cuda().train()
+    out = m(LRb.repeat(128, 1, 1, 1).cuda())
+    assert m.train_engine().io16
+    loss = F.mse_loss(out, HRb.repeat(128, 1, 1, 1).cuda())
+    loss.backward()
+    o = out.view(128, 2, -1)
+    assert torch.equal(o, o[:1].expand_as(o))
+    l_e, g_e, _, _ = _emulated_step(sd, LRb, HRb, scale_factor=25)
+    assert abs(loss.item() - l_e) <= 2e-3 * abs(l_e), (loss.item(), l_e)
+    worst = 1.0
+    gmax = float(max(v.abs().max() for v in g_e.values()))
+    for k, p in m.named_parameters():
+        ref = g_e[k].double().flatten()
+        if float(ref.abs().max()) < 1e-6 * gmax:
+            continue
+        got = p.grad.detach().cpu().double().flatten()
+        cos = float(got @ ref / (got.norm() * ref.norm()).clamp_min(1e-30))
+        worst = min(worst, cos)
+        assert cos >= 0.99, (k, cos)
+        assert abs(float(got.norm() / ref.norm()) - 1.0) < 5e-2, (k, float(got.norm() / ref.norm()))
+    print(f"[Seqs bf16-storage train B=256] loss {abs(loss.item() - l_e) / abs(l_e):.2e} from the emulated loss, worst gradient "
+          f"cosine {worst:.5f}")
+    del m, out, loss
+    torch.cuda.empty_cache()
+
+
 def _emulated_step(sd, LR, HR, **kw):
     """Loss, gradients and new running statistics of the oracle's bf16-emulating train forward (`emulate="bf16"`)."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if O.is_trainable(k)}
