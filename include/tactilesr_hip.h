@@ -149,7 +149,7 @@ int tsr_pack_w2_b16k(const float* w2_64x128, void* w_packed, void* stream);
 /* Training with bf16 activation storage: a dgrad launch of tsr_conv2d_ex whose shape tsr_conv2d_ex_dgrad_b16k(nprime, cout,
  * ks) accepts may be described with nsplit = -3 instead of -1: it then runs on the same kernel (epi_mode 2, or 0 for the
  * unmasked partial gradient; no input / residual transform), with its weight packed by tsr_pack_conv_weight_dgrad_b16k
- * (arguments as tsr_pack_conv_weight_dgrad_bf16s with nprime = 128; tsr_conv_weight_b16k_elems(128, cout, ks) elements).
+ * (arguments as tsr_pack_conv_weight_dgrad_bf16s, nprime = 128 or 64; tsr_conv_weight_b16k_elems(nprime, cout, ks) elements).
  * Slab entries as for nsplit = -1 (tsr_conv2d_slab_entries_ex accepts -3 / -4).  The predicate also accepts (128, 64, 1): the
  * masked dgrad of a 1x1 conv with 64 output channels (epi_mode 2, no partial gradient) as a streaming kernel without LDS
  * (csrc/conv1x1_b16k.hip; one slab entry per workgroup: ask tsr_conv2d_slab_entries_ex with nsplit = -3).  The same nsplit = -3 runs the FORWARD launches of that shape class (C_out = 128, C_in a
@@ -161,7 +161,8 @@ int tsr_conv2d_ex_dgrad_b16k(int nprime, int cout, int ks);
  * in_shift set: relu(z * scale + shift) of the stored pre-BatchNorm tensor, formed in LDS behind the DMA): epi_mode 0 (shift =
  * bias, residual, ReLU), weights from tsr_pack_conv_weight_b16k(.., ks = 1).  csrc/conv1x1_b16k.hip. */
 int tsr_conv2d_ex_fwd1x1_b16k(int cout, int cin);
-int tsr_pack_conv_weight_dgrad_b16k(const float* w_oihw, void* w_packed, int cout, int cin, int ks, int ci0, void* stream);
+int tsr_pack_conv_weight_dgrad_b16k(const float* w_oihw, void* w_packed, int cout, int cin, int ks, int ci0, int nprime,
+                                    void* stream);
 long long tsr_conv_weight_b16k_pair_elems(int cin);
 int tsr_pack_conv_weight_b16k_pair(const float* w128_oihw5, void* w_packed, int cin, void* stream);
 int tsr_conv2d_fwd_b16k(const void* in, int in_ctot, int in_coff, int cin, const void* w_packed, int cout, int ks,

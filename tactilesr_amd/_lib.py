@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TSR_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libtactilesr_hip.so")   # override: kernel A/B experiments
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _P, _I, _F, _L = c_void_p, c_int, c_float, c_longlong
 
@@ -43,7 +43,7 @@ SIGNATURES = {
     "tsr_pack_conv_weight_b16k": [_P, _P, _I, _I, _I, _P],
     "tsr_pack_w2_b16k": [_P, _P, _P],
     "tsr_conv2d_ex_dgrad_b16k": [_I, _I, _I],
-    "tsr_pack_conv_weight_dgrad_b16k": [_P, _P, _I, _I, _I, _I, _P],
+    "tsr_pack_conv_weight_dgrad_b16k": [_P, _P, _I, _I, _I, _I, _I, _P],
     "tsr_conv_weight_b16k_pair_elems": [_I],
     "tsr_pack_conv_weight_b16k_pair": [_P, _P, _I, _P],
     "tsr_conv2d_fwd_b16k": [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -5,7 +5,7 @@
 #define TSR_VARIANT_BUILD 0
 #endif
 
-extern "C" int tsr_abi_version(void) { return 22; }
+extern "C" int tsr_abi_version(void) { return 23; }
 
 // 0 for the shipped library (`python -m tactilesr_amd.build`).  tools/build_variant.py (kernel A/B experiments, built with
 // extra -D flags) always defines TSR_VARIANT_BUILD=1: such a library reports itself here, `_lib.load()` refuses it unless

@@ -311,7 +311,7 @@ __device__ __forceinline__ void b16k_epilogue_dgrad(const ConvArgs& a, f32x4 (&a
   char* ob = (char*)a.out + ((size_t)bsafe * (a.out_ctot >> 4) + (a.out_coff >> 4)) * plane;
   const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
   const kb16x4 zero4h = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-  float* sl = a.slab + (((size_t)bid * 4 + wm) * 128 + 4 * g) * 2;
+  float* sl = a.slab + (((size_t)bid * 4 + wm) * (MT * 16) + 4 * g) * 2;
   // the stored activation and the partial gradient of a C_out tile are requested one tile ahead of its stores
   kb16x4 mv[2][NT], rv[2][NT];
 #pragma unroll
@@ -386,7 +386,7 @@ __device__ __forceinline__ void b16k_epilogue_train(const ConvArgs& a, f32x4 (&a
   const unsigned plane = (unsigned)HW * 32u;
   char* ob = (char*)a.out + ((size_t)bsafe * (a.out_ctot >> 4) + (a.out_coff >> 4)) * plane;
   const size_t e = (size_t)bid * 4 + wm;
-  float* sl = a.slab + (e * 128 + 4 * g) * 2;
+  float* sl = a.slab + (e * (MT * 16) + 4 * g) * 2;
   if (m == 0 && g == 0) a.slab_cnt[e] = cnt;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -470,8 +470,8 @@ template <int KS, int MODE> struct B16KSteps {
 
 template <int KS, int COUT, int MODE, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void conv_b16k_kernel(const ConvArgs a) {
-  static_assert(MODE == B16K_PLAIN || (COUT == 128 && (MODE == B16K_FUSED || MODE == B16K_DGRAD || MODE == B16K_TRAIN || (b16k_pair(MODE) && KS == 5))),
-                "fused / pair / dgrad / train: 128 channels");
+  static_assert(MODE == B16K_PLAIN || MODE == B16K_DGRAD || MODE == B16K_TRAIN ||
+                (COUT == 128 && (MODE == B16K_FUSED || (b16k_pair(MODE) && KS == 5))), "fused / pair: 128 channels");
   typedef B16KGeom<KS, COUT, NW> G;
   constexpr int P = KS / 2, HH = G::HH, T = G::T, MT = COUT / 16, NT = 4;
   constexpr int PIXB = G::PIXB, ROWB = G::ROWB, IMGB = G::IMGB, HALO_B = G::HALO_B, WTAP_B = G::WTAP_B;
@@ -740,11 +740,15 @@ __global__ void pack_b16k_pair_kernel(const float* __restrict__ w, __bf16* __res
 // dgrad weight of a conv with OIHW weight w[cout_f][cin_f][ks][ks]: the packed conv is W'[n][k = co][kh][kw] =
 // W[co][ci0 + n][K-1-kh][K-1-kw] (n = 0..127: the input-channel slice whose gradient the launch produces, reduction over the
 // forward conv's C_out), in conv_b16k's slab layout [co/32][tap][k group][128][8]
-__global__ void pack_b16k_dgrad_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int cout_f, int cin_f, int T, int ci0) {
-  const size_t total = (size_t)128 * cout_f * T;
+__global__ void pack_b16k_dgrad_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int cout_f, int cin_f, int T, int ci0,
+                                       int np) {
+  const size_t total = (size_t)np * cout_f * T;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int j = i & 7, n = (i >> 3) & 127, g = (i >> 10) & 3;
-    const int tap = (i >> 12) % T, kb = (i >> 12) / T;
+    const int j = i & 7;
+    size_t r = i >> 3;
+    const int n = r % np; r /= np;
+    const int g = r & 3; r >>= 2;
+    const int tap = r % T, kb = r / T;
     const int co = kb * 32 + g * 8 + j;
     wp[i] = (__bf16)w[((size_t)co * cin_f + ci0 + n) * T + (T - 1 - tap)];
   }
@@ -792,19 +796,20 @@ extern "C" int tsr_pack_conv_weight_b16k_pair(const float* w128_oihw5, void* w_p
 // or 1x1 with the forward conv's C_out = 64 (masked form only: epi_mode 2, no partial gradient)
 extern "C" int tsr_conv2d_ex_dgrad_b16k(int nprime, int cout_f, int ks) {
   if (ks == 1) return nprime == 128 && cout_f == 64;        // the masked dgrad of a 1x1 conv (conv1x1_b16k.hip)
-  return nprime == 128 && (ks == 3 || ks == 5) && cout_f > 0 && (cout_f & 31) == 0;
+  return (nprime == 128 || nprime == 64) && (ks == 3 || ks == 5) && cout_f > 0 && (cout_f & 31) == 0;
 }
 
 // 1 if tsr_conv2d_ex accepts nsplit = -3 for the FORWARD of a 1x1 conv of this shape on a virtual input (in_scale / in_shift
 // set; epi_mode 0: bias, residual, ReLU; weights from tsr_pack_conv_weight_b16k): conv1x1_b16k.hip
 extern "C" int tsr_conv2d_ex_fwd1x1_b16k(int cout, int cin) { return cout == 64 && (cin == 256 || cin == 128); }
 
-extern "C" int tsr_pack_conv_weight_dgrad_b16k(const float* w_oihw, void* w_packed, int cout, int cin, int ks, int ci0, void* stream) {
-  if (!w_oihw || !w_packed || !tsr_conv2d_ex_dgrad_b16k(128, cout, ks) || ci0 < 0 || ci0 + 128 > cin) return TSR_ERR_ARG;
-  const size_t total = (size_t)128 * cout * ks * ks;
+extern "C" int tsr_pack_conv_weight_dgrad_b16k(const float* w_oihw, void* w_packed, int cout, int cin, int ks, int ci0, int nprime,
+                                               void* stream) {
+  if (!w_oihw || !w_packed || !tsr_conv2d_ex_dgrad_b16k(nprime, cout, ks) || ci0 < 0 || ci0 + nprime > cin) return TSR_ERR_ARG;
+  const size_t total = (size_t)nprime * cout * ks * ks;
   const int grid = (int)((total + 255) / 256);
   hipLaunchKernelGGL(pack_b16k_dgrad_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, (hipStream_t)stream, w_oihw,
-                     (__bf16*)w_packed, cout, cin, ks * ks, ci0);
+                     (__bf16*)w_packed, cout, cin, ks * ks, ci0, nprime);
   return tsr_check_launch();
 }
 
@@ -822,21 +827,29 @@ int tsr_conv_b16k_ex(const ConvArgs& a, int cout, int ks, bool pair, hipStream_t
     return TSR_ERR_ARG;
   if (ks == 1) return pair ? TSR_ERR_ARG : tsr_dgrad1x1_b16k(a, st);
   if (pair) {      // nsplit = -4: conv_3_1 || conv_5_1 of an MSRB in train mode (weights: tsr_pack_conv_weight_b16k_pair)
-    if (ks != 5 || a.epi_mode != 1 || !a.slab || !a.slab_cnt) return TSR_ERR_ARG;
+    if (ks != 5 || cout != 128 || a.epi_mode != 1 || !a.slab || !a.slab_cnt) return TSR_ERR_ARG;
     B16K_LAUNCH(5, 128, B16K_PAIR_TRAIN)
     return tsr_check_launch();
   }
+#define B16K_LAUNCH_C(MODE_)                                   \
+  {                                                            \
+    if (cout == 128) {                                         \
+      if (ks == 3) B16K_LAUNCH(3, 128, MODE_)                  \
+      else B16K_LAUNCH(5, 128, MODE_)                          \
+    } else {                                                   \
+      if (ks == 3) B16K_LAUNCH(3, 64, MODE_)                   \
+      else B16K_LAUNCH(5, 64, MODE_)                           \
+    }                                                          \
+  }
   if (a.epi_mode == 2) {
-    if (ks == 3) B16K_LAUNCH(3, 128, B16K_DGRAD)
-    else B16K_LAUNCH(5, 128, B16K_DGRAD)
+    B16K_LAUNCH_C(B16K_DGRAD)
   } else if (a.epi_mode == 1) {
     if (!a.slab || !a.slab_cnt) return TSR_ERR_ARG;
-    if (ks == 3) B16K_LAUNCH(3, 128, B16K_TRAIN)
-    else B16K_LAUNCH(5, 128, B16K_TRAIN)
+    B16K_LAUNCH_C(B16K_TRAIN)
   } else {
-    if (ks == 3) B16K_LAUNCH(3, 128, B16K_PLAIN)
-    else B16K_LAUNCH(5, 128, B16K_PLAIN)
+    B16K_LAUNCH_C(B16K_PLAIN)
   }
+#undef B16K_LAUNCH_C
   return tsr_check_launch();
 }
 

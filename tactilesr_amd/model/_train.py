@@ -107,7 +107,7 @@ def _pack(w, cout, cin, ks, nsplit=0, w_amax=None):
 def _pack_dgrad(w, cout, cin, ks, ci0, nprime, nsplit=0, w_amax=None):
     if nsplit == -3:          # bf16 activation storage, the launch runs csrc/conv_b16k.hip: that kernel's slab layout
         wp = torch.empty(_lib.load().tsr_conv_weight_b16k_elems(nprime, cout, ks), dtype=torch.bfloat16, device=w.device)
-        call("tsr_pack_conv_weight_dgrad_b16k", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), _I(ci0), stream())
+        call("tsr_pack_conv_weight_dgrad_b16k", ptr(w), ptr(wp), _I(cout), _I(cin), _I(ks), _I(ci0), _I(nprime), stream())
         return wp
     if nsplit == -1:
         nsplit = 1
@@ -377,13 +377,18 @@ class TrainEngine:
         s.X = F0
         s.f1 = buf(64)
         s.F1 = Act(s.f1, 64, 0, 64, amax=new_amax())
-        w1, wis1 = self._packw(c, rb.conv1)
-        conv_ex(B=c.B, H=c.H, W=c.W, src=F0, w=w1, cout=64, ks=3, out=s.f1, out_ctot=64, out_coff=0,
-                shift=rb.conv1.bias.detach(), relu=1, nsplit=self.nsplit, w_amax=wis1, out_amax=s.F1.amax)
-        w2, wis2 = self._packw(c, rb.conv2)
-        conv_ex(B=c.B, H=c.H, W=c.W, src=s.F1, w=w2, cout=64, ks=3, out=out, out_ctot=octot,
-                out_coff=ocoff, shift=rb.conv2.bias.detach(), relu=1, res=F0, nsplit=self.nsplit,
-                w_amax=wis2, out_amax=am_o)
+        if self._b16k(64, 64, 3) and F0.scale is None:       # bf16 storage: both convs on conv_b16k's plain mode
+            (w1, wis1), (w2, wis2), nsr = (self._packw_b16k(rb.conv1), None), (self._packw_b16k(rb.conv2), None), -3
+        else:
+            w1, wis1 = self._packw(c, rb.conv1)
+            w2, wis2 = self._packw(c, rb.conv2)
+            nsr = self.nsplit
+        with self._timed(("fwd", 3, 64, 64)):
+            conv_ex(B=c.B, H=c.H, W=c.W, src=F0, w=w1, cout=64, ks=3, out=s.f1, out_ctot=64, out_coff=0,
+                    shift=rb.conv1.bias.detach(), relu=1, nsplit=nsr, w_amax=wis1, out_amax=s.F1.amax)
+            conv_ex(B=c.B, H=c.H, W=c.W, src=s.F1, w=w2, cout=64, ks=3, out=out, out_ctot=octot,
+                    out_coff=ocoff, shift=rb.conv2.bias.detach(), relu=1, res=F0, nsplit=nsr,
+                    w_amax=wis2, out_amax=am_o)
         s.Y = Act(out, octot, ocoff, 64, amax=am_o)
         return s
 
